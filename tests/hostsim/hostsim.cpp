@@ -1,0 +1,70 @@
+// TEST INFRASTRUCTURE: g++ build of the *.cuh arithmetic headers so the CPU
+// test-suite (pytest -m "not gpu") can check the exact kernel arithmetic
+// against the oracle without a GPU.  Never linked into libzklc_mi355.so.
+#include "../../zk-light-client-implementation_amd/csrc/ed25519_verify.cuh"
+#include <string.h>
+
+static ge_niels g_btab[ZKLC_ED_BTABLE];
+static int g_btab_ready = 0;
+
+extern "C" {
+
+void hostsim_fe_op(int op, const u32 *a, const u32 *b, u32 *out) {
+    fe x, y, r;
+    memcpy(x.v, a, 32);
+    memcpy(y.v, b, 32);
+    switch (op) {
+        case 0: r = fe_add(x, y); break;
+        case 1: r = fe_sub(x, y); break;
+        case 2: r = fe_mul(x, y); break;
+        case 3: r = fe_sqr(x); break;
+        case 4: r = fe_invert(x); break;
+        case 5: r = fe_pow22523(x); break;
+        case 6: r = fe_freeze(x); break;
+        case 7: r = fe_mul_small(x, b[0]); break;
+        default: r = fe_zero();
+    }
+    memcpy(out, r.v, 32);
+}
+
+void hostsim_sc_reduce512(const u32 *x, u32 *out) { sc_reduce512(out, x); }
+u32 hostsim_sc_is_canonical(const u32 *x) { return sc_is_canonical(x); }
+
+void hostsim_sha512(const uint8_t *msg, u32 len, uint8_t *out) {
+    u64 h[8];
+    sha512_hash_msg(msg, len, h);
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(h[i] >> (56 - 8 * j));
+}
+
+u32 hostsim_decompress_compress(const uint8_t *in, uint8_t *out) {
+    u32 w[8];
+    memcpy(w, in, 32);
+    ge_p3 p;
+    u32 ok = ge_decompress(p, w);
+    u32 o[8];
+    ge_compress(o, p);
+    memcpy(out, o, 32);
+    return ok;
+}
+
+void hostsim_base_table(u32 *out /*128*24 words*/) {
+    if (!g_btab_ready) {
+        for (u32 j = 1; j <= ZKLC_ED_BTABLE; j++) g_btab[j - 1] = ed25519_base_table_entry(j);
+        g_btab_ready = 1;
+    }
+    memcpy(out, g_btab, sizeof(g_btab));
+}
+
+u32 hostsim_ed25519_verify(const uint8_t *pk, const uint8_t *sig, const uint8_t *msg, u32 msg_len) {
+    if (!g_btab_ready) {
+        u32 tmp[ZKLC_ED_BTABLE * 24];
+        hostsim_base_table(tmp);
+    }
+    u32 pkw[8], sigw[16];
+    memcpy(pkw, pk, 32);
+    memcpy(sigw, sig, 64);
+    ge_cached tab[8];
+    return ed25519_verify_one(pkw, sigw, msg, msg_len, g_btab, tab);
+}
+}

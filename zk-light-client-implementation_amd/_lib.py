@@ -1,0 +1,64 @@
+"""ctypes binding of libzklc_mi355.so (the C ABI of include/zklc.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent
+this module raises, so a GPU box can never silently run something else.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libzklc_mi355.so")
+
+_u8p = ctypes.c_void_p
+_SIGS = {
+    "zklc_init": (ctypes.c_int32, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32]),
+    "zklc_destroy": (None, [ctypes.c_void_p]),
+    "zklc_strerror": (ctypes.c_char_p, [ctypes.c_int32]),
+    "zklc_last_hip_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "zklc_synchronize": (ctypes.c_int32, [ctypes.c_void_p]),
+    "zklc_abi_version": (ctypes.c_uint32, []),
+    "zklc_ed25519_verify_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, _u8p, ctypes.c_uint32, ctypes.c_uint32,
+                                                   ctypes.c_uint32, _u8p]),
+    "zklc_ed25519_verify_batch_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, _u8p, _u8p, ctypes.c_uint32,
+                                                       ctypes.c_uint32, ctypes.c_uint32, _u8p]),
+    "zklc_sha512_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _u8p]),
+    "zklc_sha512_batch_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint32, ctypes.c_uint32,
+                                               ctypes.c_uint32, _u8p]),
+}
+
+_lib = None
+
+
+class ZklcError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        super().__init__("zklc status %d: %s%s" % (code, _strerror(code), (" [" + detail + "]") if detail else ""))
+
+
+def _strerror(code):
+    try:
+        return load().zklc_strerror(code).decode()
+    except Exception:  # pragma: no cover
+        return "?"
+
+
+def load():
+    """Load the shared library and bind every declared symbol (raises if any is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libzklc_mi355.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
+            "there is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def declared_symbols():
+    return sorted(_SIGS)

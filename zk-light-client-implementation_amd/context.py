@@ -1,0 +1,120 @@
+"""Thin object wrapper over the zklc C ABI (include/zklc.h)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _host_u8(x, name):
+    """bytes / bytearray / numpy -> contiguous uint8 numpy array (no copy when possible)."""
+    if isinstance(x, (bytes, bytearray, memoryview)):
+        return np.frombuffer(x, dtype=np.uint8)
+    a = np.ascontiguousarray(x)
+    if a.dtype != np.uint8:
+        raise TypeError("%s must be uint8" % name)
+    return a.reshape(-1)
+
+
+class Context:
+    """One zklc_ctx: a device, a stream, staging buffers and constant tables."""
+
+    def __init__(self, device_id=0):
+        self._lib = _lib.load()
+        h = ctypes.c_void_p()
+        rc = self._lib.zklc_init(ctypes.byref(h), int(device_id))
+        if rc != 0:
+            raise _lib.ZklcError(rc)
+        self._h = h
+        self.device_id = int(device_id)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.zklc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise _lib.ZklcError(rc, self._lib.zklc_last_hip_error(self._h).decode())
+
+    def synchronize(self):
+        self._check(self._lib.zklc_synchronize(self._h))
+
+    # ---- (a) Ed25519 ---------------------------------------------------
+    def ed25519_verify_batch(self, pks, sigs, msg, msg_stride=0, msg_len=None):
+        """Host-pointer path.  pks: n*32 bytes, sigs: n*64 bytes, msg: shared
+        message (msg_stride=0) or n messages of msg_len bytes at msg_stride.
+        Returns a uint8 numpy array of n 0/1 flags."""
+        pk = _host_u8(pks, "pks")
+        sg = _host_u8(sigs, "sigs")
+        if pk.size % 32 or sg.size != (pk.size // 32) * 64:
+            raise ValueError("pks must be n*32 bytes and sigs n*64 bytes")
+        n = pk.size // 32
+        m = _host_u8(msg, "msg")
+        if msg_len is None:
+            if msg_stride:
+                raise ValueError("msg_len required with msg_stride")
+            msg_len = m.size
+        need = msg_len if not msg_stride else (msg_stride * n)
+        if m.size < need:
+            raise ValueError("message buffer too small")
+        ok = np.zeros(n, dtype=np.uint8)
+        self._check(self._lib.zklc_ed25519_verify_batch(
+            self._h, pk.ctypes.data, sg.ctypes.data, m.ctypes.data if m.size else None, msg_len, msg_stride, n,
+            ok.ctypes.data))
+        return ok
+
+    def ed25519_verify_batch_dev(self, d_pks, d_sigs, d_msgs, msg_len, msg_stride, n, d_ok, stream=None):
+        """Device-pointer path: torch uint8 CUDA tensors (or raw int pointers); enqueue only."""
+        self._check(self._lib.zklc_ed25519_verify_batch_dev(
+            self._h, _stream_ptr(stream), _dev_ptr(d_pks), _dev_ptr(d_sigs), _dev_ptr(d_msgs), msg_len, msg_stride, n,
+            _dev_ptr(d_ok)))
+
+    def sha512_batch(self, data, stride, length, n):
+        d = _host_u8(data, "data")
+        if n and d.size < stride * (n - 1) + length:
+            raise ValueError("input buffer too small")
+        out = np.zeros((n, 64), dtype=np.uint8)
+        self._check(self._lib.zklc_sha512_batch(self._h, d.ctypes.data if d.size else None, stride, length, n,
+                                                out.ctypes.data))
+        return out
+
+    def sha512_batch_dev(self, d_in, stride, length, n, d_out, stream=None):
+        self._check(self._lib.zklc_sha512_batch_dev(self._h, _stream_ptr(stream), _dev_ptr(d_in), stride, length, n,
+                                                    _dev_ptr(d_out)))
+
+
+def _dev_ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    if _is_torch(t):
+        if not t.is_cuda or not t.is_contiguous():
+            raise ValueError("device tensors must be contiguous CUDA tensors")
+        return t.data_ptr()
+    raise TypeError("expected a CUDA tensor or an integer device pointer")
+
+
+def _stream_ptr(s):
+    if s is None:
+        return None
+    if isinstance(s, int):
+        return s
+    return s.cuda_stream  # torch.cuda.Stream

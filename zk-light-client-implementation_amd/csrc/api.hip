@@ -1,0 +1,74 @@
+// Context management for libzklc_mi355.so (C ABI declared in include/zklc.h).
+#include "zklc_internal.h"
+#include <new>
+
+int32_t zklc_stage(zklc_ctx *ctx, int slot, size_t bytes, void **out) {
+    zklc_devbuf &b = ctx->stage[slot];
+    if (b.cap < bytes) {
+        if (b.p) {
+            ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ZKLC_HIP(ctx, hipFree(b.p));
+            b.p = nullptr;
+            b.cap = 0;
+        }
+        size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes;
+        ZKLC_HIP(ctx, hipMalloc(&b.p, cap));
+        b.cap = cap;
+    }
+    *out = b.p;
+    return ZKLC_OK;
+}
+
+extern "C" uint32_t zklc_abi_version(void) { return 1; }
+
+extern "C" const char *zklc_strerror(int32_t code) {
+    switch (code) {
+        case ZKLC_OK: return "ok";
+        case ZKLC_ERR_INVALID_ARG: return "invalid argument";
+        case ZKLC_ERR_OOM: return "out of device memory";
+        case ZKLC_ERR_HIP: return "HIP runtime error (see zklc_last_hip_error)";
+        case ZKLC_ERR_NO_DEVICE: return "no usable gfx950 device";
+        default: return "unknown zklc status";
+    }
+}
+
+extern "C" const char *zklc_last_hip_error(zklc_ctx *ctx) { return ctx ? ctx->last_err.c_str() : ""; }
+
+extern "C" int32_t zklc_init(zklc_ctx **out, int32_t device_id) {
+    if (!out || device_id < 0) return ZKLC_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return ZKLC_ERR_NO_DEVICE;
+    if (device_id >= count) return ZKLC_ERR_INVALID_ARG;
+    zklc_ctx *ctx = new (std::nothrow) zklc_ctx();
+    if (!ctx) return ZKLC_ERR_OOM;
+    ctx->device = device_id;
+    int32_t rc = ZKLC_OK;
+    auto fail = [&](int32_t code) {
+        zklc_destroy(ctx);
+        return code;
+    };
+    if (hipSetDevice(device_id) != hipSuccess) return fail(ZKLC_ERR_NO_DEVICE);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(ZKLC_ERR_HIP);
+    if ((rc = zklc_ed25519_init(ctx))) return fail(rc);
+    *out = ctx;
+    return ZKLC_OK;
+}
+
+extern "C" void zklc_destroy(zklc_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    zklc_ed25519_fini(ctx);
+    for (auto &b : ctx->stage)
+        if (b.p) (void)hipFree(b.p);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int32_t zklc_synchronize(zklc_ctx *ctx) {
+    if (!ctx) return ZKLC_ERR_INVALID_ARG;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKLC_OK;
+}

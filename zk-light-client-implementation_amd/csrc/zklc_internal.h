@@ -1,0 +1,40 @@
+// Internal context shared by the translation units of libzklc_mi355.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include "../../include/zklc.h"
+
+struct zklc_devbuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct zklc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_err;
+    // Ed25519: 128 affine-niels multiples of the base point (12 KiB)
+    void *ed_btab = nullptr;
+    int ed_variant = 0;  // index into the compiled verify-kernel variants
+    // grow-only staging buffers for the host-pointer entry points
+    zklc_devbuf stage[8];
+};
+
+#define ZKLC_HIP(ctx, call)                                           \
+    do {                                                              \
+        hipError_t e__ = (call);                                      \
+        if (e__ != hipSuccess) {                                      \
+            (ctx)->last_err = std::string(#call) + ": " + hipGetErrorString(e__); \
+            return e__ == hipErrorOutOfMemory ? ZKLC_ERR_OOM : ZKLC_ERR_HIP;      \
+        }                                                             \
+    } while (0)
+
+// returns a device buffer of at least `bytes` in slot `slot`
+int32_t zklc_stage(zklc_ctx *ctx, int slot, size_t bytes, void **out);
+inline hipStream_t zklc_pick_stream(zklc_ctx *ctx, void *s) { return s ? (hipStream_t)s : ctx->stream; }
+
+// subsystem initialisers (called by zklc_init)
+int32_t zklc_ed25519_init(zklc_ctx *ctx);
+void zklc_ed25519_fini(zklc_ctx *ctx);

@@ -1,0 +1,86 @@
+"""Host-side mirror of the reference's approval pre-verification.
+
+Reference: near_bft_finality/src/prove_block_data/signatures.rs
+  * generate_signed_message            :24-39
+  * the loop of prove_approvals        :56-123  (native `sig.verify` :79, the
+    `valid_keys` layout :107-112, the stake accounting :59-68,113-118,
+    `panic!` on an invalid signature :119-121)
+and the byte layout constants of near_bft_finality/src/types.rs:7-17.
+
+What the reference does one signature at a time on the CPU is done here as
+ONE batched launch of the gfx950 Ed25519 kernel (Context.ed25519_verify_batch).
+Proof generation (ed25519_proof_reuse_circuit / recursive_proof) is not part
+of this function; it consumes the same (msg, sig, pk) triples.
+"""
+import numpy as np
+
+TYPE_BYTE = 1
+STAKE_BYTES = 16
+PK_HASH_BYTES = 32
+SIG_BYTES = 64
+
+
+class InvalidSignature(Exception):
+    """The reference panics ("Invalid signature.") -- signatures.rs:119-121."""
+
+    def __init__(self, positions):
+        self.positions = list(positions)
+        super().__init__("Invalid signature at approval position(s) %s" % self.positions)
+
+
+def generate_signed_message(ch_height: int, nb_height: int, nb_prev_hash: bytes) -> bytes:
+    """Approval::get_data_for_sig: borsh(ApprovalInner) || le64(nb_height)."""
+    if len(nb_prev_hash) != 32:
+        raise ValueError("prev hash must be 32 bytes")
+    if ch_height + 1 == nb_height:
+        inner = b"\x00" + bytes(nb_prev_hash)  # Endorsement(prev_hash)
+    else:
+        inner = b"\x01" + int(ch_height).to_bytes(8, "little")  # Skip(height)
+    return inner + int(nb_height).to_bytes(8, "little")
+
+
+def slice_approvals(approvals, validators):
+    """The borsh slicing of signatures.rs:72-86: returns (positions, pks[n,32], sigs[n,64])."""
+    if len(approvals) != len(validators):
+        raise ValueError("approvals and validators must have the same length")  # assert_eq! :56
+    pos, pks, sigs = [], [], []
+    for i, (ap, va) in enumerate(zip(approvals, validators)):
+        if len(ap) == SIG_BYTES + 2 * TYPE_BYTE:  # Option tag + key type + 64-byte signature
+            vl = len(va)
+            if vl < STAKE_BYTES + PK_HASH_BYTES + TYPE_BYTE:
+                raise ValueError("validator %d: borsh ValidatorStake too short" % i)
+            if ap[0] != 1 or ap[1] != 0 or va[vl - STAKE_BYTES - PK_HASH_BYTES - TYPE_BYTE] != 0:
+                raise ValueError("entry %d: only ED25519 keys/signatures are supported" % i)
+            pos.append(i)
+            sigs.append(bytes(ap[2:]))
+            pks.append(bytes(va[vl - STAKE_BYTES - PK_HASH_BYTES:vl - STAKE_BYTES]))
+    pk_arr = np.frombuffer(b"".join(pks), dtype=np.uint8).reshape(-1, 32) if pks else np.zeros((0, 32), np.uint8)
+    sg_arr = np.frombuffer(b"".join(sigs), dtype=np.uint8).reshape(-1, 64) if sigs else np.zeros((0, 64), np.uint8)
+    return pos, pk_arr, sg_arr
+
+
+def verify_approvals(ctx, msg, approvals, validators, strict=True):
+    """Batched form of the pre-check loop of prove_approvals.
+
+    Returns (valid_keys, valid_positions, valid_stake, total_stake) where
+    valid_keys = concat(pos as u8 || pk[32]) exactly as signatures.rs:107-112.
+    strict=True raises InvalidSignature like the reference's panic; with
+    strict=False invalid entries are simply left out.
+    """
+    pos, pks, sigs = slice_approvals(approvals, validators)
+    total_stake = sum(int.from_bytes(bytes(v[len(v) - STAKE_BYTES:]), "little") for v in validators)
+    ok = ctx.ed25519_verify_batch(pks, sigs, msg) if pos else np.zeros(0, np.uint8)
+    bad = [p for p, o in zip(pos, ok) if not o]
+    if bad and strict:
+        raise InvalidSignature(bad)
+    valid_keys = bytearray()
+    valid_pos = []
+    valid_stake = 0
+    for p, o, pk in zip(pos, ok, pks):
+        if o:
+            valid_keys.append(p & 0xFF)  # `pos as u8` (signatures.rs:107)
+            valid_keys += pk.tobytes()
+            valid_pos.append(p)
+            v = validators[p]
+            valid_stake += int.from_bytes(bytes(v[len(v) - STAKE_BYTES:]), "little")
+    return bytes(valid_keys), valid_pos, valid_stake, total_stake
