@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- hot-path benchmark of the MI355X zk-light-client backend.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], "C2"): the batched Ed25519 pre-verification
+of Block_i approval sets of the 100-validator shape
+(near_bft_finality/src/prove_block_data/signatures.rs:70-123).  One STEP = one
+launch of the verify kernel over `--blocks` Block_i approval sets (default 8192
+blocks x 100 validators = 819,200 signatures per GPU, every block with its own
+41-byte Approval message, 1 % of the signatures corrupted), inputs resident in
+HBM.  Multi-GPU: every rank verifies its own shard of blocks (weak scaling, no
+data-path collective -- the approval sets of different blocks are independent).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement)
+including `roofline` (HBM, algorithmic bytes 97 B/signature) and `cpu_baseline`
+(the oracle's C restatement on the host cores; kind = "port").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+VALIDATORS = 100          # C2: data/validators_ordered.json has 100 entries
+BASE_BLOCKS = 4           # distinct signed blocks generated on the host, tiled on the device
+MSG_LEN, MSG_STRIDE = 41, 48
+BYTES_PER_SIG = 97        # 32 pk + 64 sig + 1 result (message amortised)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def make_base_set():
+    """100 synthetic validators (SURVEY 8(d) C2 key derivation) signing BASE_BLOCKS
+    different Endorsement messages.  Signing uses the oracle (host, untimed)."""
+    from oracle import ed25519_ref as ref
+    import hashlib
+    keys = [ref.synthetic_seed(1, i) for i in range(VALIDATORS)]
+    pks = [ref.keypair(k)[2] for k in keys]
+    pk_rows, sig_rows, msg_rows = [], [], []
+    for b in range(BASE_BLOCKS):
+        prev_hash = hashlib.sha256(b"zklc/bench/block" + bytes([b])).digest()
+        msg = ref.generate_signed_message(105971806 + b, 105971807 + b, prev_hash)
+        assert len(msg) == MSG_LEN
+        for v in range(VALIDATORS):
+            pk_rows.append(pks[v])
+            sig_rows.append(ref.sign(keys[v], msg))
+            msg_rows.append(msg + bytes(MSG_STRIDE - MSG_LEN))
+    n = len(pk_rows)
+    return (np.frombuffer(b"".join(pk_rows), np.uint8).reshape(n, 32).copy(),
+            np.frombuffer(b"".join(sig_rows), np.uint8).reshape(n, 64).copy(),
+            np.frombuffer(b"".join(msg_rows), np.uint8).reshape(n, MSG_STRIDE).copy())
+
+
+def cpu_baseline(pk, sg, ms, budget_s=12.0):
+    """Oracle C restatement (oracle/c/ed25519_oracle.c) on all host cores, bounded sample."""
+    from oracle import cport
+    threads = os.cpu_count() or 1
+    reps = 20
+    pkb, sgb, msb = np.tile(pk, (reps, 1)), np.tile(sg, (reps, 1)), np.tile(ms, (reps, 1))
+    n = pkb.shape[0]
+    cport.ed25519_verify_batch(pkb[:256], sgb[:256], msb[:256], MSG_LEN, MSG_STRIDE, 256, nthreads=threads)  # warm
+    done, t0 = 0, time.perf_counter()
+    while True:
+        ok, used = cport.ed25519_verify_batch(pkb, sgb, msb, MSG_LEN, MSG_STRIDE, n, nthreads=threads)
+        assert int(ok.sum()) == n
+        done += n
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    return {"value": done / dt, "unit": "sig/s", "cores": used, "kind": "port",
+            "sample": "%d signatures (the bench's %d-signature base set repeated), oracle/c/ed25519_oracle.c, "
+                      "gcc -O3 -fopenmp, %.1f s" % (done, pk.shape[0], dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--blocks", type=int, default=8192, help="Block_i approval sets per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import zklc_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pk, sg, ms = make_base_set()
+    base_n = pk.shape[0]
+    reps = (args.blocks + BASE_BLOCKS - 1) // BASE_BLOCKS
+    n = reps * base_n
+    dev = torch.device("cuda", local_rank)
+    d_pk = torch.from_numpy(pk).to(dev).repeat(reps, 1).contiguous()
+    d_sg = torch.from_numpy(sg).to(dev).repeat(reps, 1).contiguous()
+    d_ms = torch.from_numpy(ms).to(dev).repeat(reps, 1).contiguous()
+    # 1 % corrupted: flip one bit of signature i (i % 100 == rank-dependent offset)
+    bad = torch.arange((7 + rank) % 100, n, 100, device=dev)
+    d_sg[bad, (bad % 64)] ^= 1
+    d_ok = torch.zeros(n, dtype=torch.uint8, device=dev)
+    expect = torch.ones(n, dtype=torch.uint8, device=dev)
+    expect[bad] = 0
+
+    ctx = zklc_amd.Context(local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    stream.wait_stream(torch.cuda.current_stream())
+
+    def step():
+        ctx.ed25519_verify_batch_dev(d_pk, d_sg, d_ms, MSG_LEN, MSG_STRIDE, n, d_ok, stream=stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        step()
+        b.record(stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+
+    # results are checked after the timed region (all GPUs)
+    assert torch.equal(d_ok, expect), "rank %d: GPU bitmap differs from the expected validity pattern" % rank
+    n_valid = int(d_ok.sum())
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+        c = torch.tensor([n_valid], device=dev, dtype=torch.int64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        n_valid = int(c[0])
+
+    if rank == 0:
+        total = n * world
+        value = total * args.steps / elapsed
+        achieved = BYTES_PER_SIG * n / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Block_i approval-signature verifications/s (100-validator Ed25519 batch, stage (a) of the "
+                      "BFT-finality proof path)",
+            "value": value, "unit": "sig/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "C2: batched Ed25519 verify, %d Block_i approval sets x %d validators per GPU per step "
+                                   "(%d signatures, 41-byte per-block message, 1%% corrupted)" % (n // VALIDATORS, VALIDATORS, n),
+                       "signatures_per_gpu": n, "blocks_per_s": value / VALIDATORS, "valid": n_valid,
+                       "kernel_variant": int(os.environ.get("ZKLC_ED_VARIANT", "0"))},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ed25519_verify_kernel", "kernel_ms": kernel_ms,
+                         "note": "algorithmic bytes = 97 B/signature; the kernel is integer-VALU-bound "
+                                 "(~1e6 lane-instructions per signature), see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pk, sg, ms)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,8 +8,9 @@
  *
  * Conventions
  *   - all integers little-endian; status = int32_t, 0 = ZKLC_OK, negative = error
- *   - `*_dev` entry points take DEVICE pointers plus a hipStream_t (as void*,
- *     NULL = the context's own stream) and only enqueue work;
+ *   - `*_dev` entry points take DEVICE pointers plus a hipStream_t (as void*;
+ *     NULL = HIP's legacy default stream, as everywhere in HIP) and only
+ *     enqueue work on that stream;
  *     the plain entry points take caller-owned HOST pointers, stage through the
  *     context's device buffers and return after the result is on the host.
  *   - never aborts, never unwinds across the boundary; re-entrant per context

@@ -21,16 +21,17 @@ for n in [100, 1 << 14, 1 << 18, 1 << 20]:
     for v in range(4):
         os.environ["ZKLC_ED_VARIANT"] = str(v)
         with zklc_amd.Context(0) as c:
-            st = torch.cuda.current_stream()
+            st = torch.cuda.Stream()
+            st.wait_stream(torch.cuda.current_stream())
             c.ed25519_verify_batch_dev(pk, sg, m, len(msg), 0, n, ok, stream=st)
             torch.cuda.synchronize()
             assert int(ok.sum()) == n
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             iters = 3 if n >= (1 << 18) else 10
-            e0.record()
+            e0.record(st)
             for _ in range(iters):
                 c.ed25519_verify_batch_dev(pk, sg, m, len(msg), 0, n, ok, stream=st)
-            e1.record()
+            e1.record(st)
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / iters
             print("n=%8d variant=%d  %.3f ms  %.3f Msig/s" % (n, v, ms, n / ms / 1e3), flush=True)

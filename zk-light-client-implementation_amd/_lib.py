@@ -51,6 +51,13 @@ def load():
         raise ImportError(
             "libzklc_mi355.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
             "there is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7; importing
+    # torch first makes the dynamic loader resolve our NEEDED entry to that copy, so
+    # torch tensors, streams and RCCL share a runtime with the zklc kernels.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover - torch is plumbing, not a dependency of the ABI
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -33,7 +33,8 @@ struct zklc_ctx {
 
 // returns a device buffer of at least `bytes` in slot `slot`
 int32_t zklc_stage(zklc_ctx *ctx, int slot, size_t bytes, void **out);
-inline hipStream_t zklc_pick_stream(zklc_ctx *ctx, void *s) { return s ? (hipStream_t)s : ctx->stream; }
+// *_dev entry points launch on exactly the hipStream_t they are given (NULL = the legacy default stream)
+inline hipStream_t zklc_pick_stream(zklc_ctx *, void *s) { return (hipStream_t)s; }
 
 // subsystem initialisers (called by zklc_init)
 int32_t zklc_ed25519_init(zklc_ctx *ctx);
