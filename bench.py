@@ -59,10 +59,32 @@ def make_base_set():
             np.frombuffer(b"".join(msg_rows), np.uint8).reshape(n, MSG_STRIDE).copy())
 
 
+def host_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def pmc_traffic(n):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot read
+    hardware counters itself); None when the profile was taken at another batch size."""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "ed25519_pmc_latest.json")))
+        return j["hbm_bytes_per_launch"] if j["signatures"] == n else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def cpu_baseline(pk, sg, ms, budget_s=12.0):
     """Oracle C restatement (oracle/c/ed25519_oracle.c) on all host cores, bounded sample."""
     from oracle import cport
-    threads = os.cpu_count() or 1
+    threads = host_cores()
     reps = 20
     pkb, sgb, msb = np.tile(pk, (reps, 1)), np.tile(sg, (reps, 1)), np.tile(ms, (reps, 1))
     n = pkb.shape[0]
@@ -166,12 +188,13 @@ def main():
             "config": {"workload": "C2: batched Ed25519 verify, %d Block_i approval sets x %d validators per GPU per step "
                                    "(%d signatures, 41-byte per-block message, 1%% corrupted)" % (n // VALIDATORS, VALIDATORS, n),
                        "signatures_per_gpu": n, "blocks_per_s": value / VALIDATORS, "valid": n_valid,
-                       "kernel_variant": int(os.environ.get("ZKLC_ED_VARIANT", "0"))},
+                       "kernel_variant": int(os.environ.get("ZKLC_ED_VARIANT", "1"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n),
                          "kernel": "ed25519_verify_kernel", "kernel_ms": kernel_ms,
-                         "note": "algorithmic bytes = 97 B/signature; the kernel is integer-VALU-bound "
-                                 "(~1e6 lane-instructions per signature), see DESIGN.md"},
+                         "note": "algorithmic bytes = 97 B/signature; traffic = HBM bytes per launch from "
+                                 "profiles/ed25519_pmc_latest.json (2*FETCH_SIZE + WRITE_SIZE); the kernel is "
+                                 "integer-VALU-bound (~6e5 lane-instructions per signature), see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pk, sg, ms)

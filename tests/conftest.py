@@ -46,7 +46,7 @@ def hostsim():
             for f in os.listdir(os.path.join(ROOT, "zk-light-client-implementation_amd", "csrc")) if f.endswith(".cuh")]
     newest = max(os.path.getmtime(p) for p in [src] + hdrs)
     if not os.path.exists(so) or os.path.getmtime(so) < newest:
-        subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-o", so, src])
+        subprocess.check_call(["g++", "-O2", "-DZKLC_FE_BOUND_CHECKS", "-shared", "-fPIC", "-o", so, src])
     return ctypes.CDLL(so)
 
 

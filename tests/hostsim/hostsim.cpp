@@ -10,9 +10,7 @@ static int g_btab_ready = 0;
 extern "C" {
 
 void hostsim_fe_op(int op, const u32 *a, const u32 *b, u32 *out) {
-    fe x, y, r;
-    memcpy(x.v, a, 32);
-    memcpy(y.v, b, 32);
+    fe x = fe_from_words(a), y = fe_from_words(b), r;  // inputs < 2^255
     switch (op) {
         case 0: r = fe_add(x, y); break;
         case 1: r = fe_sub(x, y); break;
@@ -21,10 +19,15 @@ void hostsim_fe_op(int op, const u32 *a, const u32 *b, u32 *out) {
         case 4: r = fe_invert(x); break;
         case 5: r = fe_pow22523(x); break;
         case 6: r = fe_freeze(x); break;
-        case 7: r = fe_mul_small(x, b[0]); break;
+        case 7: r = fe_sqr2(x); break;
+        case 8: {  // three-term lazy inputs built from REDUCED values
+            fe xr = fe_mul(x, fe_one()), yr = fe_mul(y, fe_one());
+            r = fe_mul(fe_add(fe_add(xr, yr), xr), fe_sub(fe_sub(yr, xr), xr));
+            break;
+        }
         default: r = fe_zero();
     }
-    memcpy(out, r.v, 32);
+    fe_freeze_words(out, r);  // canonical
 }
 
 void hostsim_sc_reduce512(const u32 *x, u32 *out) { sc_reduce512(out, x); }
@@ -48,7 +51,7 @@ u32 hostsim_decompress_compress(const uint8_t *in, uint8_t *out) {
     return ok;
 }
 
-void hostsim_base_table(u32 *out /*128*24 words*/) {
+void hostsim_base_table(u32 *out /*128*30 words*/) {
     if (!g_btab_ready) {
         for (u32 j = 1; j <= ZKLC_ED_BTABLE; j++) g_btab[j - 1] = ed25519_base_table_entry(j);
         g_btab_ready = 1;
@@ -58,13 +61,13 @@ void hostsim_base_table(u32 *out /*128*24 words*/) {
 
 u32 hostsim_ed25519_verify(const uint8_t *pk, const uint8_t *sig, const uint8_t *msg, u32 msg_len) {
     if (!g_btab_ready) {
-        u32 tmp[ZKLC_ED_BTABLE * 24];
+        u32 tmp[ZKLC_ED_BTABLE * 30];
         hostsim_base_table(tmp);
     }
     u32 pkw[8], sigw[16];
     memcpy(pkw, pk, 32);
     memcpy(sigw, sig, 64);
-    ge_cached tab[8];
-    return ed25519_verify_one(pkw, sigw, msg, msg_len, g_btab, tab);
+    i32 tab[ZKLC_ED_ATAB_WORDS];
+    return ed25519_verify_one<1>(pkw, sigw, msg, msg_len, g_btab, tab);
 }
 }

@@ -25,20 +25,21 @@ def _fe_op(lib, op, a, b=0):
 
 def test_field_ops(hostsim):
     rng = random.Random(1)
-    edge = [0, 1, 2, 19, 38, P - 1, P, P + 1, 2 * P - 1, 2 * P, 2 * P + 1, 2**256 - 1, 2**256 - 38, 2**256 - 39,
-            2**255 - 1, 2**255, 2**255 + 18, 2**255 + 19]
-    vals = edge + [rng.getrandbits(256) for _ in range(120)]
+    M = 2**255
+    edge = [0, 1, 2, 19, 38, P - 1, P, P + 1, M - 1, M - 19, M - 20, 2**254, 2**26 - 1, 2**51 - 1, (1 << 230) - 1]
+    vals = edge + [rng.getrandbits(255) for _ in range(150)]
     for a in vals:
-        for b in rng.sample(vals, 8) + edge[:6] + [2**256 - 1]:
-            assert _fe_op(hostsim, 0, a, b) % P == (a + b) % P
-            assert _fe_op(hostsim, 1, a, b) % P == (a - b) % P
-            assert _fe_op(hostsim, 2, a, b) % P == (a * b) % P
-            assert _fe_op(hostsim, 7, a, b & 0xFFFFFFFF) % P == (a * (b & 0xFFFFFFFF)) % P
-        assert _fe_op(hostsim, 3, a) % P == a * a % P
+        for b in rng.sample(vals, 8) + edge[:6] + [M - 1]:
+            assert _fe_op(hostsim, 0, a, b) == (a + b) % P
+            assert _fe_op(hostsim, 1, a, b) == (a - b) % P
+            assert _fe_op(hostsim, 2, a, b) == (a * b) % P
+            assert _fe_op(hostsim, 8, a, b) == ((2 * a + b) * (b - 2 * a)) % P
+        assert _fe_op(hostsim, 3, a) == a * a % P
+        assert _fe_op(hostsim, 7, a) == 2 * a * a % P
         assert _fe_op(hostsim, 6, a) == a % P
     for a in vals[:40]:
-        assert _fe_op(hostsim, 4, a) % P == pow(a, P - 2, P)
-        assert _fe_op(hostsim, 5, a) % P == pow(a, (P - 5) // 8, P)
+        assert _fe_op(hostsim, 4, a) == pow(a, P - 2, P)
+        assert _fe_op(hostsim, 5, a) == pow(a, (P - 5) // 8, P)
 
 
 def test_scalar_reduce(hostsim):
@@ -63,13 +64,18 @@ def test_sha512(hostsim):
 
 
 def test_base_table(hostsim):
-    T = (ctypes.c_uint32 * (128 * 24))()
+    T = (ctypes.c_uint32 * (128 * 30))()
     hostsim.hostsim_base_table(T)
-    fe = lambda i: sum(T[i + k] << (32 * k) for k in range(8))
+    def fe(i):  # ten radix-2^25.5 limbs
+        v, pos = 0, 0
+        for k in range(10):
+            v += T[i + k] << pos
+            pos += 26 if k % 2 == 0 else 25
+        return v
     for j in [1, 2, 3, 7, 64, 127, 128]:
         x, y = ref.pt_affine(ref.pt_mul(j, ref.BASE))
-        o = (j - 1) * 24
-        assert (fe(o), fe(o + 8), fe(o + 16)) == ((y + x) % P, (y - x) % P, 2 * ref.D * x * y % P)
+        o = (j - 1) * 30
+        assert (fe(o), fe(o + 10), fe(o + 20)) == ((y + x) % P, (y - x) % P, 2 * ref.D * x * y % P)
 
 
 @pytest.mark.parametrize("name", near_sets())

@@ -6,6 +6,7 @@
 // the arithmetic against the oracle without a GPU).  There is no CPU product
 // path: the C ABI in zklc_api.hip launches HIP kernels and nothing else.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 #if defined(__HIPCC__)

@@ -40,7 +40,9 @@ sha512_batch_kernel(const uint8_t *__restrict__ in, u32 stride, u32 len, u32 n, 
 
 int32_t zklc_ed25519_init(zklc_ctx *ctx) {
     // tuning knob: which compiled variant of the verify kernel to launch
-    ctx->ed_variant = 0;
+    // 0: W=3 table, field ops as calls   1: W=3, field ops inlined (default, fastest: profiles/r01_ed25519_variants_v2.txt)
+    // 2: W=2 table (8 waves/CU), inlined  3: W=2, calls
+    ctx->ed_variant = 1;
     if (const char *e = getenv("ZKLC_ED_VARIANT")) {
         int v = atoi(e);
         if (v >= 0 && v < ZKLC_ED_NVARIANTS) ctx->ed_variant = v;

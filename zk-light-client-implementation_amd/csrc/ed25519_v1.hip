@@ -2,6 +2,6 @@
 // run time by zklc_ctx::ed_variant / env ZKLC_ED_VARIANT).
 #define ZKLC_ED_VARIANT_ID 1
 #define ZKLC_ED_BLOCK 64
-#define ZKLC_ED_MINW 2
-#define ZKLC_FE_MUL_IMPL 0
+#define ZKLC_ED_MINW 1
+#define ZKLC_FE_INLINE 1
 #include "ed25519_kernels.inc"

@@ -39,30 +39,27 @@ ZKLC_HD ge_cached ge_to_cached(const ge_p3 &p) {
     return c;
 }
 
-// dbl-2008-hwcd
-template <bool WANT_T>
-ZKLC_HD ge_p3 ge_double(const ge_p3 &p) {
+// dbl-2008-hwcd.  want_t (wave-uniform) = the next operation is an addition and
+// needs T; a following doubling does not.
+ZKLC_HD ge_p3 ge_double(const ge_p3 &p, bool want_t) {
     fe A = fe_sqr(p.X);
     fe B = fe_sqr(p.Y);
-    fe ZZ = fe_sqr(p.Z);
-    fe C = fe_add(ZZ, ZZ);
-    fe xy = fe_add(p.X, p.Y);
-    fe E = fe_sub(fe_sub(fe_sqr(xy), A), B);  // 2XY
-    fe G = fe_sub(B, A);                      // D + B with D = -A
+    fe C = fe_sqr2(p.Z);                                   // 2 Z^2, reduced
+    fe E = fe_sub(fe_sub(fe_sqr(fe_add(p.X, p.Y)), A), B);  // 2XY
+    fe G = fe_sub(B, A);                                   // D + B with D = -A
     fe F = fe_sub(G, C);
     fe H = fe_sub(fe_neg(A), B);  // D - B
     ge_p3 r;
     r.X = fe_mul(E, F);
     r.Y = fe_mul(G, H);
     r.Z = fe_mul(F, G);
-    if (WANT_T) r.T = fe_mul(E, H);
+    if (want_t) r.T = fe_mul(E, H);
     else r.T = fe_zero();
     return r;
 }
 
 // add-2008-hwcd-3 with a cached second operand; neg=1 adds -q
-template <bool WANT_T>
-ZKLC_HD ge_p3 ge_add_cached(const ge_p3 &p, const ge_cached &q, u32 neg) {
+ZKLC_HD ge_p3 ge_add_cached(const ge_p3 &p, const ge_cached &q, u32 neg, bool want_t) {
     fe qa = fe_select(q.YmX, q.YpX, neg);  // (Y2-X2) or, for -q, (Y2+X2)
     fe qb = fe_select(q.YpX, q.YmX, neg);
     fe A = fe_mul(fe_sub(p.Y, p.X), qa);
@@ -79,15 +76,13 @@ ZKLC_HD ge_p3 ge_add_cached(const ge_p3 &p, const ge_cached &q, u32 neg) {
     r.X = fe_mul(E, F);
     r.Y = fe_mul(G, H);
     r.Z = fe_mul(F, G);
-    if (WANT_T) r.T = fe_mul(E, H);
+    if (want_t) r.T = fe_mul(E, H);
     else r.T = fe_zero();
     return r;
 }
 
-// mixed addition with an affine-niels operand (Z2 = 1); neg=1 adds -q;
-// zero=1 adds the identity (niels identity = (1, 1, 0))
-template <bool WANT_T>
-ZKLC_HD ge_p3 ge_add_niels(const ge_p3 &p, const ge_niels &q, u32 neg) {
+// mixed addition with an affine-niels operand (Z2 = 1); neg=1 adds -q
+ZKLC_HD ge_p3 ge_add_niels(const ge_p3 &p, const ge_niels &q, u32 neg, bool want_t) {
     fe qa = fe_select(q.ymx, q.ypx, neg);
     fe qb = fe_select(q.ypx, q.ymx, neg);
     fe A = fe_mul(fe_sub(p.Y, p.X), qa);
@@ -103,7 +98,7 @@ ZKLC_HD ge_p3 ge_add_niels(const ge_p3 &p, const ge_niels &q, u32 neg) {
     r.X = fe_mul(E, F);
     r.Y = fe_mul(G, H);
     r.Z = fe_mul(F, G);
-    if (WANT_T) r.T = fe_mul(E, H);
+    if (want_t) r.T = fe_mul(E, H);
     else r.T = fe_zero();
     return r;
 }
@@ -142,10 +137,8 @@ ZKLC_HD u32 ge_decompress(ge_p3 &r, const u32 *w) {
 ZKLC_HD void ge_compress(u32 *out, const ge_p3 &p) {
     fe zi = fe_invert(p.Z);
     fe x = fe_mul(p.X, zi);
-    fe y = fe_freeze(fe_mul(p.Y, zi));
     u32 s = fe_is_negative(x);
-#pragma unroll
-    for (int i = 0; i < 8; i++) out[i] = y.v[i];
+    fe_freeze_words(out, fe_mul(p.Y, zi));
     out[7] |= s << 31;
 }
 
@@ -161,8 +154,8 @@ ZKLC_HD ge_niels ge_to_niels(const ge_p3 &p) {  // normalises Z (one inversion)
 }
 
 // base point B (crypto/plonky2_ed25519/src/curve/ed25519.rs:37-51)
-#define GE_BASE_X {{0x8f25d51au, 0xc9562d60u, 0x9525a7b2u, 0x692cc760u, 0xfdd6dc5cu, 0xc0a4e231u, 0xcd6e53feu, 0x216936d3u}}
-#define GE_BASE_Y {{0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u}}
+#define GE_BASE_X {{52811034, 25909283, 16144682, 17082669, 27570973, 30858332, 40966398, 8378388, 20764389, 8758491}}
+#define GE_BASE_Y {{40265304, 26843545, 13421772, 20132659, 26843545, 6710886, 53687091, 13421772, 40265318, 26843545}}
 
 ZKLC_HD ge_p3 ge_base() {
     const fe bx = GE_BASE_X, by = GE_BASE_Y;
