@@ -64,6 +64,47 @@ int32_t zklc_sha512_batch(zklc_ctx *ctx, const uint8_t *in, uint32_t stride, uin
 int32_t zklc_sha512_batch_dev(zklc_ctx *ctx, void *stream, const uint8_t *d_in, uint32_t stride, uint32_t len,
                               uint32_t n, uint8_t *d_out);
 
+/* ---- (b) Goldilocks: NTT / LDE / Poseidon / Merkle --------------------------
+ * Replace the prover internals of the un-vendored plonky2 fork
+ * (wormhole-foundation/plonky2-near@2244a9d, Cargo.toml:44-47) reached from
+ * `circuit_data.prove(pw)` at near_bft_finality/src/prove_crypto/ed25519.rs:60,100
+ * and recursion.rs:95: `fft`/`ifft`/`coset_fft` (plonky2_field::fft),
+ * `PolynomialBatch::from_coeffs` (LDE + Merkle) and `MerkleTree::new`.
+ * Elements are canonical u64 < p = 2^64 - 2^32 + 1.  A batch is POLY-MAJOR:
+ * polynomial b, index i at data[b * 2^log_n + i].
+ * values[k] = sum_j coeffs[j] w^(jk), w = 1753635133440165772^(2^32 / n)
+ * (gnark-plonky2-verifier/goldilocks/base.go:33-42). */
+#define ZKLC_NTT_INVERSE 1u     /* inverse transform (includes the 1/n factor) */
+#define ZKLC_NTT_IN_BITREV 2u   /* input is in bit-reversed order (output natural) */
+#define ZKLC_NTT_OUT_BITREV 4u  /* leave the output in bit-reversed order (skips the permutation pass) */
+/* In-place batched NTT.  coset_shift != 0 (forward, natural-order input only):
+ * coefficient j is first multiplied by coset_shift^j (= evaluation on shift*<w>). */
+int32_t zklc_gl_ntt(zklc_ctx *ctx, uint64_t *data, uint32_t log_n, uint32_t batch, uint32_t flags, uint64_t coset_shift);
+int32_t zklc_gl_ntt_dev(zklc_ctx *ctx, void *stream, uint64_t *d_data, uint32_t log_n, uint32_t batch, uint32_t flags,
+                        uint64_t coset_shift);
+/* Low-degree extension: coeffs (batch x 2^log_n, natural order) -> evaluations on
+ * coset_shift * <w_N>, N = 2^(log_n + rate_bits), out = batch x N; flags: ZKLC_NTT_OUT_BITREV
+ * gives the order plonky2 commits to (leaf i = evaluation at shift * w^bitrev(i)). */
+int32_t zklc_gl_lde(zklc_ctx *ctx, const uint64_t *coeffs, uint32_t log_n, uint32_t rate_bits, uint32_t batch,
+                    uint64_t coset_shift, uint64_t *out, uint32_t flags);
+int32_t zklc_gl_lde_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_coeffs, uint32_t log_n, uint32_t rate_bits,
+                        uint32_t batch, uint64_t coset_shift, uint64_t *d_out, uint32_t flags);
+/* Poseidon-Goldilocks permutation of n states of 12 elements, in place
+ * (gnark-plonky2-verifier/poseidon/goldilocks.go:30-37). */
+int32_t zklc_poseidon_gl_permute(zklc_ctx *ctx, uint64_t *states, uint32_t n);
+int32_t zklc_poseidon_gl_permute_dev(zklc_ctx *ctx, void *stream, uint64_t *d_states, uint32_t n);
+/* Merkle tree with cap (plonky2 `MerkleTree::new`; verification side restated in
+ * gnark-plonky2-verifier/fri/fri.go:97-144).  Leaf i = (mat[p * stride + i])_{p < width},
+ * leaf digest = hash_or_noop, inner node = two_to_one.  tree receives all digest levels,
+ * leaves first: level l (2^(log_leaves - l) digests of 4 u64) at word offset
+ * sum_{j<l} 4 * 2^(log_leaves - j); the last level (l = log_leaves - cap_height) is the cap.
+ * zklc_gl_merkle_tree_words gives the total size in u64 words. */
+uint64_t zklc_gl_merkle_tree_words(uint32_t log_leaves, uint32_t cap_height);
+int32_t zklc_gl_merkle_commit(zklc_ctx *ctx, const uint64_t *mat, uint64_t stride, uint32_t log_leaves, uint32_t width,
+                              uint32_t cap_height, uint64_t *tree_out);
+int32_t zklc_gl_merkle_commit_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_mat, uint64_t stride, uint32_t log_leaves,
+                                  uint32_t width, uint32_t cap_height, uint64_t *d_tree);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,16 @@ def load():
                                                          ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_int]
         lib.zklc_oracle_sha512.restype = None
         lib.zklc_oracle_sha512.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_char_p]
+        u64p = ctypes.c_void_p
+        lib.zklc_oracle_gl_ntt.restype = ctypes.c_int
+        lib.zklc_oracle_gl_ntt.argtypes = [u64p, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int]
+        lib.zklc_oracle_gl_lde.restype = ctypes.c_int
+        lib.zklc_oracle_gl_lde.argtypes = [u64p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, u64p, ctypes.c_int]
+        lib.zklc_oracle_poseidon_gl_permute.restype = None
+        lib.zklc_oracle_poseidon_gl_permute.argtypes = [u64p]
+        lib.zklc_oracle_gl_merkle_commit.restype = ctypes.c_int
+        lib.zklc_oracle_gl_merkle_commit.argtypes = [u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, u64p,
+                                                     ctypes.c_int]
         _lib = lib
     return _lib
 
@@ -49,3 +59,50 @@ def sha512(msg):
     out = ctypes.create_string_buffer(64)
     load().zklc_oracle_sha512(msg, len(msg), out)
     return out.raw
+
+
+# ---- Goldilocks (oracle/c/goldilocks_oracle.c) ----
+def gl_ntt(data, inverse=False, nthreads=1):
+    """uint64 [batch, n] -> transformed copy (natural order in and out)"""
+    import numpy as np
+    a = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    if a.ndim == 1:
+        a = a[None, :]
+    batch, n = a.shape
+    load().zklc_oracle_gl_ntt(a.ctypes.data, n.bit_length() - 1, batch, int(inverse), nthreads)
+    return a.reshape(np.shape(data))
+
+
+def gl_lde(coeffs, rate_bits, shift=7, nthreads=1):
+    import numpy as np
+    a = np.ascontiguousarray(coeffs, dtype=np.uint64)
+    if a.ndim == 1:
+        a = a[None, :]
+    batch, n = a.shape
+    out = np.zeros((batch, n << rate_bits), dtype=np.uint64)
+    load().zklc_oracle_gl_lde(a.ctypes.data, n.bit_length() - 1, rate_bits, batch, shift, out.ctypes.data, nthreads)
+    return out
+
+
+def poseidon_gl_permute(state):
+    import numpy as np
+    a = np.array(state, dtype=np.uint64)
+    load().zklc_oracle_poseidon_gl_permute(a.ctypes.data)
+    return [int(x) for x in a]
+
+
+def gl_merkle_commit(mat, cap_height, nthreads=1):
+    """mat uint64 [width, n] (poly-major) -> list of levels ([m,4] arrays), leaves first, cap last"""
+    import numpy as np
+    a = np.ascontiguousarray(mat, dtype=np.uint64)
+    width, n = a.shape
+    log_leaves = n.bit_length() - 1
+    words = sum(4 << (log_leaves - l) for l in range(log_leaves - cap_height + 1))
+    tree = np.zeros(words, dtype=np.uint64)
+    load().zklc_oracle_gl_merkle_commit(a.ctypes.data, n, log_leaves, width, cap_height, tree.ctypes.data, nthreads)
+    levels, off = [], 0
+    for l in range(log_leaves - cap_height + 1):
+        m = n >> l
+        levels.append(tree[off:off + 4 * m].reshape(m, 4))
+        off += 4 * m
+    return levels

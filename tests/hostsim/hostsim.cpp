@@ -2,6 +2,7 @@
 // test-suite (pytest -m "not gpu") can check the exact kernel arithmetic
 // against the oracle without a GPU.  Never linked into libzklc_mi355.so.
 #include "../../zk-light-client-implementation_amd/csrc/ed25519_verify.cuh"
+#include "../../zk-light-client-implementation_amd/csrc/poseidon_gl.cuh"
 #include <string.h>
 
 static ge_niels g_btab[ZKLC_ED_BTABLE];
@@ -70,4 +71,19 @@ u32 hostsim_ed25519_verify(const uint8_t *pk, const uint8_t *sig, const uint8_t 
     i32 tab[ZKLC_ED_ATAB_WORDS];
     return ed25519_verify_one<1>(pkw, sigw, msg, msg_len, g_btab, tab);
 }
+
+u64 hostsim_gl_op(int op, u64 a, u64 b) {
+    switch (op) {
+        case 0: return gl_add(a, b);
+        case 1: return gl_sub(a, b);
+        case 2: return gl_mul(a, b);
+        case 3: return gl_inv(a);
+        case 4: return gl_reduce128(a, b);
+        case 5: return gl_root_of_unity((u32)a);
+        default: return 0;
+    }
+}
+void hostsim_poseidon_gl_permute(u64 *s) { poseidon_gl_permute(s); }
+void hostsim_poseidon_gl_hash(const u64 *in, u32 len, u64 *out4) { poseidon_gl_hash_or_noop(in, 1, len, out4); }
+void hostsim_poseidon_gl_two_to_one(const u64 *l, const u64 *r, u64 *out4) { poseidon_gl_two_to_one(l, r, out4); }
 }

@@ -24,7 +24,23 @@ _SIGS = {
     "zklc_sha512_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _u8p]),
     "zklc_sha512_batch_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint32, ctypes.c_uint32,
                                                ctypes.c_uint32, _u8p]),
+    "zklc_gl_ntt": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64]),
+    "zklc_gl_ntt_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                         ctypes.c_uint64]),
+    "zklc_gl_lde": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, _u8p,
+                                     ctypes.c_uint32]),
+    "zklc_gl_lde_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                         ctypes.c_uint64, _u8p, ctypes.c_uint32]),
+    "zklc_poseidon_gl_permute": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint32]),
+    "zklc_poseidon_gl_permute_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint32]),
+    "zklc_gl_merkle_tree_words": (ctypes.c_uint64, [ctypes.c_uint32, ctypes.c_uint32]),
+    "zklc_gl_merkle_commit": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                               ctypes.c_uint32, _u8p]),
+    "zklc_gl_merkle_commit_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint64, ctypes.c_uint32,
+                                                   ctypes.c_uint32, ctypes.c_uint32, _u8p]),
 }
+
+NTT_INVERSE, NTT_IN_BITREV, NTT_OUT_BITREV = 1, 2, 4
 
 _lib = None
 

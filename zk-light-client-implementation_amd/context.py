@@ -100,6 +100,72 @@ class Context:
                                                     _dev_ptr(d_out)))
 
 
+    # ---- (b) Goldilocks ------------------------------------------------
+    def gl_ntt(self, data, flags=0, coset_shift=0):
+        """data: uint64 numpy array [batch, 2^log_n] (poly-major), transformed copy returned."""
+        a = np.ascontiguousarray(data, dtype=np.uint64)
+        if a.ndim == 1:
+            a = a[None, :]
+        batch, n = a.shape
+        log_n = n.bit_length() - 1
+        if 1 << log_n != n:
+            raise ValueError("transform length must be a power of two")
+        out = a.copy()
+        self._check(self._lib.zklc_gl_ntt(self._h, out.ctypes.data, log_n, batch, flags, coset_shift))
+        return out.reshape(np.shape(data))
+
+    def gl_ntt_dev(self, d_data, log_n, batch, flags=0, coset_shift=0, stream=None):
+        self._check(self._lib.zklc_gl_ntt_dev(self._h, _stream_ptr(stream), _dev_ptr(d_data), log_n, batch, flags, coset_shift))
+
+    def gl_lde(self, coeffs, rate_bits, coset_shift=7, flags=0):
+        a = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        if a.ndim == 1:
+            a = a[None, :]
+        batch, n = a.shape
+        log_n = n.bit_length() - 1
+        if 1 << log_n != n:
+            raise ValueError("polynomial length must be a power of two")
+        out = np.zeros((batch, n << rate_bits), dtype=np.uint64)
+        self._check(self._lib.zklc_gl_lde(self._h, a.ctypes.data, log_n, rate_bits, batch, coset_shift, out.ctypes.data, flags))
+        return out
+
+    def gl_lde_dev(self, d_coeffs, log_n, rate_bits, batch, coset_shift, d_out, flags=0, stream=None):
+        self._check(self._lib.zklc_gl_lde_dev(self._h, _stream_ptr(stream), _dev_ptr(d_coeffs), log_n, rate_bits, batch,
+                                              coset_shift, _dev_ptr(d_out), flags))
+
+    def poseidon_gl_permute(self, states):
+        a = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 12).copy()
+        self._check(self._lib.zklc_poseidon_gl_permute(self._h, a.ctypes.data, a.shape[0]))
+        return a
+
+    def poseidon_gl_permute_dev(self, d_states, n, stream=None):
+        self._check(self._lib.zklc_poseidon_gl_permute_dev(self._h, _stream_ptr(stream), _dev_ptr(d_states), n))
+
+    def gl_merkle_tree_words(self, log_leaves, cap_height):
+        return int(self._lib.zklc_gl_merkle_tree_words(log_leaves, cap_height))
+
+    def gl_merkle_commit(self, mat, cap_height):
+        """mat: uint64 [width, n_leaves] (poly-major).  Returns (cap [2^cap_height, 4], levels list of [m, 4] arrays)."""
+        a = np.ascontiguousarray(mat, dtype=np.uint64)
+        width, n = a.shape
+        log_leaves = n.bit_length() - 1
+        if 1 << log_leaves != n:
+            raise ValueError("leaf count must be a power of two")
+        words = self.gl_merkle_tree_words(log_leaves, cap_height)
+        tree = np.zeros(words, dtype=np.uint64)
+        self._check(self._lib.zklc_gl_merkle_commit(self._h, a.ctypes.data, n, log_leaves, width, cap_height, tree.ctypes.data))
+        levels, off = [], 0
+        for l in range(log_leaves - cap_height + 1):
+            m = n >> l
+            levels.append(tree[off:off + 4 * m].reshape(m, 4))
+            off += 4 * m
+        return levels[-1], levels
+
+    def gl_merkle_commit_dev(self, d_mat, stride, log_leaves, width, cap_height, d_tree, stream=None):
+        self._check(self._lib.zklc_gl_merkle_commit_dev(self._h, _stream_ptr(stream), _dev_ptr(d_mat), stride, log_leaves, width,
+                                                        cap_height, _dev_ptr(d_tree)))
+
+
 def _dev_ptr(t):
     if t is None:
         return None

@@ -1,0 +1,74 @@
+// Goldilocks field p = 2^64 - 2^32 + 1 (canonical u64 in, canonical u64 out).
+//
+// Replaces plonky2_field::goldilocks_field (plonky2-near@2244a9d, un-vendored:
+// Cargo.toml:44-47); parameters as restated in
+// gnark-plonky2-verifier/goldilocks/base.go:33-42 (generator 7, 2-adicity 32,
+// POWER_OF_TWO_GENERATOR 1753635133440165772).  gfx950 has no 64x64 multiply:
+// a product is four v_mad_u64_u32 and the reduction uses 2^64 = 2^32 - 1,
+// 2^96 = -1 (mod p).
+#pragma once
+#include "common.cuh"
+
+#define GL_P 0xFFFFFFFF00000001ULL
+#define GL_EPS 0xFFFFFFFFULL
+#define GL_GENERATOR 7ULL
+#define GL_POWER_OF_TWO_GENERATOR 1753635133440165772ULL
+
+ZKLC_HD u64 gl_add(u64 a, u64 b) {
+    u64 s = a + b;
+    // a + b overflowed 2^64: fold 2^64 = EPS (cannot overflow again, result < p);
+    // otherwise a single conditional subtraction of p
+    u64 wrapped = s + GL_EPS;
+    u64 sub = s - GL_P;
+    return (s < a) ? wrapped : (s >= GL_P ? sub : s);
+}
+ZKLC_HD u64 gl_sub(u64 a, u64 b) {
+    u64 d = a - b;
+    return (a < b) ? d + GL_P : d;
+}
+ZKLC_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
+ZKLC_HD u64 gl_double(u64 a) { return gl_add(a, a); }
+
+// (hi:lo) mod p for any 128-bit value
+ZKLC_HD u64 gl_reduce128(u64 lo, u64 hi) {
+    u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+    u64 t0 = lo - hi_hi;  // 2^96 = -1
+    if (lo < hi_hi) t0 -= GL_EPS;  // borrow: -2^64 = -EPS
+    u64 t1 = hi_lo * GL_EPS;  // 2^64 = EPS ; (hi_lo << 32) - hi_lo
+    u64 r = t0 + t1;
+    if (r < t1) r += GL_EPS;  // carry
+    return r >= GL_P ? r - GL_P : r;
+}
+
+ZKLC_HD void gl_mul_wide(u64 a, u64 b, u64 &lo, u64 &hi) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 p00 = (u64)a0 * b0;
+    u64 p01 = (u64)a0 * b1 + (p00 >> 32);           // < 2^64: (2^32-1)^2 + 2^32 - 1
+    u64 p10 = (u64)a1 * b0 + (u32)p01;              // < 2^64
+    u64 p11 = (u64)a1 * b1 + (p01 >> 32) + (p10 >> 32);
+    lo = (p10 << 32) | (u32)p00;
+    hi = p11;
+}
+
+ZKLC_HD u64 gl_mul(u64 a, u64 b) {
+    u64 lo, hi;
+    gl_mul_wide(a, b, lo, hi);
+    return gl_reduce128(lo, hi);
+}
+ZKLC_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
+
+ZKLC_HD u64 gl_pow(u64 a, u64 e) {
+    u64 r = 1;
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    while (e) {
+        if (e & 1) r = gl_mul(r, a);
+        a = gl_sqr(a);
+        e >>= 1;
+    }
+    return r;
+}
+ZKLC_HD u64 gl_inv(u64 a) { return gl_pow(a, GL_P - 2); }
+// primitive 2^log_n-th root of unity
+ZKLC_HD u64 gl_root_of_unity(u32 log_n) { return gl_pow(GL_POWER_OF_TWO_GENERATOR, 1ULL << (32 - log_n)); }

@@ -1,0 +1,418 @@
+// Goldilocks NTT / LDE, Poseidon permutation, leaf hashing and Merkle trees
+// (gfx950) + their C ABI.  These are the kernels behind the plonky2 commit phase
+// (`PolynomialBatch::from_values/from_coeffs`, `MerkleTree::new` in the
+// un-vendored plonky2-near fork; reference call sites
+// near_bft_finality/src/prove_crypto/ed25519.rs:60,100, recursion.rs:95).
+//
+// Data layout in HBM: a batch of polynomials is POLY-MAJOR (poly p, index i at
+// p * stride + i).  That is the natural layout for the NTT (each transform is
+// contiguous) AND for leaf hashing with one lane per leaf (for every column p the
+// 64 lanes of a wave read 64 consecutive u64 = 512 contiguous bytes), so the
+// "transpose to row-major leaves" pass of the CPU prover disappears.
+#include "poseidon_gl.cuh"
+#include "zklc_internal.h"
+
+#define NTT_THREADS 256
+#define NTT_TILE_LOG_MAX 12
+#define NTT_TILE_MAX (1 << NTT_TILE_LOG_MAX)
+
+// ---------------------------------------------------------------- tables
+__global__ void gl_pow_table_kernel(u64 *out, u64 base, u64 n, u64 exp_stride) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gl_pow(base, i * exp_stride);
+}
+
+// ---------------------------------------------------------------- NTT passes
+// One launch = k consecutive radix-2 stages of a size-2^logn transform, done in LDS on
+// tiles of 2^(k+c+d) elements: all 2^k values of the k-bit index window the stages act on,
+// times 2^c consecutive low indices (coalesced 8*2^c-byte runs), times 2^d high indices.
+// Stage s (0-based from the top) pairs indices that differ in bit (logn-1-s) and uses the
+// twiddle w^((i mod h) << s), h = 2^(logn-1-s), from the table tw[i] = w^i, i < 2^(logn-1).
+//   DIF (forward order of stages): natural-order input -> bit-reversed output
+//   DIT (reverse order of stages): bit-reversed input  -> natural-order output
+struct ntt_pass {
+    int logn, s0, k, c, d;
+    int log_in;        // input indices >= 2^log_in read as zero (LDE zero padding); = logn otherwise
+    int scale_shift;   // log2 of the low table size of the two-level load scale (0 = no load scale)
+    u64 out_scale;     // multiplied into every stored value when != 1 (1/n of the inverse transform)
+};
+
+template <bool DIT>
+__global__ void __launch_bounds__(NTT_THREADS)
+gl_ntt_pass_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t in_stride, size_t out_stride, ntt_pass p,
+                   const u64 *__restrict__ tw, const u64 *__restrict__ scale_hi, const u64 *__restrict__ scale_lo) {
+    __shared__ u64 tile[NTT_TILE_MAX];
+    const int tile_log = p.k + p.c + p.d;
+    const int tile_n = 1 << tile_log;
+    const int lowbits = p.logn - p.s0 - p.k;
+    const u32 tid = threadIdx.x;
+    // tile coordinates
+    const u64 t_id = blockIdx.x;
+    const u64 tileL = t_id & ((1ULL << (lowbits - p.c)) - 1);
+    const u64 tileH = t_id >> (lowbits - p.c);
+    const u64 *src = in + (size_t)blockIdx.y * in_stride;
+    u64 *dst = out + (size_t)blockIdx.y * out_stride;
+
+    auto global_index = [&](u32 e) -> u64 {
+        u64 lowc = e & ((1u << p.c) - 1);
+        u64 mid = (e >> p.c) & ((1u << p.k) - 1);
+        u64 hid = e >> (p.c + p.k);
+        u64 L = (tileL << p.c) | lowc;
+        u64 H = (tileH << p.d) | hid;
+        return (H << (lowbits + p.k)) | (mid << lowbits) | L;
+    };
+
+    for (u32 e = tid; e < (u32)tile_n; e += NTT_THREADS) {
+        u64 g = global_index(e);
+        u64 v = 0;
+        if (g < (1ULL << p.log_in)) {
+            v = src[g];
+            if (p.scale_shift) v = gl_mul(v, gl_mul(scale_hi[g >> p.scale_shift], scale_lo[g & ((1u << p.scale_shift) - 1)]));
+        }
+        tile[e] = v;
+    }
+    __syncthreads();
+
+    for (int tt = 0; tt < p.k; tt++) {
+        const int t = DIT ? (p.k - 1 - tt) : tt;
+        const int s = p.s0 + t;
+        const int pb = p.c + (p.k - 1 - t);  // tile-index bit of the paired elements
+        for (u32 b = tid; b < (u32)(tile_n >> 1); b += NTT_THREADS) {
+            u32 e0 = ((b >> pb) << (pb + 1)) | (b & ((1u << pb) - 1));
+            u32 e1 = e0 | (1u << pb);
+            u64 lowc = e0 & ((1u << p.c) - 1);
+            u64 mid = (e0 >> p.c) & ((1u << p.k) - 1);
+            u64 j = ((mid & ((1u << (p.k - 1 - t)) - 1)) << lowbits) | ((tileL << p.c) | lowc);
+            u64 w = tw[j << s];
+            u64 u = tile[e0], v = tile[e1];
+            if (DIT) {
+                v = gl_mul(v, w);
+                tile[e0] = gl_add(u, v);
+                tile[e1] = gl_sub(u, v);
+            } else {
+                tile[e0] = gl_add(u, v);
+                tile[e1] = gl_mul(gl_sub(u, v), w);
+            }
+        }
+        __syncthreads();
+    }
+
+    for (u32 e = tid; e < (u32)tile_n; e += NTT_THREADS) {
+        u64 v = tile[e];
+        if (p.out_scale != 1) v = gl_mul(v, p.out_scale);
+        dst[global_index(e)] = v;
+    }
+}
+
+// out[i] = in[bitrev(i)] (per polynomial)
+__global__ void __launch_bounds__(256) gl_bitrev_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t stride, int logn) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1ULL << logn)) return;
+    u64 r = __brevll(i) >> (64 - logn);
+    out[(size_t)blockIdx.y * stride + i] = in[(size_t)blockIdx.y * stride + r];
+}
+
+// ---------------------------------------------------------------- Poseidon / Merkle
+__global__ void __launch_bounds__(256) poseidon_gl_permute_kernel(u64 *states, u32 n) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 s[12];
+    u64 *p = states + (size_t)i * 12;
+#pragma unroll
+    for (int k = 0; k < 12; k++) s[k] = p[k];
+    poseidon_gl_permute(s);
+#pragma unroll
+    for (int k = 0; k < 12; k++) p[k] = s[k];
+}
+
+// leaf i = (mat[p * stride + i])_{p < width}; one lane per leaf, coalesced across lanes for every p
+__global__ void __launch_bounds__(256)
+gl_hash_leaves_kernel(const u64 *__restrict__ mat, size_t stride, u32 width, u32 n_leaves, u64 *__restrict__ digests) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves) return;
+    u64 h[4];
+    poseidon_gl_hash_or_noop(mat + i, stride, width, h);
+    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(digests + (size_t)i * 4);
+    o[0] = make_ulonglong2(h[0], h[1]);
+    o[1] = make_ulonglong2(h[2], h[3]);
+}
+
+// parents[i] = two_to_one(children[2i], children[2i+1])
+__global__ void __launch_bounds__(256) gl_merkle_level_kernel(const u64 *__restrict__ children, u64 *__restrict__ parents, u32 n_parents) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parents) return;
+    const ulonglong2 *c = reinterpret_cast<const ulonglong2 *>(children + (size_t)i * 8);
+    ulonglong2 a = c[0], b = c[1], cc = c[2], dd = c[3];
+    u64 l[4] = {a.x, a.y, b.x, b.y}, r[4] = {cc.x, cc.y, dd.x, dd.y}, h[4];
+    poseidon_gl_two_to_one(l, r, h);
+    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(parents + (size_t)i * 4);
+    o[0] = make_ulonglong2(h[0], h[1]);
+    o[1] = make_ulonglong2(h[2], h[3]);
+}
+
+// ---------------------------------------------------------------- host side
+static u64 host_gl_mul(u64 a, u64 b) {
+    unsigned __int128 x = (unsigned __int128)a * b;
+    return (u64)(x % GL_P);
+}
+static u64 host_gl_pow(u64 a, u64 e) {
+    u64 r = 1;
+    while (e) {
+        if (e & 1) r = host_gl_mul(r, a);
+        a = host_gl_mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+
+void zklc_gl_fini(zklc_ctx *ctx) {
+    for (int i = 0; i <= ZKLC_GL_MAX_LOG; i++) {
+        if (ctx->gl_tw_fwd[i]) (void)hipFree(ctx->gl_tw_fwd[i]);
+        if (ctx->gl_tw_inv[i]) (void)hipFree(ctx->gl_tw_inv[i]);
+        ctx->gl_tw_fwd[i] = ctx->gl_tw_inv[i] = nullptr;
+    }
+    if (ctx->gl_scale_hi) (void)hipFree(ctx->gl_scale_hi);
+    if (ctx->gl_scale_lo) (void)hipFree(ctx->gl_scale_lo);
+    ctx->gl_scale_hi = ctx->gl_scale_lo = nullptr;
+}
+
+// twiddle tables w^i (i < n/2) for the forward and inverse transforms of size 2^logn
+static int32_t gl_get_twiddles(zklc_ctx *ctx, hipStream_t st, int logn, bool inverse, const u64 **out) {
+    void **slot = inverse ? &ctx->gl_tw_inv[logn] : &ctx->gl_tw_fwd[logn];
+    if (!*slot) {
+        u64 n_half = logn ? (1ULL << (logn - 1)) : 1;
+        ZKLC_HIP(ctx, hipMalloc(slot, n_half * 8));
+        u64 w = host_gl_pow(GL_POWER_OF_TWO_GENERATOR, 1ULL << (32 - logn));
+        if (inverse) w = host_gl_pow(w, GL_P - 2);
+        hipLaunchKernelGGL(gl_pow_table_kernel, dim3((unsigned)((n_half + 255) / 256)), dim3(256), 0, st, (u64 *)*slot, w, n_half,
+                           (u64)1);
+        ZKLC_HIP(ctx, hipGetLastError());
+    }
+    *out = (const u64 *)*slot;
+    return ZKLC_OK;
+}
+
+#define GL_SCALE_LO_LOG 10
+// two-level table of shift^j: hi[j >> 10] * lo[j & 1023]
+static int32_t gl_get_scale(zklc_ctx *ctx, hipStream_t st, u64 shift, int logn) {
+    int hi_n = logn > GL_SCALE_LO_LOG ? (1 << (logn - GL_SCALE_LO_LOG)) : 1;
+    if (ctx->gl_scale_shift == shift && ctx->gl_scale_hi_n >= hi_n) return ZKLC_OK;
+    if (ctx->gl_scale_hi) (void)hipFree(ctx->gl_scale_hi);
+    ctx->gl_scale_hi = nullptr;
+    if (!ctx->gl_scale_lo) ZKLC_HIP(ctx, hipMalloc(&ctx->gl_scale_lo, (1 << GL_SCALE_LO_LOG) * 8));
+    int cap = hi_n < (1 << 14) ? (1 << 14) : hi_n;
+    ZKLC_HIP(ctx, hipMalloc(&ctx->gl_scale_hi, (size_t)cap * 8));
+    hipLaunchKernelGGL(gl_pow_table_kernel, dim3((1 << GL_SCALE_LO_LOG) / 256), dim3(256), 0, st, (u64 *)ctx->gl_scale_lo, shift,
+                       (u64)(1 << GL_SCALE_LO_LOG), (u64)1);
+    hipLaunchKernelGGL(gl_pow_table_kernel, dim3((cap + 255) / 256), dim3(256), 0, st, (u64 *)ctx->gl_scale_hi, shift, (u64)cap,
+                       (u64)(1 << GL_SCALE_LO_LOG));
+    ZKLC_HIP(ctx, hipGetLastError());
+    ctx->gl_scale_shift = shift;
+    ctx->gl_scale_hi_n = cap;
+    return ZKLC_OK;
+}
+
+// Runs all passes of one transform.  dit=false: natural in -> bit-reversed out; dit=true: bit-reversed in -> natural out.
+static int32_t gl_ntt_run(zklc_ctx *ctx, hipStream_t st, const u64 *in, size_t in_stride, u64 *out, size_t out_stride, int logn,
+                          int log_in, u32 batch, bool inverse, bool dit, u64 load_shift) {
+    if (logn == 0) {
+        if (in != out)
+            for (u32 b = 0; b < batch; b++)
+                ZKLC_HIP(ctx, hipMemcpyAsync(out + b * out_stride, in + b * in_stride, 8, hipMemcpyDeviceToDevice, st));
+        return ZKLC_OK;
+    }
+    const u64 *tw;
+    int32_t rc = gl_get_twiddles(ctx, st, logn, inverse, &tw);
+    if (rc) return rc;
+    if (load_shift) {
+        if ((rc = gl_get_scale(ctx, st, load_shift, log_in))) return rc;
+    }
+    // plan: strided windows of <= 8 bits from the top, then one contiguous window of <= 12 bits
+    int ks[8], np = 0;
+    int k_last = logn < NTT_TILE_LOG_MAX ? logn : NTT_TILE_LOG_MAX;
+    int remaining = logn - k_last;
+    while (remaining > 0) {
+        int k = remaining < 8 ? remaining : 8;
+        ks[np++] = k;
+        remaining -= k;
+    }
+    ks[np++] = k_last;
+    u64 n_inv = inverse ? host_gl_pow(1ULL << logn, GL_P - 2) : 1;
+    int s0_of[8], s0 = 0;
+    for (int i = 0; i < np; i++) {
+        s0_of[i] = s0;
+        s0 += ks[i];
+    }
+    for (int ii = 0; ii < np; ii++) {
+        int i = dit ? (np - 1 - ii) : ii;  // DIT runs the windows bottom-up
+        ntt_pass p;
+        p.logn = logn;
+        p.s0 = s0_of[i];
+        p.k = ks[i];
+        int lowbits = logn - p.s0 - p.k;
+        p.c = lowbits < (NTT_TILE_LOG_MAX - p.k) ? lowbits : (NTT_TILE_LOG_MAX - p.k);
+        int room = NTT_TILE_LOG_MAX - p.k - p.c;
+        p.d = p.s0 < room ? p.s0 : room;
+        bool first = (ii == 0), last = (ii == np - 1);
+        p.log_in = first ? log_in : logn;
+        p.scale_shift = (first && load_shift) ? GL_SCALE_LO_LOG : 0;
+        p.out_scale = last ? n_inv : 1;
+        const u64 *src = first ? in : out;
+        size_t sstride = first ? in_stride : out_stride;
+        dim3 grid((unsigned)(1ULL << (logn - (p.k + p.c + p.d))), batch);
+        if (dit)
+            hipLaunchKernelGGL(gl_ntt_pass_kernel<true>, grid, dim3(NTT_THREADS), 0, st, src, out, sstride, out_stride, p, tw,
+                               (const u64 *)ctx->gl_scale_hi, (const u64 *)ctx->gl_scale_lo);
+        else
+            hipLaunchKernelGGL(gl_ntt_pass_kernel<false>, grid, dim3(NTT_THREADS), 0, st, src, out, sstride, out_stride, p, tw,
+                               (const u64 *)ctx->gl_scale_hi, (const u64 *)ctx->gl_scale_lo);
+        ZKLC_HIP(ctx, hipGetLastError());
+    }
+    return ZKLC_OK;
+}
+
+extern "C" int32_t zklc_gl_ntt_dev(zklc_ctx *ctx, void *stream, uint64_t *d_data, uint32_t log_n, uint32_t batch,
+                                   uint32_t flags, uint64_t coset_shift) {
+    if (!ctx || !d_data || log_n > ZKLC_GL_MAX_LOG) return ZKLC_ERR_INVALID_ARG;
+    if (batch == 0) return ZKLC_OK;
+    bool inverse = flags & ZKLC_NTT_INVERSE, in_br = flags & ZKLC_NTT_IN_BITREV, out_br = flags & ZKLC_NTT_OUT_BITREV;
+    if (in_br && out_br) return ZKLC_ERR_INVALID_ARG;
+    if (coset_shift && (inverse || in_br)) return ZKLC_ERR_INVALID_ARG;  // coset scaling is applied to natural-order coefficients
+    if (coset_shift >= GL_P) return ZKLC_ERR_INVALID_ARG;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = zklc_pick_stream(ctx, stream);
+    size_t n = 1ULL << log_n;
+    if (in_br) return gl_ntt_run(ctx, st, d_data, n, d_data, n, log_n, log_n, batch, inverse, true, 0);
+    int32_t rc = gl_ntt_run(ctx, st, d_data, n, d_data, n, log_n, log_n, batch, inverse, false, coset_shift);
+    if (rc || out_br) return rc;
+    // natural order requested: permute through the context scratch buffer
+    void *tmp;
+    if ((rc = zklc_stage(ctx, 7, n * batch * 8, &tmp))) return rc;
+    ZKLC_HIP(ctx, hipMemcpyAsync(tmp, d_data, n * batch * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(gl_bitrev_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, st, (const u64 *)tmp, d_data, n,
+                       (int)log_n);
+    ZKLC_HIP(ctx, hipGetLastError());
+    return ZKLC_OK;
+}
+
+extern "C" int32_t zklc_gl_lde_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_coeffs, uint32_t log_n, uint32_t rate_bits,
+                                   uint32_t batch, uint64_t coset_shift, uint64_t *d_out, uint32_t flags) {
+    if (!ctx || !d_coeffs || !d_out || log_n + rate_bits > ZKLC_GL_MAX_LOG || coset_shift >= GL_P) return ZKLC_ERR_INVALID_ARG;
+    if (batch == 0) return ZKLC_OK;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = zklc_pick_stream(ctx, stream);
+    int logN = log_n + rate_bits;
+    size_t n = 1ULL << log_n, N = 1ULL << logN;
+    int32_t rc = gl_ntt_run(ctx, st, d_coeffs, n, d_out, N, logN, log_n, batch, false, false, coset_shift);
+    if (rc || (flags & ZKLC_NTT_OUT_BITREV)) return rc;
+    void *tmp;
+    if ((rc = zklc_stage(ctx, 7, N * batch * 8, &tmp))) return rc;
+    ZKLC_HIP(ctx, hipMemcpyAsync(tmp, d_out, N * batch * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(gl_bitrev_kernel, dim3((unsigned)((N + 255) / 256), batch), dim3(256), 0, st, (const u64 *)tmp, d_out, N,
+                       logN);
+    ZKLC_HIP(ctx, hipGetLastError());
+    return ZKLC_OK;
+}
+
+extern "C" int32_t zklc_poseidon_gl_permute_dev(zklc_ctx *ctx, void *stream, uint64_t *d_states, uint32_t n) {
+    if (!ctx || (n && !d_states)) return ZKLC_ERR_INVALID_ARG;
+    if (n == 0) return ZKLC_OK;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(poseidon_gl_permute_kernel, dim3((n + 255) / 256), dim3(256), 0, zklc_pick_stream(ctx, stream), d_states, n);
+    ZKLC_HIP(ctx, hipGetLastError());
+    return ZKLC_OK;
+}
+
+extern "C" uint64_t zklc_gl_merkle_tree_words(uint32_t log_leaves, uint32_t cap_height) {
+    if (cap_height > log_leaves) return 0;
+    uint64_t words = 0;
+    for (uint32_t l = 0; l <= log_leaves - cap_height; l++) words += 4ULL << (log_leaves - l);
+    return words;
+}
+
+extern "C" int32_t zklc_gl_merkle_commit_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_mat, uint64_t stride, uint32_t log_leaves,
+                                             uint32_t width, uint32_t cap_height, uint64_t *d_tree) {
+    if (!ctx || !d_mat || !d_tree || log_leaves > 30 || cap_height > log_leaves || width == 0) return ZKLC_ERR_INVALID_ARG;
+    if (stride < (1ULL << log_leaves)) return ZKLC_ERR_INVALID_ARG;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = zklc_pick_stream(ctx, stream);
+    u32 n = 1u << log_leaves;
+    hipLaunchKernelGGL(gl_hash_leaves_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_mat, (size_t)stride, width, n, d_tree);
+    ZKLC_HIP(ctx, hipGetLastError());
+    u64 *level = d_tree;
+    for (u32 l = 0; l < log_leaves - cap_height; l++) {
+        u32 parents = n >> (l + 1);
+        u64 *next = level + (4ULL << (log_leaves - l));
+        hipLaunchKernelGGL(gl_merkle_level_kernel, dim3((parents + 255) / 256), dim3(256), 0, st, (const u64 *)level, next, parents);
+        ZKLC_HIP(ctx, hipGetLastError());
+        level = next;
+    }
+    return ZKLC_OK;
+}
+
+// ---- host-pointer flavours (stage through the context buffers) ----
+extern "C" int32_t zklc_gl_ntt(zklc_ctx *ctx, uint64_t *data, uint32_t log_n, uint32_t batch, uint32_t flags, uint64_t coset_shift) {
+    if (!ctx || !data || log_n > ZKLC_GL_MAX_LOG) return ZKLC_ERR_INVALID_ARG;
+    if (batch == 0) return ZKLC_OK;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t bytes = ((size_t)batch << log_n) * 8;
+    void *d;
+    int32_t rc;
+    if ((rc = zklc_stage(ctx, 0, bytes, &d))) return rc;
+    ZKLC_HIP(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = zklc_gl_ntt_dev(ctx, ctx->stream, (uint64_t *)d, log_n, batch, flags, coset_shift))) return rc;
+    ZKLC_HIP(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKLC_OK;
+}
+
+extern "C" int32_t zklc_gl_lde(zklc_ctx *ctx, const uint64_t *coeffs, uint32_t log_n, uint32_t rate_bits, uint32_t batch,
+                               uint64_t coset_shift, uint64_t *out, uint32_t flags) {
+    if (!ctx || !coeffs || !out || log_n + rate_bits > ZKLC_GL_MAX_LOG) return ZKLC_ERR_INVALID_ARG;
+    if (batch == 0) return ZKLC_OK;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t in_bytes = ((size_t)batch << log_n) * 8, out_bytes = ((size_t)batch << (log_n + rate_bits)) * 8;
+    void *din, *dout;
+    int32_t rc;
+    if ((rc = zklc_stage(ctx, 0, in_bytes, &din))) return rc;
+    if ((rc = zklc_stage(ctx, 1, out_bytes, &dout))) return rc;
+    ZKLC_HIP(ctx, hipMemcpyAsync(din, coeffs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = zklc_gl_lde_dev(ctx, ctx->stream, (const uint64_t *)din, log_n, rate_bits, batch, coset_shift, (uint64_t *)dout, flags)))
+        return rc;
+    ZKLC_HIP(ctx, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKLC_OK;
+}
+
+extern "C" int32_t zklc_poseidon_gl_permute(zklc_ctx *ctx, uint64_t *states, uint32_t n) {
+    if (!ctx || (n && !states)) return ZKLC_ERR_INVALID_ARG;
+    if (n == 0) return ZKLC_OK;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t bytes = (size_t)n * 96;
+    void *d;
+    int32_t rc;
+    if ((rc = zklc_stage(ctx, 0, bytes, &d))) return rc;
+    ZKLC_HIP(ctx, hipMemcpyAsync(d, states, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = zklc_poseidon_gl_permute_dev(ctx, ctx->stream, (uint64_t *)d, n))) return rc;
+    ZKLC_HIP(ctx, hipMemcpyAsync(states, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKLC_OK;
+}
+
+extern "C" int32_t zklc_gl_merkle_commit(zklc_ctx *ctx, const uint64_t *mat, uint64_t stride, uint32_t log_leaves, uint32_t width,
+                                         uint32_t cap_height, uint64_t *tree_out) {
+    if (!ctx || !mat || !tree_out || log_leaves > 30 || cap_height > log_leaves || width == 0) return ZKLC_ERR_INVALID_ARG;
+    if (stride < (1ULL << log_leaves)) return ZKLC_ERR_INVALID_ARG;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t in_bytes = (size_t)stride * width * 8, tree_bytes = zklc_gl_merkle_tree_words(log_leaves, cap_height) * 8;
+    void *dm, *dt;
+    int32_t rc;
+    if ((rc = zklc_stage(ctx, 0, in_bytes, &dm))) return rc;
+    if ((rc = zklc_stage(ctx, 1, tree_bytes, &dt))) return rc;
+    ZKLC_HIP(ctx, hipMemcpyAsync(dm, mat, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = zklc_gl_merkle_commit_dev(ctx, ctx->stream, (const uint64_t *)dm, stride, log_leaves, width, cap_height, (uint64_t *)dt)))
+        return rc;
+    ZKLC_HIP(ctx, hipMemcpyAsync(tree_out, dt, tree_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKLC_OK;
+}

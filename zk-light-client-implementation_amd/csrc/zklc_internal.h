@@ -6,6 +6,8 @@
 #include <string>
 #include "../../include/zklc.h"
 
+#define ZKLC_GL_MAX_LOG 24
+
 struct zklc_devbuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -18,7 +20,14 @@ struct zklc_ctx {
     // Ed25519: 128 affine-niels multiples of the base point (12 KiB)
     void *ed_btab = nullptr;
     int ed_variant = 0;  // index into the compiled verify-kernel variants
-    // grow-only staging buffers for the host-pointer entry points
+    // Goldilocks: twiddle tables w^i (i < 2^(logn-1)) per transform size, forward and inverse
+    void *gl_tw_fwd[ZKLC_GL_MAX_LOG + 1] = {};
+    void *gl_tw_inv[ZKLC_GL_MAX_LOG + 1] = {};
+    // two-level table of coset-shift powers (shift^j = hi[j >> 10] * lo[j & 1023])
+    void *gl_scale_hi = nullptr, *gl_scale_lo = nullptr;
+    uint64_t gl_scale_shift = 0;
+    int gl_scale_hi_n = 0;
+    // grow-only staging buffers for the host-pointer entry points (slot 7 = kernel scratch)
     zklc_devbuf stage[8];
 };
 
@@ -39,3 +48,4 @@ inline hipStream_t zklc_pick_stream(zklc_ctx *, void *s) { return (hipStream_t)s
 // subsystem initialisers (called by zklc_init)
 int32_t zklc_ed25519_init(zklc_ctx *ctx);
 void zklc_ed25519_fini(zklc_ctx *ctx);
+void zklc_gl_fini(zklc_ctx *ctx);
