@@ -105,6 +105,21 @@ int32_t zklc_gl_merkle_commit(zklc_ctx *ctx, const uint64_t *mat, uint64_t strid
 int32_t zklc_gl_merkle_commit_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_mat, uint64_t stride, uint32_t log_leaves,
                                   uint32_t width, uint32_t cap_height, uint64_t *d_tree);
 
+/* ---- (c) BN254 ---------------------------------------------------------------
+ * G1 multi-scalar multiplication sum_i scalars[i] * points[i].
+ * Replaces gnark-crypto `bn254.G1Affine.MultiExp` (un-vendored; gnark-plonky2-verifier/go.mod:9)
+ * called from `groth16.Prove` at gnark-plonky2-verifier/cmd/web-api.go:77.
+ * points: n affine points in gnark-crypto's memory layout = x then y, each 4 little-endian
+ * u64 limbs in Montgomery form (x * 2^256 mod p); (0, 0) is the point at infinity.
+ * scalars: n x 4 little-endian u64, REGULAR (non-Montgomery) form, reduced (< r).
+ * out_affine: 8 u64 in the same layout, canonical; *out_is_infinity = 1 when the sum is
+ * the point at infinity (then out_affine is zero).  Pointers must be 16-byte aligned. */
+int32_t zklc_bn254_g1_msm(zklc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, uint64_t n, uint64_t *out_affine,
+                          uint32_t *out_is_infinity);
+uint64_t zklc_bn254_g1_msm_workspace_bytes(uint64_t n);
+int32_t zklc_bn254_g1_msm_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, const uint64_t *d_scalars, uint64_t n,
+                              uint64_t *d_out_affine, uint32_t *d_out_is_infinity, void *d_workspace, uint64_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

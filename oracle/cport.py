@@ -38,6 +38,12 @@ def load():
         lib.zklc_oracle_gl_merkle_commit.restype = ctypes.c_int
         lib.zklc_oracle_gl_merkle_commit.argtypes = [u64p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, u64p,
                                                      ctypes.c_int]
+        lib.zklc_oracle_bn254_gen_points.restype = None
+        lib.zklc_oracle_bn254_gen_points.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64, u64p]
+        lib.zklc_oracle_bn254_msm_naive.restype = ctypes.c_int
+        lib.zklc_oracle_bn254_msm_naive.argtypes = [u64p, u64p, ctypes.c_uint64, u64p]
+        lib.zklc_oracle_bn254_msm.restype = ctypes.c_int
+        lib.zklc_oracle_bn254_msm.argtypes = [u64p, u64p, ctypes.c_uint64, u64p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         _lib = lib
     return _lib
 
@@ -106,3 +112,26 @@ def gl_merkle_commit(mat, cap_height, nthreads=1):
         levels.append(tree[off:off + 4 * m].reshape(m, 4))
         off += 4 * m
     return levels
+
+
+# ---- BN254 (oracle/c/bn254_oracle.c) ----
+def bn254_gen_points(n, a=7, b=11):
+    """n affine points (a + i*b) * G in gnark Montgomery layout, uint64 [n, 8]"""
+    import numpy as np
+    out = np.zeros((n, 8), dtype=np.uint64)
+    load().zklc_oracle_bn254_gen_points(a, b, n, out.ctypes.data)
+    return out
+
+
+def bn254_msm(points, scalars, nthreads=1, naive=False):
+    """-> (uint64[8] affine gnark layout, is_infinity, threads_used)"""
+    import numpy as np
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(8, dtype=np.uint64)
+    used = ctypes.c_int(1)
+    if naive:
+        inf = load().zklc_oracle_bn254_msm_naive(pts.ctypes.data, sc.ctypes.data, pts.shape[0], out.ctypes.data)
+    else:
+        inf = load().zklc_oracle_bn254_msm(pts.ctypes.data, sc.ctypes.data, pts.shape[0], out.ctypes.data, nthreads, ctypes.byref(used))
+    return out, bool(inf), used.value

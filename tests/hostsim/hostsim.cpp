@@ -3,6 +3,7 @@
 // against the oracle without a GPU.  Never linked into libzklc_mi355.so.
 #include "../../zk-light-client-implementation_amd/csrc/ed25519_verify.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/poseidon_gl.cuh"
+#include "../../zk-light-client-implementation_amd/csrc/bn254_g1.cuh"
 #include <string.h>
 
 static ge_niels g_btab[ZKLC_ED_BTABLE];
@@ -86,4 +87,36 @@ u64 hostsim_gl_op(int op, u64 a, u64 b) {
 void hostsim_poseidon_gl_permute(u64 *s) { poseidon_gl_permute(s); }
 void hostsim_poseidon_gl_hash(const u64 *in, u32 len, u64 *out4) { poseidon_gl_hash_or_noop(in, 1, len, out4); }
 void hostsim_poseidon_gl_two_to_one(const u64 *l, const u64 *r, u64 *out4) { poseidon_gl_two_to_one(l, r, out4); }
+
+// BN254: operands and results in gnark Montgomery words (8 x u32 per Fp element)
+void hostsim_fp_op(int op, const u32 *a, const u32 *b, u32 *out) {
+    fp xl = fp_from_gnark(a), yl = fp_from_gnark(b), x = fp_reduce(xl), y = fp_reduce(yl), r;
+    switch (op) {
+        case 0: r = fp_add(x, y); break;
+        case 1: r = fp_sub(x, y); break;
+        case 2: r = fp_mul(xl, yl); break;  // lazy operands straight into the multiplier
+        case 3: r = fp_sqr(xl); break;
+        case 4: r = fp_inv(x); break;
+        case 5: r = fp_mul(fp_sub(fp_sub(fp_mul(x, y), x), fp_dbl(y)), fp_add(fp_add(x, y), fp_mul(x, x))); break;  // lazy chains
+        default: r = fp_zero();
+    }
+    fp_to_gnark(out, r);
+}
+// op 0: P + Q (mixed), 1: P - Q (mixed), 2: 2P, 3: (P + Q) + (P + Q) general add, 4: ((P+Q)+Q)+... chain of n mixed adds of Q
+u32 hostsim_g1_op(int op, const u32 *p16, u32 pinf, const u32 *q16, u32 qinf, u32 n, u32 *out16) {
+    g1_aff P, Q;
+    P.x = fp_from_gnark(p16); P.y = fp_from_gnark(p16 + 8); P.inf = pinf;
+    Q.x = fp_from_gnark(q16); Q.y = fp_from_gnark(q16 + 8); Q.inf = qinf;
+    g1_xyzz a = g1_from_affine(P), r;
+    switch (op) {
+        case 0: r = qinf ? a : g1_add_affine(a, Q.x, Q.y, 0); break;  // Q stays lazy, as in the MSM bucket loop
+        case 1: r = qinf ? a : g1_add_affine(a, Q.x, Q.y, 1); break;
+        case 2: r = g1_double(a); break;
+        case 3: { g1_xyzz s = qinf ? a : g1_add_affine(a, Q.x, Q.y, 0); r = g1_add(s, s); break; }
+        case 4: { r = a; for (u32 i = 0; i < n; i++) r = g1_add_affine(r, Q.x, Q.y, 0); break; }
+        case 5: { g1_xyzz s = g1_from_affine(Q); r = g1_add(a, s); break; }
+        default: r = g1_infinity();
+    }
+    return g1_to_affine_gnark(out16, r);
+}
 }

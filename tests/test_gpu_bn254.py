@@ -1,0 +1,101 @@
+"""GPU parity: BN254 G1 MSM through the C ABI vs the oracle (affine result, bit-exact)."""
+import numpy as np
+import pytest
+
+from oracle import bn254 as bn
+from oracle import cport
+
+pytestmark = pytest.mark.gpu
+
+
+def scalar_words(s):
+    return [(s >> (64 * i)) & (2**64 - 1) for i in range(4)]
+
+
+def rand_scalars(rng, n):
+    sc = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)  # < 2^252 < r
+    return sc
+
+
+def unwords(w):
+    return (bn.from_mont_words([int(x) for x in w[:4]]), bn.from_mont_words([int(x) for x in w[4:]]))
+
+
+def test_tiny_against_python(zctx):
+    pts = cport.bn254_gen_points(5, 7, 11)
+    scalars = [0, 1, bn.R - 1, 123456789, 2**200 + 17]
+    sc = np.array([scalar_words(s) for s in scalars], dtype=np.uint64)
+    out, inf = zctx.bn254_g1_msm(pts, sc)
+    want = bn.msm(scalars, [bn.mul(7 + 11 * i, bn.G1) for i in range(5)])
+    assert not inf and unwords(out) == want
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1000, 5000, 40000])
+def test_uniform_scalars(zctx, n):
+    rng = np.random.default_rng(n)
+    pts = cport.bn254_gen_points(n, 3, 5) if n else np.zeros((0, 8), np.uint64)
+    sc = rand_scalars(rng, n)
+    got, ginf = zctx.bn254_g1_msm(pts, sc)
+    want, winf, _ = cport.bn254_msm(pts, sc, nthreads=4) if n else (np.zeros(8, np.uint64), True, 1)
+    assert ginf == winf and np.array_equal(got, want)
+
+
+def test_witness_like_distribution(zctx):
+    """50% in {0,1}, 30% < 2^64, 20% uniform -> one huge bucket (heavy path)."""
+    rng = np.random.default_rng(5)
+    n = 30000
+    pts = cport.bn254_gen_points(n, 9, 2)
+    sc = rand_scalars(rng, n)
+    kind = rng.random(n)
+    sc[kind < 0.5] = 0
+    sc[kind < 0.5, 0] = rng.integers(0, 2, size=int((kind < 0.5).sum()), dtype=np.uint64)
+    mid = (kind >= 0.5) & (kind < 0.8)
+    sc[mid, 1:] = 0
+    got, ginf = zctx.bn254_g1_msm(pts, sc)
+    want, winf, _ = cport.bn254_msm(pts, sc, nthreads=4)
+    assert ginf == winf and np.array_equal(got, want)
+
+
+def test_adversarial_equal_points_and_scalars(zctx):
+    """(A): all points equal (every bucket addition after the first is a DOUBLING), all scalars equal,
+    points at infinity in the input, and a cancelling pair."""
+    n = 3000
+    one = cport.bn254_gen_points(1, 7, 11)
+    pts = np.repeat(one, n, axis=0)
+    sc = np.tile(np.array(scalar_words(0x1234567890ABCDEF1234567890ABCDEF), dtype=np.uint64), (n, 1))
+    got, ginf = zctx.bn254_g1_msm(pts, sc)
+    want = bn.mul(n * 0x1234567890ABCDEF1234567890ABCDEF, bn.mul(7, bn.G1))
+    assert not ginf and unwords(got) == want
+    # infinity inputs are skipped
+    pts2 = cport.bn254_gen_points(100, 3, 5)
+    pts2[::3] = 0
+    sc2 = rand_scalars(np.random.default_rng(1), 100)
+    got, ginf = zctx.bn254_g1_msm(pts2, sc2)
+    want, winf, _ = cport.bn254_msm(pts2, sc2)
+    assert ginf == winf and np.array_equal(got, want)
+    # s*P + (r - s)*P = infinity
+    two = np.vstack([one, one])
+    s2 = np.array([scalar_words(5), scalar_words(bn.R - 5)], dtype=np.uint64)
+    got, ginf = zctx.bn254_g1_msm(two, s2)
+    assert ginf and not got.any()
+
+
+def test_linearity_at_2_pow_18(zctx):
+    """Full-size property: MSM(a + b) = MSM(a) + MSM(b) on 2^18 points, and agreement with the oracle."""
+    n = 1 << 18
+    rng = np.random.default_rng(18)
+    pts = cport.bn254_gen_points(n, 5, 3)
+    a, b = rand_scalars(rng, n), rand_scalars(rng, n)
+    a[:, 3] >>= np.uint64(1)
+    b[:, 3] >>= np.uint64(1)
+    s = a.astype(object) + 0
+    ai = [sum(int(a[i, k]) << (64 * k) for k in range(4)) for i in range(0, n, 1)]
+    bi = [sum(int(b[i, k]) << (64 * k) for k in range(4)) for i in range(0, n, 1)]
+    ab = np.array([scalar_words(x + y) for x, y in zip(ai, bi)], dtype=np.uint64)
+    ra, _ = zctx.bn254_g1_msm(pts, a)
+    rb, _ = zctx.bn254_g1_msm(pts, b)
+    rab, _ = zctx.bn254_g1_msm(pts, ab)
+    assert bn.add(unwords(ra), unwords(rb)) == unwords(rab)
+    want, _, _ = cport.bn254_msm(pts, a, nthreads=8)
+    assert np.array_equal(ra, want)
