@@ -17,6 +17,15 @@ data-path collective -- the approval sets of different blocks are independent).
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement)
 including `roofline` (HBM, algorithmic bytes 97 B/signature) and `cpu_baseline`
 (the oracle's C restatement on the host cores; kind = "port").
+
+After the timed headline region the same process measures the other stages of the
+path (their numbers ride along in `stages`, each with its own roofline block and,
+on one GPU, a bounded CPU sample of the oracle):
+  msm      BN254 G1 MSM, 2^22 points per GPU (C4); N > 1: index-sharded, partial sums
+           all-gathered over RCCL and added with a unit-scalar MSM (inside the timing)
+  lde      Goldilocks coset LDE 234 x (2^17 -> 2^20), bit-reversed output (C3)
+  merkle   Poseidon leaf hashing + Merkle tree, 2^20 leaves x 234 columns, cap height 4 (C3)
+`--no-stages` skips them.
 """
 import argparse
 import json
@@ -102,6 +111,137 @@ def cpu_baseline(pk, sg, ms, budget_s=12.0):
                       "gcc -O3 -fopenmp, %.1f s" % (done, pk.shape[0], dt)}
 
 
+def _time_stream(fn, stream, iters, barrier):
+    """average ms of `fn` over `iters` launches on `stream` (HIP events), after one warm-up"""
+    import torch
+    fn()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(iters):
+        fn()
+    e1.record(stream)
+    barrier()
+    wall = (time.perf_counter() - t0) / iters * 1e3
+    return e0.elapsed_time(e1) / iters, wall
+
+
+def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
+    """Secondary measurements: MSM (C4), LDE and Merkle commit (C3).  Returns a dict on every rank."""
+    import torch
+    import torch.distributed as dist
+    from oracle import cport
+    import zklc_amd
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_max(x):
+        if world > 1:
+            t = torch.tensor([x], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t[0])
+        return x
+
+    res = {}
+    threads = host_cores()
+    # ---------------- MSM: 2^msm_log points per GPU
+    n = 1 << args.msm_log
+    pts_h = cport.bn254_gen_points(n, 5 + 1000003 * rank, 3)      # (5 + 1000003 rank + 3 i) * G
+    rng = np.random.default_rng(1 + rank)
+    sc_h = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    sc_h[:, 3] &= np.uint64((1 << 60) - 1)                        # < 2^252 < r
+    d_pts = torch.from_numpy(pts_h.view(np.int64)).to(dev)
+    d_sc = torch.from_numpy(sc_h.view(np.int64)).to(dev)
+    wb = ctx.bn254_g1_msm_workspace_bytes(n)
+    d_ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+    d_out = torch.zeros(9, dtype=torch.int64, device=dev)         # 8 words + infinity flag (as int64 for the gather)
+    d_inf = torch.zeros(2, dtype=torch.int32, device=dev)
+    gathered = [torch.zeros(9, dtype=torch.int64, device=dev) for _ in range(world)]
+    d_cpts = torch.zeros((world, 8), dtype=torch.int64, device=dev)
+    d_ones = torch.zeros((world, 4), dtype=torch.int64, device=dev)
+    d_ones[:, 0] = 1
+    wb2 = ctx.bn254_g1_msm_workspace_bytes(world)
+    d_ws2 = torch.empty(wb2, dtype=torch.uint8, device=dev)
+    d_final = torch.zeros(8, dtype=torch.int64, device=dev)
+
+    def msm_step():
+        ctx.bn254_g1_msm_dev(d_pts, d_sc, n, d_out, d_inf, d_ws, wb, stream=stream)
+        if world > 1:
+            with torch.cuda.stream(stream):
+                d_out[8] = d_inf[0]
+                dist.all_gather(gathered, d_out)
+                g = torch.stack(gathered)
+                d_cpts.copy_(g[:, :8] * (g[:, 8:9] == 0))            # infinity partials -> (0, 0)
+            ctx.bn254_g1_msm_dev(d_cpts, d_ones, world, d_final, d_inf[1:], d_ws2, wb2, stream=stream)
+
+    ms, wall = _time_stream(msm_step, stream, 3, barrier)
+    ms, wall = reduce_max(ms), reduce_max(wall)
+    msm = {"metric": "BN254 G1 MSM", "value": n * world / (wall * 1e-3) / 1e6, "unit": "Melem/s", "points_per_gpu": n,
+           "ms": wall, "kernel_ms": ms,
+           "roofline": {"bound": "hbm", "achieved": 96.0 * n / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": 96.0 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "algorithmic bytes = 96 B/element (64 B point + 32 B scalar); integer-VALU-bound"}}
+    if with_cpu:
+        t0 = time.perf_counter()
+        want, winf, used = cport.bn254_msm(pts_h, sc_h, nthreads=threads)
+        dt = time.perf_counter() - t0
+        got = d_out[:8].cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, want), "GPU MSM differs from the oracle"
+        msm["cpu_baseline"] = {"value": n / dt / 1e6, "unit": "Melem/s", "cores": used, "kind": "port",
+                               "sample": "the same 2^%d-point MSM once, oracle/c/bn254_oracle.c (also the parity check)" % args.msm_log}
+    res["msm"] = msm
+    del d_pts, d_sc, d_ws, pts_h, sc_h
+    torch.cuda.empty_cache()
+
+    # ---------------- LDE + Merkle commit at the C3 shape
+    log_n, rate, batch, cap = 17, 3, 234, 4
+    nn, N = 1 << log_n, 1 << (log_n + rate)
+    g = torch.Generator(device=dev).manual_seed(0xC0FFEE + rank)
+    coeffs = torch.randint(0, 2**63 - 1, (batch, nn), generator=g, device=dev, dtype=torch.int64)  # < p: canonical
+    lde = torch.empty((batch, N), dtype=torch.int64, device=dev)
+    ms, wall = _time_stream(lambda: ctx.gl_lde_dev(coeffs, log_n, rate, batch, 7, lde, flags=zklc_amd._lib.NTT_OUT_BITREV, stream=stream),
+                            stream, 5, barrier)
+    ms = reduce_max(ms)
+    alg = 8.0 * (nn + N) * batch
+    res["lde"] = {"metric": "Goldilocks coset LDE 234 x (2^17 -> 2^20)", "value": world * alg / (ms * 1e-3) / 1e9, "unit": "GB/s",
+                  "ms": ms, "gbutterflies_per_s": world * (N // 2) * (log_n + rate) * batch / (ms * 1e-3) / 1e9,
+                  "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                               "note": "algorithmic bytes = 8*(n + N) per polynomial (read coefficients once, write evaluations once)"}}
+    words = ctx.gl_merkle_tree_words(log_n + rate, cap)
+    tree = torch.empty(words, dtype=torch.int64, device=dev)
+    ms, wall = _time_stream(lambda: ctx.gl_merkle_commit_dev(lde, N, log_n + rate, batch, cap, tree, stream=stream), stream, 3, barrier)
+    ms = reduce_max(ms)
+    algm = (8.0 * batch + 32) * N
+    res["merkle"] = {"metric": "Poseidon Merkle commit, 2^20 leaves x 234 columns, cap 4", "value": world * N / (ms * 1e-3) / 1e6,
+                     "unit": "Mleaf/s", "ms": ms, "mperm_per_s": world * (N * ((batch + 7) // 8) + N) / (ms * 1e-3) / 1e6,
+                     "roofline": {"bound": "hbm", "achieved": algm / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": algm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                  "note": "algorithmic bytes = 8*width + 32 per leaf; 30 Poseidon permutations per leaf: VALU-bound"}}
+    if with_cpu:
+        cb, cl = 16, 16
+        ch = coeffs[:cb].cpu().numpy().view(np.uint64)
+        t0 = time.perf_counter()
+        ref_lde = cport.gl_lde(ch, rate, 7, nthreads=threads)
+        dt = time.perf_counter() - t0
+        br = np.array([int(format(i, "020b")[::-1], 2) for i in range(N)])
+        assert np.array_equal(lde[:cb].cpu().numpy().view(np.uint64), ref_lde[:, br]), "GPU LDE differs from the oracle"
+        res["lde"]["cpu_baseline"] = {"value": 8.0 * (nn + N) * cb / dt / 1e9, "unit": "GB/s", "cores": threads, "kind": "port",
+                                      "sample": "%d of the 234 polynomials, oracle/c/goldilocks_oracle.c (also the parity check)" % cb}
+        sub = lde[:, :1 << cl].cpu().numpy().view(np.uint64).copy()
+        t0 = time.perf_counter()
+        lv = cport.gl_merkle_commit(sub, cap, nthreads=threads)
+        dt = time.perf_counter() - t0
+        assert np.array_equal(tree[:4 << cl].cpu().numpy().view(np.uint64).reshape(-1, 4), lv[0]), "GPU leaf digests differ from the oracle"
+        res["merkle"]["cpu_baseline"] = {"value": (1 << cl) / dt / 1e6, "unit": "Mleaf/s", "cores": threads, "kind": "port",
+                                         "sample": "the first 2^%d leaves (x 234 columns), oracle/c/goldilocks_oracle.c" % cl}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +249,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=8192, help="Block_i approval sets per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stages", action="store_true", help="only the headline C2 measurement")
+    ap.add_argument("--msm-log", type=int, default=22, help="log2 of the MSM size per GPU")
     args = ap.parse_args()
 
     import torch
@@ -175,6 +317,12 @@ def main():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         n_valid = int(c[0])
 
+    stages = None
+    if not args.no_stages:
+        del d_pk, d_sg, d_ms, d_ok, expect
+        torch.cuda.empty_cache()
+        stages = run_stages(args, ctx, dev, stream, rank, world, with_cpu=(world == 1 and not args.no_cpu_baseline))
+
     if rank == 0:
         total = n * world
         value = total * args.steps / elapsed
@@ -198,6 +346,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pk, sg, ms)
+        if stages is not None:
+            out["stages"] = stages
         print(json.dumps(out), flush=True)
     ctx.close()
     if world > 1:

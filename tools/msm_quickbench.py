@@ -1,0 +1,48 @@
+"""Quick timing of the BN254 G1 MSM at C4 sizes (not the driver's bench)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import zklc_amd  # noqa: E402
+from oracle import cport  # noqa: E402
+
+logs = [int(x) for x in sys.argv[1:]] or [16, 18, 20, 22]
+nmax = 1 << max(logs)
+t0 = time.time()
+pts_h = cport.bn254_gen_points(nmax, 5, 3)
+print("generated %d points in %.1f s" % (nmax, time.time() - t0), flush=True)
+rng = np.random.default_rng(1)
+sc_h = rng.integers(0, 2**63, size=(nmax, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(nmax, 4), dtype=np.uint64)
+sc_h[:, 3] &= np.uint64((1 << 60) - 1)
+pts = torch.from_numpy(pts_h.view(np.int64)).cuda()
+sc = torch.from_numpy(sc_h.view(np.int64)).cuda()
+with zklc_amd.Context(0) as c:
+    st = torch.cuda.Stream()
+    for lg in logs:
+        n = 1 << lg
+        wb = c.bn254_g1_msm_workspace_bytes(n)
+        ws = torch.empty(wb, dtype=torch.uint8, device="cuda")
+        out = torch.zeros(8, dtype=torch.int64, device="cuda")
+        inf = torch.zeros(1, dtype=torch.int32, device="cuda")
+        fn = lambda: c.bn254_g1_msm_dev(pts, sc, n, out, inf, ws, wb, stream=st)
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 3
+        e0.record(st)
+        for _ in range(iters):
+            fn()
+        e1.record(st)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        print("MSM 2^%d: %.2f ms  %.2f Melem/s  workspace %.0f MB" % (lg, ms, n / ms / 1e3, wb / 1e6), flush=True)
+        if lg <= 20:
+            t0 = time.time()
+            want, winf, used = cport.bn254_msm(pts_h[:n], sc_h[:n], nthreads=16)
+            dt = time.time() - t0
+            got = out.cpu().numpy().view(np.uint64)
+            print("   oracle (C, %d threads): %.2f s  %.3f Melem/s  match=%s" % (used, dt, n / dt / 1e6, bool(np.array_equal(got, want))), flush=True)

@@ -14,3 +14,4 @@ There is no CPU fallback anywhere in this package.
 from ._lib import ZklcError, load, LIB_PATH, declared_symbols  # noqa: F401
 from .context import Context  # noqa: F401
 from . import signatures  # noqa: F401
+from . import distributed  # noqa: F401
