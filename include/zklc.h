@@ -105,6 +105,20 @@ int32_t zklc_gl_merkle_commit(zklc_ctx *ctx, const uint64_t *mat, uint64_t strid
 int32_t zklc_gl_merkle_commit_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_mat, uint64_t stride, uint32_t log_leaves,
                                   uint32_t width, uint32_t cap_height, uint64_t *d_tree);
 
+/* Poseidon-BN254 (iden3 t = 4) hasher of the last recursion -- replaces
+ * crypto/plonky2_bn128/src/poseidon_bn128.rs:18-108 (`permution`) and the `Hasher` impl
+ * crypto/plonky2_bn128/src/config.rs:132-199 (hash_no_pad / hash_or_noop / two_to_one).
+ * states: n x 4 Fr, each 4 little-endian u64 in REGULAR (non-Montgomery) canonical form
+ * (= ff's `to_repr`).  The Merkle entry points take the same poly-major Goldilocks matrix as
+ * zklc_gl_merkle_commit and produce a tree of the same shape whose digests are the 32-byte
+ * little-endian Fr value (= PoseidonBN128HashOut::to_bytes). */
+int32_t zklc_poseidon_bn254_permute(zklc_ctx *ctx, uint64_t *states, uint32_t n);
+int32_t zklc_poseidon_bn254_permute_dev(zklc_ctx *ctx, void *stream, uint64_t *d_states, uint32_t n);
+int32_t zklc_bn254_merkle_commit(zklc_ctx *ctx, const uint64_t *mat, uint64_t stride, uint32_t log_leaves, uint32_t width,
+                                 uint32_t cap_height, uint64_t *tree_out);
+int32_t zklc_bn254_merkle_commit_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_mat, uint64_t stride, uint32_t log_leaves,
+                                     uint32_t width, uint32_t cap_height, uint64_t *d_tree);
+
 /* ---- (c) BN254 ---------------------------------------------------------------
  * G1 multi-scalar multiplication sum_i scalars[i] * points[i].
  * Replaces gnark-crypto `bn254.G1Affine.MultiExp` (un-vendored; gnark-plonky2-verifier/go.mod:9)

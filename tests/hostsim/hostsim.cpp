@@ -4,6 +4,7 @@
 #include "../../zk-light-client-implementation_amd/csrc/ed25519_verify.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/poseidon_gl.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/bn254_g1.cuh"
+#include "../../zk-light-client-implementation_amd/csrc/poseidon_bn254.cuh"
 #include <string.h>
 
 static ge_niels g_btab[ZKLC_ED_BTABLE];
@@ -119,4 +120,14 @@ u32 hostsim_g1_op(int op, const u32 *p16, u32 pinf, const u32 *q16, u32 qinf, u3
     }
     return g1_to_affine_gnark(out16, r);
 }
+
+// Poseidon-BN254: states as 4 x 8 words, regular (non-Montgomery) form
+void hostsim_poseidon_bn254_permute(u32 *st32) {
+    fr s[4];
+    for (int i = 0; i < 4; i++) s[i] = fr_from_regular(st32 + 8 * i);
+    poseidon_bn254_permute(s);
+    for (int i = 0; i < 4; i++) fr_to_regular(st32 + 8 * i, s[i]);
+}
+void hostsim_poseidon_bn254_hash(const u64 *in, u32 len, u32 *out8) { poseidon_bn254_hash_or_noop(in, 1, len, out8); }
+void hostsim_poseidon_bn254_two_to_one(const u32 *l, const u32 *r, u32 *out8) { poseidon_bn254_two_to_one(l, r, out8); }
 }

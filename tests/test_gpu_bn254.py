@@ -99,3 +99,41 @@ def test_linearity_at_2_pow_18(zctx):
     assert bn.add(unwords(ra), unwords(rb)) == unwords(rab)
     want, _, _ = cport.bn254_msm(pts, a, nthreads=8)
     assert np.array_equal(ra, want)
+
+
+# ---------------- Poseidon-BN254 hasher (a8)
+def _fr_words(x):
+    return [(x >> (64 * i)) & (2**64 - 1) for i in range(4)]
+
+
+def _fr_int(w):
+    return sum(int(w[i]) << (64 * i) for i in range(4))
+
+
+def test_poseidon_bn254_kats_and_random(zctx):
+    from oracle import poseidon_bn254 as pb
+    import random
+    rng = random.Random(2)
+    ins = [k["in"] for k in pb.KATS] + [[rng.randrange(pb.R) for _ in range(4)] for _ in range(70)]
+    st = np.array([[_fr_words(x) for x in s] for s in ins], dtype=np.uint64)
+    out = zctx.poseidon_bn254_permute(st)
+    for i, k in enumerate(pb.KATS):   # crypto/plonky2_bn128/src/poseidon_bn128.rs:133-180
+        assert [_fr_int(out[i, j]) for j in range(4)] == k["out"]
+    for i in range(len(pb.KATS), len(ins)):
+        assert [_fr_int(out[i, j]) for j in range(4)] == pb.permute(ins[i])
+
+
+@pytest.mark.parametrize("width,log_leaves,cap", [(1, 0, 0), (3, 2, 0), (4, 3, 1), (9, 4, 2), (10, 3, 3), (135, 6, 4), (19, 7, 0)])
+def test_bn254_merkle_commit(zctx, width, log_leaves, cap):
+    from oracle import poseidon_bn254 as pb
+    rng = np.random.default_rng(width * 7 + log_leaves)
+    GP = 2**64 - 2**32 + 1
+    a = rng.integers(0, 2**64, size=(width, 1 << log_leaves), dtype=np.uint64)
+    mat = np.where(a >= np.uint64(GP), a - np.uint64(GP), a)
+    cap_gpu, levels = zctx.bn254_merkle_commit(mat, cap)
+    n = 1 << log_leaves
+    layer = [pb.hash_or_noop([int(mat[p, i]) for p in range(width)]) for i in range(n)]
+    for l in range(log_leaves - cap + 1):
+        assert [_fr_int(d) for d in levels[l]] == layer
+        layer = [pb.two_to_one(layer[2 * i], layer[2 * i + 1]) for i in range(len(layer) // 2)]
+    assert len(cap_gpu) == 1 << cap

@@ -67,3 +67,31 @@ def test_g1_ops(hostsim):
     for _ in range(10):
         X, Y = bn.hash_to_curve(7, rng.randrange(10**6)), bn.hash_to_curve(7, rng.randrange(10**6))
         assert bn.is_on_curve(X) and gop(0, X, Y) == bn.add(X, Y)
+
+
+def test_poseidon_bn254(hostsim):
+    """crypto/plonky2_bn128/src/poseidon_bn128.rs:133-180 KATs + hasher packing (config.rs:132-199)."""
+    from oracle import poseidon_bn254 as pb
+    rng = random.Random(1)
+    w8l = lambda x: [(x >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+
+    def perm(st):
+        a = (ctypes.c_uint32 * 32)(*sum([w8l(x) for x in st], []))
+        hostsim.hostsim_poseidon_bn254_permute(a)
+        return [sum(a[8 * i + k] << (32 * k) for k in range(8)) for i in range(4)]
+    for k in pb.KATS:
+        assert perm(k["in"]) == k["out"]
+    for _ in range(3):
+        s = [rng.randrange(pb.R) for _ in range(4)]
+        assert perm(s) == pb.permute(s)
+    GP = 2**64 - 2**32 + 1
+    for n in [0, 1, 3, 4, 8, 9, 10, 18, 19, 135]:
+        v = [rng.randrange(GP) for _ in range(n)]
+        a = (ctypes.c_uint64 * max(1, n))(*v)
+        o = (ctypes.c_uint32 * 8)()
+        hostsim.hostsim_poseidon_bn254_hash(a, n, o)
+        assert sum(o[k] << (32 * k) for k in range(8)) == pb.hash_or_noop(v)
+    l, r = rng.randrange(pb.R), rng.randrange(pb.R)
+    o = (ctypes.c_uint32 * 8)()
+    hostsim.hostsim_poseidon_bn254_two_to_one((ctypes.c_uint32 * 8)(*w8l(l)), (ctypes.c_uint32 * 8)(*w8l(r)), o)
+    assert sum(o[k] << (32 * k) for k in range(8)) == pb.two_to_one(l, r)

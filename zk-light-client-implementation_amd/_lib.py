@@ -38,6 +38,12 @@ _SIGS = {
                                                ctypes.c_uint32, _u8p]),
     "zklc_gl_merkle_commit_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint64, ctypes.c_uint32,
                                                    ctypes.c_uint32, ctypes.c_uint32, _u8p]),
+    "zklc_poseidon_bn254_permute": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint32]),
+    "zklc_poseidon_bn254_permute_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint32]),
+    "zklc_bn254_merkle_commit": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32,
+                                                  ctypes.c_uint32, _u8p]),
+    "zklc_bn254_merkle_commit_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint64, ctypes.c_uint32,
+                                                      ctypes.c_uint32, ctypes.c_uint32, _u8p]),
     "zklc_bn254_g1_msm": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _u8p]),
     "zklc_bn254_g1_msm_workspace_bytes": (ctypes.c_uint64, [ctypes.c_uint64]),
     "zklc_bn254_g1_msm_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _u8p, _u8p,

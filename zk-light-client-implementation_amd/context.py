@@ -166,6 +166,36 @@ class Context:
                                                         cap_height, _dev_ptr(d_tree)))
 
 
+    def poseidon_bn254_permute(self, states):
+        """states: uint64 [n, 4, 4] (regular-form Fr as 4 LE u64).  Returns the permuted copy."""
+        a = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 16).copy()
+        self._check(self._lib.zklc_poseidon_bn254_permute(self._h, a.ctypes.data, a.shape[0]))
+        return a.reshape(-1, 4, 4)
+
+    def poseidon_bn254_permute_dev(self, d_states, n, stream=None):
+        self._check(self._lib.zklc_poseidon_bn254_permute_dev(self._h, _stream_ptr(stream), _dev_ptr(d_states), n))
+
+    def bn254_merkle_commit(self, mat, cap_height):
+        """Poseidon-BN254 Merkle tree over a poly-major Goldilocks matrix [width, n_leaves]; same return shape as gl_merkle_commit."""
+        a = np.ascontiguousarray(mat, dtype=np.uint64)
+        width, n = a.shape
+        log_leaves = n.bit_length() - 1
+        if 1 << log_leaves != n:
+            raise ValueError("leaf count must be a power of two")
+        words = self.gl_merkle_tree_words(log_leaves, cap_height)
+        tree = np.zeros(words, dtype=np.uint64)
+        self._check(self._lib.zklc_bn254_merkle_commit(self._h, a.ctypes.data, n, log_leaves, width, cap_height, tree.ctypes.data))
+        levels, off = [], 0
+        for l in range(log_leaves - cap_height + 1):
+            m = n >> l
+            levels.append(tree[off:off + 4 * m].reshape(m, 4))
+            off += 4 * m
+        return levels[-1], levels
+
+    def bn254_merkle_commit_dev(self, d_mat, stride, log_leaves, width, cap_height, d_tree, stream=None):
+        self._check(self._lib.zklc_bn254_merkle_commit_dev(self._h, _stream_ptr(stream), _dev_ptr(d_mat), stride, log_leaves, width,
+                                                           cap_height, _dev_ptr(d_tree)))
+
     # ---- (c) BN254 -----------------------------------------------------
     def bn254_g1_msm(self, points, scalars):
         """points: uint64 [n, 8] (gnark Montgomery affine), scalars: uint64 [n, 4] (regular form).
