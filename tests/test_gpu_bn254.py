@@ -137,3 +137,47 @@ def test_bn254_merkle_commit(zctx, width, log_leaves, cap):
         assert [_fr_int(d) for d in levels[l]] == layer
         layer = [pb.two_to_one(layer[2 * i], layer[2 * i + 1]) for i in range(len(layer) // 2)]
     assert len(cap_gpu) == 1 << cap
+
+
+def test_golden_proof_merkle_paths_with_gpu_hashing(zctx):
+    """Walk the Merkle paths of the reference's golden proof (near_bft_finality/proofs/random/CGZP...)
+    with the GPU kernels only: leaf digests from bn254_merkle_commit, inner nodes from the Poseidon-BN254
+    permutation kernel; every path must end in the proof's own cap entry."""
+    from conftest import load_golden
+    from oracle import plonky2_verifier as V
+    j = load_golden("plonky2_near_random_CGZP.json")
+    pf = V.parse_proof(j["proof"], j["verifier_data"])
+    ch = V.challenges(pf, j["common_data"])
+    n_log = j["common_data"]["fri_params"]["degree_bits"] + 3
+    caps = [pf["constants_sigmas_cap"], pf["wires_cap"], pf["zs_pp_cap"], pf["quotient_cap"]]
+
+    def gpu_leaf_digest(leaf):
+        mat = np.array(leaf, dtype=np.uint64).reshape(-1, 1)      # [width, 1 leaf]
+        cap, _ = zctx.bn254_merkle_commit(mat, 0)
+        return _fr_int(cap[0])
+
+    def gpu_two_to_one(l, r):
+        st = np.array([[_fr_words(0), _fr_words(0), _fr_words(l), _fr_words(r)]], dtype=np.uint64)
+        return _fr_int(zctx.poseidon_bn254_permute(st)[0, 0])
+
+    checked = 0
+    for rnd, (init, steps) in enumerate(pf["rounds"][:2]):
+        x_index = ch["query_indices"][rnd] % (1 << n_log)
+        for k in range(4):
+            leaf, sib = init[k]
+            cur, idx = gpu_leaf_digest(leaf), x_index
+            for s in sib:
+                cur = gpu_two_to_one(s, cur) if idx & 1 else gpu_two_to_one(cur, s)
+                idx >>= 1
+            assert cur == caps[k][idx]
+            checked += 1
+        idx = x_index
+        for i, (evals, sib) in enumerate(steps):
+            idx >>= 4
+            cur, w = gpu_leaf_digest([c for e in evals for c in e]), idx
+            for s in sib:
+                cur = gpu_two_to_one(s, cur) if w & 1 else gpu_two_to_one(cur, s)
+                w >>= 1
+            assert cur == pf["commit_caps"][i][w]
+            checked += 1
+    assert checked == 12
