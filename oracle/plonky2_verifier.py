@@ -10,21 +10,51 @@ Restates, line by line, the reference's in-tree Go restatement of the plonky2 ve
   fri/fri.go:314-384     coset interpolation      fri/fri.go:386-497 query round
   fri/fri_utils.go:26-142 oracle / polynomial layout
   poseidon/bn254.go:47-120 hash_no_pad / hash_or_noop / two_to_one / to_vec
-What is NOT checked here: the vanishing-polynomial identity at zeta (plonk/plonk.go:121-250 and the
-14 gate evaluators) -- it constrains the openings, not the commitment/hash/FRI machinery this
-repo's kernels implement.  Everything that involves a hash, a Merkle path, the evaluation domain
-order or the FRI folding IS checked, which is what pins oracle/poseidon_gl.py,
-oracle/poseidon_bn254.py and the Merkle conventions against the reference's golden proofs.
+  plonk/plonk.go:60-250  vanishing-polynomial identity at zeta (gate evaluators: oracle/plonky2_gates.py)
+Both hash configurations are handled: "bn128" (PoseidonBN128GoldilocksConfig, the outer wrap -- all golden
+proofs in the tree) and "gl" (PoseidonGoldilocksConfig, the inner proofs; hash = 4 Goldilocks elements).
+Everything that involves a hash, a Merkle path, the evaluation-domain order, the FRI folding or a gate
+constraint IS checked, which is what pins oracle/poseidon_gl.py, oracle/poseidon_bn254.py,
+oracle/plonky2_gates.py and the Merkle conventions against the reference's golden proofs.
 """
 from . import goldilocks as gl
 from . import poseidon_bn254 as pbn
+from . import plonky2_gates as G
 from . import poseidon_gl as pgl
 
 P = gl.P
 
 
+class HasherBN128:
+    """PoseidonBN128Hash (crypto/plonky2_bn128/src/config.rs:132-199): digest = one Fr, JSON = decimal string"""
+    name = "bn128"
+    parse = staticmethod(lambda h: int(h))
+    dump = staticmethod(lambda h: str(h))
+    hash_or_noop = staticmethod(pbn.hash_or_noop)
+    hash_no_pad = staticmethod(pbn.hash_no_pad)
+    two_to_one = staticmethod(pbn.two_to_one)
+    to_vec = staticmethod(pbn.hash_to_vec)
+
+
+class HasherGL:
+    """PoseidonHash (plonky2 [UPSTREAM]; poseidon/goldilocks.go:72-90): digest = 4 Goldilocks elements,
+    JSON = {"elements": [..4..]}"""
+    name = "gl"
+    parse = staticmethod(lambda h: tuple(int(x) for x in h["elements"]))
+    dump = staticmethod(lambda h: {"elements": [int(x) for x in h]})
+    hash_or_noop = staticmethod(lambda v: tuple(pgl.hash_or_noop(v)))
+    hash_no_pad = staticmethod(lambda v: tuple(pgl.hash_no_pad(v)))
+    two_to_one = staticmethod(lambda a, b: tuple(pgl.two_to_one(a, b)))
+    to_vec = staticmethod(lambda h: list(h))
+
+
+def hasher_of(verifier_json):
+    return HasherGL if isinstance(verifier_json["circuit_digest"], dict) else HasherBN128
+
+
 class Challenger:
-    def __init__(self):
+    def __init__(self, hasher=HasherBN128):
+        self.H = hasher
         self.state = [0] * 12
         self.inp = []
         self.out = []
@@ -39,12 +69,12 @@ class Challenger:
         for e in es:
             self.observe(e)
 
-    def observe_bn254_hash(self, h):
-        self.observe_many(pbn.hash_to_vec(h))
+    def observe_hash(self, h):
+        self.observe_many(self.H.to_vec(h))
 
     def observe_cap(self, cap):
         for h in cap:
-            self.observe_bn254_hash(h)
+            self.observe_hash(h)
 
     def observe_ext(self, x):
         self.observe_many(list(x))
@@ -88,34 +118,37 @@ def reduce_with_powers(terms, alpha):
 
 
 def parse_proof(proof_json, verifier_json):
+    H = hasher_of(verifier_json)
+    hp = H.parse
     pr = proof_json["proof"]
     ext = lambda v: [(int(a) % P, int(b) % P) for a, b in v]
     o = pr["openings"]
     op = pr["opening_proof"]
     rounds = []
     for q in op["query_round_proofs"]:
-        init = [([int(x) for x in ep[0]], [int(s) for s in ep[1]["siblings"]]) for ep in q["initial_trees_proof"]["evals_proofs"]]
-        steps = [(ext(st["evals"]), [int(s) for s in st["merkle_proof"]["siblings"]]) for st in q["steps"]]
+        init = [([int(x) for x in ep[0]], [hp(s) for s in ep[1]["siblings"]]) for ep in q["initial_trees_proof"]["evals_proofs"]]
+        steps = [(ext(st["evals"]), [hp(s) for s in st["merkle_proof"]["siblings"]]) for st in q["steps"]]
         rounds.append((init, steps))
     return {
         "public_inputs": [int(x) for x in proof_json["public_inputs"]],
-        "wires_cap": [int(x) for x in pr["wires_cap"]],
-        "zs_pp_cap": [int(x) for x in pr["plonk_zs_partial_products_cap"]],
-        "quotient_cap": [int(x) for x in pr["quotient_polys_cap"]],
+        "hasher": H,
+        "wires_cap": [hp(x) for x in pr["wires_cap"]],
+        "zs_pp_cap": [hp(x) for x in pr["plonk_zs_partial_products_cap"]],
+        "quotient_cap": [hp(x) for x in pr["quotient_polys_cap"]],
         "openings": {k: ext(o[k]) for k in ["constants", "plonk_sigmas", "wires", "plonk_zs", "plonk_zs_next", "partial_products", "quotient_polys"]},
-        "commit_caps": [[int(x) for x in cap] for cap in op["commit_phase_merkle_caps"]],
+        "commit_caps": [[hp(x) for x in cap] for cap in op["commit_phase_merkle_caps"]],
         "final_poly": ext(op["final_poly"]["coeffs"]),
         "pow_witness": int(op["pow_witness"]),
         "rounds": rounds,
-        "circuit_digest": int(verifier_json["circuit_digest"]),
-        "constants_sigmas_cap": [int(x) for x in verifier_json["constants_sigmas_cap"]],
+        "circuit_digest": hp(verifier_json["circuit_digest"]),
+        "constants_sigmas_cap": [hp(x) for x in verifier_json["constants_sigmas_cap"]],
     }
 
 
-def merkle_verify_bn254(leaf, index, siblings, cap):
-    cur = pbn.hash_or_noop(leaf)
+def merkle_verify(H, leaf, index, siblings, cap):
+    cur = H.hash_or_noop(leaf)
     for s in siblings:
-        cur = pbn.two_to_one(s, cur) if index & 1 else pbn.two_to_one(cur, s)
+        cur = H.two_to_one(s, cur) if index & 1 else H.two_to_one(cur, s)
         index >>= 1
     return cur == cap[index]
 
@@ -123,8 +156,8 @@ def merkle_verify_bn254(leaf, index, siblings, cap):
 def challenges(pf, common):
     cfg = common["config"]
     nch = cfg["num_challenges"]
-    ch = Challenger()
-    ch.observe_bn254_hash(pf["circuit_digest"])
+    ch = Challenger(pf["hasher"])
+    ch.observe_hash(pf["circuit_digest"])
     ch.observe_many(pgl.hash_no_pad(pf["public_inputs"]))
     ch.observe_cap(pf["wires_cap"])
     betas, gammas = ch.challenges(nch), ch.challenges(nch)
@@ -151,6 +184,27 @@ def challenges(pf, common):
             "pow_response": pow_response, "query_indices": indices, "batches": [batch0, batch1]}
 
 
+def check_vanishing(pf, common, ch):
+    """plonk.go:209-250: vanishing(zeta) == Z_H(zeta) * reduce_with_powers(quotient chunk openings, zeta^n)"""
+    K = G.ExtK
+    o = pf["openings"]
+    degree_bits = common["fri_params"]["degree_bits"]
+    n = 1 << degree_bits
+    zeta = ch["zeta"]
+    zeta_pow_n = ext_pow(zeta, n)
+    zh = gl.ext_sub(zeta_pow_n, (1, 0))
+    l0 = gl.ext_mul(zh, gl.ext_inv(gl.ext_sub(gl.ext_mul(zeta, (n % P, 0)), (n % P, 0))))
+    gates = [G.gate_from_id(g) for g in common["gates"]]
+    pih = pgl.hash_no_pad(pf["public_inputs"])
+    terms = G.vanishing_terms(K, common, gates, zeta, l0, o["constants"], o["plonk_sigmas"], o["wires"], o["plonk_zs"],
+                              o["plonk_zs_next"], o["partial_products"], ch["betas"], ch["gammas"], pih)
+    qdf = common["quotient_degree_factor"]
+    for i, a in enumerate(ch["alphas"]):
+        van = reduce_with_powers(terms, (a, 0))
+        t = reduce_with_powers(o["quotient_polys"][i * qdf:(i + 1) * qdf], zeta_pow_n)
+        assert van == gl.ext_mul(zh, t), "vanishing polynomial identity, challenge %d" % i
+
+
 def verify(proof_json, verifier_json, common, max_rounds=None):
     """Returns the derived challenges; raises AssertionError on any failed check."""
     pf = parse_proof(proof_json, verifier_json)
@@ -164,6 +218,8 @@ def verify(proof_json, verifier_json, common, max_rounds=None):
     degree_bits, rate_bits, cap_h = fp["degree_bits"], fc["rate_bits"], fc["cap_height"]
     n_log = degree_bits + rate_bits
     nch = cfg["num_challenges"]
+    if "selectors_info" in common:
+        check_vanishing(pf, common, ch)
     # oracle layout (fri_utils.go:60-142)
     n_pre = common["num_constants"] + cfg["num_routed_wires"]
     widths = [n_pre, cfg["num_wires"], nch * (1 + common["num_partial_products"]), nch * common["quotient_degree_factor"]]
@@ -184,7 +240,7 @@ def verify(proof_json, verifier_json, common, max_rounds=None):
         for k in range(4):
             leaf, sib = init[k]
             assert len(leaf) == widths[k] and len(sib) == n_log - cap_h
-            assert merkle_verify_bn254(leaf, x_index, sib, caps[k]), "initial tree %d, round %d" % (k, rnd)
+            assert merkle_verify(pf["hasher"], leaf, x_index, sib, caps[k]), "initial tree %d, round %d" % (k, rnd)
         # x = g_mult * w^(bitrev(x_index)) (fri.go:187-206)
         rev = int(format(x_index, "0%db" % n_log)[::-1], 2)
         x = gl.GENERATOR * pow(gl.root_of_unity(n_log), rev, P) % P
@@ -225,7 +281,7 @@ def verify(proof_json, verifier_json, common, max_rounds=None):
             flat = [c for e in evals for c in e]
             bits -= arity_bits
             assert len(sib) == bits - cap_h
-            assert merkle_verify_bn254(flat, coset, sib, pf["commit_caps"][i]), "commit-phase tree %d, round %d" % (i, rnd)
+            assert merkle_verify(pf["hasher"], flat, coset, sib, pf["commit_caps"][i]), "commit-phase tree %d, round %d" % (i, rnd)
             assert coset >> (bits - cap_h) == cap_index
             x = pow(x, arity, P)
             idx = coset

@@ -23,7 +23,7 @@ def trim(name, pj, vj, cj):
     c = json.load(open(os.path.join(REF, cj)))
     p["proof"]["opening_proof"]["query_round_proofs"] = p["proof"]["opening_proof"]["query_round_proofs"][:KEEP]
     common = {k: c[k] for k in ["config", "fri_params", "num_constants", "num_partial_products", "quotient_degree_factor",
-                                "num_public_inputs", "num_gate_constraints", "gates", "k_is"] if k in c}
+                                "num_public_inputs", "num_gate_constraints", "gates", "k_is", "selectors_info"] if k in c}
     out = {"source": [pj, vj, cj], "kept_query_rounds": KEEP, "proof": p, "verifier_data": v, "common_data": common}
     path = os.path.join(OUT, "plonky2_%s.json" % name)
     json.dump(out, open(path, "w"), separators=(",", ":"))
