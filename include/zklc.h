@@ -119,6 +119,74 @@ int32_t zklc_bn254_merkle_commit(zklc_ctx *ctx, const uint64_t *mat, uint64_t st
 int32_t zklc_bn254_merkle_commit_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_mat, uint64_t stride, uint32_t log_leaves,
                                      uint32_t width, uint32_t cap_height, uint64_t *d_tree);
 
+/* ---- (b') plonky2 prover -------------------------------------------------------
+ * Replaces `CircuitData::prove` of the un-vendored plonky2 fork (plonky2-near@2244a9d `plonk/prover.rs`
+ * prove_with_partition_witness: wires commit, Z / partial products, quotient, openings, FRI), reached from
+ *   near_bft_finality/src/prove_crypto/ed25519.rs:60,100 (ed25519 proofs, 2^17 rows x 234 wires)
+ *   near_bft_finality/src/prove_crypto/recursion.rs:95   (recursion proofs, 2^12 rows x 135 wires)
+ *   near_bft_finality/src/bin/prove_block.rs:279-287     (final wrap, Poseidon-BN128 hasher)
+ * The boundary is the one of `prove_with_partition_witness`: the caller has built the circuit (gates, constants,
+ * copy permutation) and generated the full witness; the library returns the proof in the byte format of
+ * `ProofWithPublicInputs::to_bytes()` (what prove_block.rs:320-458 writes to proof.bin).
+ * Gate constraints are evaluated by device code for the gate types in `zklc_plonky2_gate_type`
+ * (the .go files of gnark-plonky2-verifier/plonk/gates and the .rs files of crypto/plonky2_u32/src/gates). */
+enum zklc_plonky2_gate_type {
+    ZKLC_GATE_NOOP = 0, ZKLC_GATE_CONSTANT /* p0 = num_consts */, ZKLC_GATE_PUBLIC_INPUT, ZKLC_GATE_ARITHMETIC /* p0 = num_ops */,
+    ZKLC_GATE_ARITHMETIC_EXT /* p0 = num_ops */, ZKLC_GATE_MUL_EXT /* p0 = num_ops */, ZKLC_GATE_BASE_SUM /* p0 = num_limbs, p1 = base */,
+    ZKLC_GATE_POSEIDON, ZKLC_GATE_POSEIDON_MDS, ZKLC_GATE_RANDOM_ACCESS /* p0 = bits, p1 = num_copies, p2 = num_extra_constants */,
+    ZKLC_GATE_REDUCING /* p0 = num_coeffs */, ZKLC_GATE_REDUCING_EXT /* p0 = num_coeffs */, ZKLC_GATE_EXPONENTIATION /* p0 = num_power_bits */,
+    ZKLC_GATE_COSET_INTERPOLATION /* p0 = subgroup_bits, p1 = degree; extra = weights then subgroup points */,
+    ZKLC_GATE_U32_ARITHMETIC /* p0 = num_ops */, ZKLC_GATE_U32_ADD_MANY /* p0 = num_addends, p1 = num_ops */,
+    ZKLC_GATE_U32_SUBTRACTION /* p0 = num_ops */, ZKLC_GATE_U32_RANGE_CHECK /* p0 = num_input_limbs */,
+    ZKLC_GATE_COMPARISON /* p0 = num_bits, p1 = num_chunks */
+};
+typedef struct {
+    uint32_t type;            /* zklc_plonky2_gate_type */
+    uint32_t p[4];            /* gate parameters (see the enum) */
+    uint32_t selector_index;  /* which selector polynomial filters this gate (common_data selectors_info) */
+    uint32_t group_start, group_end; /* the selector group [start, end) this gate belongs to */
+    uint32_t extra_off;       /* offset in u64 words into gate_extra */
+} zklc_plonky2_gate;
+#define ZKLC_HASHER_POSEIDON_GL 0u     /* PoseidonGoldilocksConfig (inner proofs) */
+#define ZKLC_HASHER_POSEIDON_BN128 1u  /* PoseidonBN128GoldilocksConfig (final wrap, crypto/plonky2_bn128/src/config.rs:21-28) */
+typedef struct {
+    uint32_t degree_bits, num_wires, num_routed_wires, num_constants /* selectors included */, num_selectors, num_challenges;
+    uint32_t rate_bits, cap_height, proof_of_work_bits, num_query_rounds;
+    uint32_t quotient_degree_factor, num_partial_products, num_gate_constraints, num_public_inputs;
+    uint32_t hasher, num_gates, num_arities, arity_bits[8];
+} zklc_plonky2_params;
+typedef struct zklc_plonky2_circuit zklc_plonky2_circuit;
+/* gates: the circuit's gate list in common_data order (row i of the list = selector value i).  k_is: num_routed_wires
+ * coset shifts.  constants: num_constants x 2^degree_bits values (poly-major, selectors first); sigmas: num_routed_wires x
+ * 2^degree_bits values of the sigma polynomials on the subgroup.  All host pointers.  Preprocesses the circuit on the GPU
+ * (constants_sigmas commitment, circuit digest) and allocates the prover's working set in HBM. */
+int32_t zklc_plonky2_circuit_create(zklc_ctx *ctx, const zklc_plonky2_params *params, const zklc_plonky2_gate *gates,
+                                    const uint64_t *gate_extra, uint32_t gate_extra_words, const uint64_t *k_is,
+                                    const uint64_t *constants, const uint64_t *sigmas, zklc_plonky2_circuit **out);
+void zklc_plonky2_circuit_destroy(zklc_plonky2_circuit *c);
+/* verifier_only data: constants_sigmas_cap (2^cap_height digests of 32 bytes) and circuit_digest (32 bytes);
+ * Goldilocks digests = 4 u64 LE, BN128 digests = the Fr value little-endian (PoseidonBN128HashOut::to_bytes) */
+int32_t zklc_plonky2_verifier_data(zklc_plonky2_circuit *c, uint8_t *cap_out, uint8_t *digest_out);
+uint64_t zklc_plonky2_proof_bytes(zklc_plonky2_circuit *c);
+/* wires: num_wires x 2^degree_bits witness values (poly-major), public_inputs: num_public_inputs values (host).
+ * proof_out receives zklc_plonky2_proof_bytes() bytes.  Returns ZKLC_ERR_INVALID_ARG when the witness does not
+ * satisfy the copy constraints (the permutation product does not close). */
+int32_t zklc_plonky2_prove(zklc_ctx *ctx, zklc_plonky2_circuit *c, const uint64_t *wires, const uint64_t *public_inputs,
+                           uint8_t *proof_out, uint64_t proof_cap, uint64_t *proof_len);
+/* same with the witness matrix already resident in HBM; work is enqueued on `stream` and the call returns when the
+ * proof bytes are on the host (the Fiat-Shamir transcript runs on the host between kernels) */
+int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plonky2_circuit *c, const uint64_t *d_wires,
+                               const uint64_t *public_inputs, uint8_t *proof_out, uint64_t proof_cap, uint64_t *proof_len);
+/* challenges of the last proof, for stage-by-stage parity tests: betas, gammas, alphas (num_challenges each), zeta (2),
+ * fri_alpha (2), then one extension element per FRI reduction; returns the number of u64 written */
+uint32_t zklc_plonky2_last_challenges(zklc_plonky2_circuit *c, uint64_t *out, uint32_t cap);
+/* wall-clock milliseconds of the stages of the last proof: wires commit, partial products + commit, quotient + commit,
+ * openings, FRI (combine + commit phase), PoW, queries + serialisation, total; returns the number of doubles written */
+uint32_t zklc_plonky2_last_timings(zklc_plonky2_circuit *c, double *out_ms, uint32_t cap);
+/* PoseidonGate witness rows (host function, no GPU): inputs n x 12, swap n (0/1, NULL = all 0) -> rows n x 135
+ * in the wire layout of gnark-plonky2-verifier/plonk/gates/poseidon_gate.go:27-82 */
+int32_t zklc_poseidon_gl_gate_rows(const uint64_t *inputs, const uint64_t *swap, uint32_t n, uint64_t *rows);
+
 /* ---- (c) BN254 ---------------------------------------------------------------
  * G1 multi-scalar multiplication sum_i scalars[i] * points[i].
  * Replaces gnark-crypto `bn254.G1Affine.MultiExp` (un-vendored; gnark-plonky2-verifier/go.mod:9)

@@ -34,6 +34,7 @@ class HasherBN128:
     hash_no_pad = staticmethod(pbn.hash_no_pad)
     two_to_one = staticmethod(pbn.two_to_one)
     to_vec = staticmethod(pbn.hash_to_vec)
+    pad_to = 9      # config.rs:168-176: pad10*1 to a multiple of RATE * GOLDILOCKS_ELEMENTS
 
 
 class HasherGL:
@@ -46,6 +47,14 @@ class HasherGL:
     hash_no_pad = staticmethod(lambda v: tuple(pgl.hash_no_pad(v)))
     two_to_one = staticmethod(lambda a, b: tuple(pgl.two_to_one(a, b)))
     to_vec = staticmethod(lambda h: list(h))
+    pad_to = 8      # plonky2 plonk/config.rs `hash_pad` [UPSTREAM]: pad10*1 to a multiple of the sponge rate
+
+
+def hash_pad(H, inp):
+    v = list(inp) + [1]
+    while (len(v) + 1) % H.pad_to:
+        v.append(0)
+    return H.hash_no_pad(v + [1])
 
 
 def hasher_of(verifier_json):
@@ -96,7 +105,7 @@ class Challenger:
         for i, e in enumerate(self.inp):
             self.state[i] = e
         self.inp = []
-        self.state = pgl.permute(self.state)
+        self.state = pgl._perm(self.state)
         self.out = list(self.state[:8])
 
 

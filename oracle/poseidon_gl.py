@@ -82,19 +82,31 @@ def permute(state):
     return s
 
 
+_perm = permute
+
+
+def use_c_port():
+    """route the sponge / Merkle helpers below through oracle/c/goldilocks_oracle.c (checked equal to `permute`
+    in tests/test_oracle_c.py); used by the plonky2 prover restatement, where pure Python is too slow"""
+    global _perm
+    from . import cport
+    cport.load()
+    _perm = cport.poseidon_gl_permute
+
+
 def hash_n_to_m_no_pad(inp, n_out):
     s = [0] * 12
     for i in range(0, len(inp), RATE):
         chunk = inp[i:i + RATE]
         s[:len(chunk)] = chunk
-        s = permute(s)
+        s = _perm(s)
     out = []
     while True:
         for i in range(RATE):
             out.append(s[i])
             if len(out) == n_out:
                 return out
-        s = permute(s)
+        s = _perm(s)
 
 
 def hash_no_pad(inp):
@@ -108,7 +120,7 @@ def hash_or_noop(inp):
 
 
 def two_to_one(left, right):
-    return permute(list(left) + list(right) + [0] * 4)[:4]
+    return _perm(list(left) + list(right) + [0] * 4)[:4]
 
 
 def merkle_tree(leaves, cap_height):

@@ -48,6 +48,18 @@ _SIGS = {
     "zklc_bn254_g1_msm_workspace_bytes": (ctypes.c_uint64, [ctypes.c_uint64]),
     "zklc_bn254_g1_msm_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _u8p, _u8p,
                                                ctypes.c_uint64]),
+    "zklc_plonky2_circuit_create": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint32, _u8p,
+                                                     _u8p, _u8p, ctypes.POINTER(ctypes.c_void_p)]),
+    "zklc_plonky2_circuit_destroy": (None, [ctypes.c_void_p]),
+    "zklc_plonky2_verifier_data": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p]),
+    "zklc_plonky2_proof_bytes": (ctypes.c_uint64, [ctypes.c_void_p]),
+    "zklc_plonky2_prove": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, _u8p, _u8p, ctypes.c_uint64,
+                                            ctypes.POINTER(ctypes.c_uint64)]),
+    "zklc_plonky2_prove_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _u8p, _u8p, _u8p, ctypes.c_uint64,
+                                                ctypes.POINTER(ctypes.c_uint64)]),
+    "zklc_plonky2_last_challenges": (ctypes.c_uint32, [ctypes.c_void_p, _u8p, ctypes.c_uint32]),
+    "zklc_plonky2_last_timings": (ctypes.c_uint32, [ctypes.c_void_p, _u8p, ctypes.c_uint32]),
+    "zklc_poseidon_gl_gate_rows": (ctypes.c_int32, [_u8p, _u8p, ctypes.c_uint32, _u8p]),
 }
 
 NTT_INVERSE, NTT_IN_BITREV, NTT_OUT_BITREV = 1, 2, 4

@@ -25,8 +25,13 @@ def _newest(paths):
     return max((os.path.getmtime(p) for p in paths), default=0.0)
 
 
+HOST_CXX = os.environ.get("CXX", "g++")
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
+
+
 def _compile(src, obj, log):
-    cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+    # *.hip = device + host code for gfx950 (hipcc); *.cpp = host-only helpers (transcript), plain C++
+    cmd = ([HIPCC] + FLAGS if src.endswith(".hip") else [HOST_CXX] + HOST_FLAGS) + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
@@ -38,13 +43,13 @@ def _compile(src, obj, log):
 def build(verbose=True, force=False):
     os.makedirs(BUILD, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
     hdrs = glob.glob(os.path.join(CSRC, "*.cuh")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(
-        os.path.join(HERE, "..", "include", "*.h"))
+        os.path.join(CSRC, "*.inc")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     dep_time = _newest(hdrs + [os.path.abspath(__file__)])
     jobs, objs = [], []
     for s in srcs:
-        o = os.path.join(BUILD, os.path.basename(s)[:-4] + ".o")
+        o = os.path.join(BUILD, os.path.basename(s).replace(".", "_") + ".o")
         objs.append(o)
         if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), dep_time):
             jobs.append((s, o))

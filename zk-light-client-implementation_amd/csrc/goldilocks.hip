@@ -125,13 +125,15 @@ __global__ void __launch_bounds__(256) poseidon_gl_permute_kernel(u64 *states, u
     for (int k = 0; k < 12; k++) p[k] = s[k];
 }
 
-// leaf i = (mat[p * stride + i])_{p < width}; one lane per leaf, coalesced across lanes for every p
+// leaf i = (mat[p * stride + i * leaf_stride])_{p < width}; one lane per leaf.  Poly-major matrices (leaf_stride 1)
+// are coalesced across lanes for every p; leaf_stride = width, stride = 1 reads row-major leaves (FRI commit trees).
 __global__ void __launch_bounds__(256)
-gl_hash_leaves_kernel(const u64 *__restrict__ mat, size_t stride, u32 width, u32 n_leaves, u64 *__restrict__ digests) {
+gl_hash_leaves_kernel(const u64 *__restrict__ mat, size_t stride, size_t leaf_stride, u32 width, u32 n_leaves,
+                      u64 *__restrict__ digests) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_leaves) return;
     u64 h[4];
-    poseidon_gl_hash_or_noop(mat + i, stride, width, h);
+    poseidon_gl_hash_or_noop(mat + (size_t)i * leaf_stride, stride, width, h);
     ulonglong2 *o = reinterpret_cast<ulonglong2 *>(digests + (size_t)i * 4);
     o[0] = make_ulonglong2(h[0], h[1]);
     o[1] = make_ulonglong2(h[2], h[3]);
@@ -334,10 +336,15 @@ extern "C" int32_t zklc_gl_merkle_commit_dev(zklc_ctx *ctx, void *stream, const 
                                              uint32_t width, uint32_t cap_height, uint64_t *d_tree) {
     if (!ctx || !d_mat || !d_tree || log_leaves > 30 || cap_height > log_leaves || width == 0) return ZKLC_ERR_INVALID_ARG;
     if (stride < (1ULL << log_leaves)) return ZKLC_ERR_INVALID_ARG;
+    return zklc_gl_merkle_commit_strided(ctx, zklc_pick_stream(ctx, stream), d_mat, stride, 1, log_leaves, width, cap_height, d_tree);
+}
+
+int32_t zklc_gl_merkle_commit_strided(zklc_ctx *ctx, hipStream_t st, const uint64_t *d_mat, uint64_t stride, uint64_t leaf_stride,
+                                      uint32_t log_leaves, uint32_t width, uint32_t cap_height, uint64_t *d_tree) {
     ZKLC_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = zklc_pick_stream(ctx, stream);
     u32 n = 1u << log_leaves;
-    hipLaunchKernelGGL(gl_hash_leaves_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_mat, (size_t)stride, width, n, d_tree);
+    hipLaunchKernelGGL(gl_hash_leaves_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_mat, (size_t)stride, (size_t)leaf_stride,
+                       width, n, d_tree);
     ZKLC_HIP(ctx, hipGetLastError());
     u64 *level = d_tree;
     for (u32 l = 0; l < log_leaves - cap_height; l++) {

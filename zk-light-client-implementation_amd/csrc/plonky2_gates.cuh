@@ -1,0 +1,430 @@
+// plonky2 gate-constraint evaluators over the base field (one LDE point per lane) -- the `eval_unfiltered_base`
+// side of every gate type on the signature-aggregation path.  Row a9 of SURVEY section 8.
+//
+// Standard gates (un-vendored plonky2-near@2244a9d `plonky2/src/gates/*`), restated in the reference at
+//   gnark-plonky2-verifier/plonk/gates/{arithmetic,arithmetic_extension,multiplication_extension,base_sum,constant,
+//   public_input,poseidon,poseidon_mds,random_access,reducing,reducing_extension,exponentiation,coset_interpolation}_gate.go
+// u32 gates (in-tree): crypto/plonky2_u32/src/gates/{arithmetic_u32,add_many_u32,subtraction_u32,range_check_u32,
+//   comparison}.rs (`eval_unfiltered`).
+// Filters / selector groups: plonk/gates/evaluate_gates.go:34-105.
+//
+// Every evaluator pushes its constraints, in the reference's order, into a consumer that keeps
+// sum_i alpha_c^(offset + i) * constraint_i for each challenge c (plonk/plonk.go:186-205 reduces the full list with
+// powers of alpha; the sum over gates commutes with that reduction, so no per-constraint storage is needed).
+// Wires and constants are read straight from the bit-reversed LDE matrices (poly-major: column j at j * stride + p),
+// so lanes of a wave read 64 consecutive u64 of one column.
+#pragma once
+#include "gl_ext.cuh"
+#include "poseidon_gl.cuh"
+
+#define P2_MAX_CH 2
+#define P2_UNUSED_SELECTOR 0xFFFFFFFFULL
+
+enum p2_gate_type {
+    P2_NOOP = 0, P2_CONSTANT, P2_PUBLIC_INPUT, P2_ARITHMETIC, P2_ARITHMETIC_EXT, P2_MUL_EXT, P2_BASE_SUM, P2_POSEIDON,
+    P2_POSEIDON_MDS, P2_RANDOM_ACCESS, P2_REDUCING, P2_REDUCING_EXT, P2_EXPONENTIATION, P2_COSET_INTERPOLATION,
+    P2_U32_ARITHMETIC, P2_U32_ADD_MANY, P2_U32_SUBTRACTION, P2_U32_RANGE_CHECK, P2_COMPARISON, P2_NUM_GATE_TYPES
+};
+
+// mirrors zklc_plonky2_gate of include/zklc.h
+struct p2_gate {
+    u32 type;
+    u32 p[4];
+    u32 selector_index, group_start, group_end;
+    u32 extra_off;  // offset (u64 words) into the circuit's gate_extra table
+};
+
+struct p2_consumer {
+    u64 alpha[P2_MAX_CH], apow[P2_MAX_CH], acc[P2_MAX_CH];
+    int nch;
+    ZKLC_D void emit(u64 c) {
+#pragma unroll
+        for (int k = 0; k < P2_MAX_CH; k++)
+            if (k < nch) {
+                acc[k] = gl_add(acc[k], gl_mul(c, apow[k]));
+                apow[k] = gl_mul(apow[k], alpha[k]);
+            }
+    }
+    ZKLC_D void emit2(gl2 c) {
+        emit(c.a);
+        emit(c.b);
+    }
+};
+
+struct p2_vars {
+    const u64 *wires;   // LDE of the wire polynomials, column j at wires[j * stride + p]
+    const u64 *consts;  // LDE of the constants (selectors first); gate-local constant j = column nsel + j
+    size_t stride, p;
+    u32 nsel;
+    u64 pih[4];
+    ZKLC_D u64 w(u32 j) const { return wires[(size_t)j * stride + p]; }
+    ZKLC_D u64 c(u32 j) const { return consts[(size_t)(nsel + j) * stride + p]; }
+    ZKLC_D u64 sel(u32 j) const { return consts[(size_t)j * stride + p]; }
+    ZKLC_D gl2 wa(u32 j) const { return gl2_make(w(j), w(j + 1)); }
+};
+
+// prod_{k < base} (x - k)
+ZKLC_D u64 p2_range_product(u64 x, u32 base) {
+    u64 acc = x;
+    for (u32 k = 1; k < base; k++) acc = gl_mul(acc, gl_sub(x, k));
+    return acc;
+}
+
+ZKLC_D void p2_eval_constant(const p2_vars &v, u32 n, p2_consumer &out) {
+    for (u32 i = 0; i < n; i++) out.emit(gl_sub(v.c(i), v.w(i)));
+}
+
+ZKLC_D void p2_eval_public_input(const p2_vars &v, p2_consumer &out) {
+    for (u32 i = 0; i < 4; i++) out.emit(gl_sub(v.w(i), v.pih[i]));
+}
+
+ZKLC_D void p2_eval_arithmetic(const p2_vars &v, u32 num_ops, p2_consumer &out) {
+    u64 c0 = v.c(0), c1 = v.c(1);
+    for (u32 i = 0; i < num_ops; i++) {
+        u64 m0 = v.w(4 * i), m1 = v.w(4 * i + 1), a = v.w(4 * i + 2), o = v.w(4 * i + 3);
+        out.emit(gl_sub(o, gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(a, c1))));
+    }
+}
+
+ZKLC_D void p2_eval_arithmetic_ext(const p2_vars &v, u32 num_ops, p2_consumer &out) {
+    u64 c0 = v.c(0), c1 = v.c(1);
+    for (u32 i = 0; i < num_ops; i++) {
+        gl2 m0 = v.wa(8 * i), m1 = v.wa(8 * i + 2), a = v.wa(8 * i + 4), o = v.wa(8 * i + 6);
+        gl2 comp = gl2_add(gl2_scale(a, c1), gl2_scale(gl2_mul(m0, m1), c0));
+        out.emit2(gl2_sub(o, comp));
+    }
+}
+
+ZKLC_D void p2_eval_mul_ext(const p2_vars &v, u32 num_ops, p2_consumer &out) {
+    u64 c0 = v.c(0);
+    for (u32 i = 0; i < num_ops; i++) {
+        gl2 m0 = v.wa(6 * i), m1 = v.wa(6 * i + 2), o = v.wa(6 * i + 4);
+        out.emit2(gl2_sub(o, gl2_scale(gl2_mul(m0, m1), c0)));
+    }
+}
+
+ZKLC_D void p2_eval_base_sum(const p2_vars &v, u32 num_limbs, u32 base, p2_consumer &out) {
+    u64 acc = 0;
+    for (u32 i = num_limbs; i-- > 0;) acc = gl_add(gl_mul(acc, base), v.w(1 + i));
+    out.emit(gl_sub(acc, v.w(0)));
+    for (u32 i = 0; i < num_limbs; i++) out.emit(p2_range_product(v.w(1 + i), base));
+}
+
+// poseidon_gate.go:84-181
+ZKLC_D void p2_eval_poseidon(const p2_vars &v, p2_consumer &out) {
+    u64 swap = v.w(24);
+    out.emit(gl_mul(swap, gl_sub(swap, 1)));
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 lhs = v.w(i), rhs = v.w(i + 4), delta = v.w(25 + i);
+        out.emit(gl_sub(gl_mul(swap, gl_sub(rhs, lhs)), delta));
+        s[i] = gl_add(lhs, delta);
+        s[i + 4] = gl_sub(rhs, delta);
+    }
+#pragma unroll
+    for (int i = 8; i < 12; i++) s[i] = v.w(i);
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PGL_RC[12 * r + i]);
+        if (r != 0) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                u64 sin = v.w(29 + 12 * (r - 1) + i);
+                out.emit(gl_sub(s[i], sin));
+                s[i] = sin;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = pgl_sbox(s[i]);
+        pgl_mds(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PGL_FP_FIRST[i]);
+    {
+        u64 t[12];
+        t[0] = s[0];
+#pragma unroll
+        for (int d = 1; d < 12; d++) t[d] = 0;
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+        for (int r = 1; r < 12; r++) {
+            u64 sr = s[1];
+#pragma unroll
+            for (int d = 1; d < 12; d++) t[d] = gl_add(t[d], gl_mul(sr, PGL_FP_INIT[(r - 1) * 11 + d - 1]));
+#pragma unroll
+            for (int q = 1; q < 11; q++) s[q] = s[q + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = t[i];
+    }
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (int r = 0; r < 22; r++) {
+        u64 sin = v.w(65 + r);
+        out.emit(gl_sub(s[0], sin));
+        u64 s0 = gl_add(pgl_sbox(sin), PGL_FP_RC[r]);  // the 22nd constant is zero (poseidon_gate.go:151-155)
+        u64 d = gl_mul(s0, 25);
+#pragma unroll
+        for (int j = 1; j < 12; j++) d = gl_add(d, gl_mul(s[j], PGL_FP_WHATS[r * 11 + j - 1]));
+#pragma unroll
+        for (int j = 1; j < 12; j++) s[j] = gl_add(s[j], gl_mul(s0, PGL_FP_VS[r * 11 + j - 1]));
+        s[0] = d;
+    }
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            u64 x = gl_add(s[i], PGL_RC[12 * (26 + r) + i]);
+            u64 sin = v.w(87 + 12 * r + i);
+            out.emit(gl_sub(x, sin));
+            s[i] = pgl_sbox(sin);
+        }
+        pgl_mds(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) out.emit(gl_sub(s[i], v.w(12 + i)));
+}
+
+ZKLC_D void p2_eval_poseidon_mds(const p2_vars &v, p2_consumer &out) {
+    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    for (u32 r = 0; r < 12; r++) {
+        gl2 acc = gl2_make(0, 0);
+        for (u32 i = 0; i < 12; i++) acc = gl2_add(acc, gl2_scale(v.wa(2 * ((i + r) % 12)), C[i]));
+        if (r == 0) acc = gl2_add(acc, gl2_scale(v.wa(0), 8));
+        out.emit2(gl2_sub(v.wa(2 * (12 + r)), acc));
+    }
+}
+
+ZKLC_D void p2_eval_random_access(const p2_vars &v, u32 bits, u32 copies, u32 extra, p2_consumer &out) {
+    const u32 vs = 1u << bits;
+    const u32 routed = (2 + vs) * copies + extra;
+    for (u32 cp = 0; cp < copies; cp++) {
+        u32 base = (2 + vs) * cp;
+        u64 idx = v.w(base), claimed = v.w(base + 1);
+        u64 rec = 0;
+        for (u32 i = 0; i < bits; i++) {
+            u64 b = v.w(routed + cp * bits + i);
+            out.emit(gl_sub(gl_sqr(b), b));
+        }
+        for (u32 i = bits; i-- > 0;) rec = gl_add(gl_double(rec), v.w(routed + cp * bits + i));
+        out.emit(gl_sub(rec, idx));
+        // fold the list by the bits (lowest bit first): item = x + b (y - x); at most 64 entries (bits <= 6)
+        u64 items[64];
+        for (u32 i = 0; i < vs; i++) items[i] = v.w(base + 2 + i);
+        u32 len = vs;
+        for (u32 i = 0; i < bits; i++) {
+            u64 b = v.w(routed + cp * bits + i);
+            len >>= 1;
+            for (u32 k = 0; k < len; k++) items[k] = gl_add(items[2 * k], gl_mul(b, gl_sub(items[2 * k + 1], items[2 * k])));
+        }
+        out.emit(gl_sub(items[0], claimed));
+    }
+    for (u32 i = 0; i < extra; i++) out.emit(gl_sub(v.c(i), v.w((2 + vs) * copies + i)));
+}
+
+ZKLC_D void p2_eval_reducing(const p2_vars &v, u32 n, bool ext, p2_consumer &out) {
+    gl2 alpha = v.wa(2), acc = v.wa(4);
+    const u32 start_accs = 6 + (ext ? 2 * n : n);
+    for (u32 i = 0; i < n; i++) {
+        gl2 nxt = (i == n - 1) ? v.wa(0) : v.wa(start_accs + 2 * i);
+        gl2 coeff = ext ? v.wa(6 + 2 * i) : gl2_make(v.w(6 + i), 0);
+        out.emit2(gl2_sub(gl2_add(gl2_mul(acc, alpha), coeff), nxt));
+        acc = nxt;
+    }
+}
+
+ZKLC_D void p2_eval_exponentiation(const p2_vars &v, u32 n, p2_consumer &out) {
+    u64 base = v.w(0);
+    u64 prev_inter = 0;
+    for (u32 i = 0; i < n; i++) {
+        u64 prev = i == 0 ? 1 : gl_sqr(prev_inter);
+        u64 b = v.w(1 + (n - 1 - i));
+        u64 mul_by = gl_sub(gl_mul(b, base), gl_sub(b, 1));
+        u64 inter = v.w(2 + n + i);
+        out.emit(gl_sub(gl_mul(prev, mul_by), inter));
+        prev_inter = inter;
+    }
+    out.emit(gl_sub(v.w(1 + n), prev_inter));
+}
+
+// coset_interpolation_gate.go:152-226; extra = [barycentric weights (2^bits) | subgroup points w^i (2^bits)]
+ZKLC_D void p2_coset_partial(const p2_vars &v, const u64 *extra, u32 np, u32 s, u32 e, gl2 point, gl2 &ev, gl2 &prod) {
+    for (u32 i = s; i < e; i++) {
+        gl2 term = gl2_sub(point, gl2_make(extra[np + i], 0));
+        gl2 wv = gl2_scale(v.wa(1 + 2 * i), extra[i]);
+        ev = gl2_add(gl2_mul(ev, term), gl2_mul(wv, prod));
+        prod = gl2_mul(prod, term);
+    }
+}
+ZKLC_D void p2_eval_coset_interpolation(const p2_vars &v, u32 bits, u32 degree, const u64 *extra, p2_consumer &out) {
+    const u32 np = 1u << bits;
+    const u32 n_inter = (np - 2) / (degree - 1);
+    const u32 start_pt = 1 + 2 * np, start_val = start_pt + 2, start_inter = start_val + 2;
+    u64 shift = v.w(0);
+    gl2 point = v.wa(start_pt), shifted = v.wa(start_inter + 4 * n_inter);
+    out.emit2(gl2_add(gl2_scale(shifted, gl_neg(shift)), point));
+    gl2 ev = gl2_make(0, 0), prod = gl2_make(1, 0);
+    p2_coset_partial(v, extra, np, 0, degree, shifted, ev, prod);
+    for (u32 i = 0; i < n_inter; i++) {
+        gl2 iev = v.wa(start_inter + 2 * i), ipr = v.wa(start_inter + 2 * (n_inter + i));
+        out.emit2(gl2_sub(iev, ev));
+        out.emit2(gl2_sub(ipr, prod));
+        u32 s = 1 + (degree - 1) * (i + 1);
+        u32 e = s + degree - 1 < np ? s + degree - 1 : np;
+        ev = iev;
+        prod = ipr;
+        p2_coset_partial(v, extra, np, s, e, shifted, ev, prod);
+    }
+    out.emit2(gl2_sub(v.wa(start_val), ev));
+}
+
+// crypto/plonky2_u32/src/gates/arithmetic_u32.rs:110-165
+ZKLC_D void p2_eval_u32_arithmetic(const p2_vars &v, u32 num_ops, p2_consumer &out) {
+    for (u32 i = 0; i < num_ops; i++) {
+        u64 m0 = v.w(6 * i), m1 = v.w(6 * i + 1), add = v.w(6 * i + 2), lo = v.w(6 * i + 3), hi = v.w(6 * i + 4),
+            inv = v.w(6 * i + 5);
+        u64 computed = gl_add(gl_mul(m0, m1), add);
+        u64 diff = gl_sub(0xFFFFFFFFULL, hi);
+        u64 hi_not_max = gl_sub(gl_mul(inv, diff), 1);
+        out.emit(gl_mul(hi_not_max, lo));
+        out.emit(gl_sub(gl_add(gl_mul(hi, 1ULL << 32), lo), computed));
+        u64 comb_lo = 0, comb_hi = 0;
+        for (u32 j = 32; j-- > 0;) {
+            u64 l = v.w(6 * num_ops + 32 * i + j);
+            out.emit(p2_range_product(l, 4));
+            if (j < 16)
+                comb_lo = gl_add(gl_mul(comb_lo, 4), l);
+            else
+                comb_hi = gl_add(gl_mul(comb_hi, 4), l);
+        }
+        out.emit(gl_sub(comb_lo, lo));
+        out.emit(gl_sub(comb_hi, hi));
+    }
+}
+
+// add_many_u32.rs: per op (num_addends + 3) routed wires, then 16 + 2 two-bit limbs
+ZKLC_D void p2_eval_u32_add_many(const p2_vars &v, u32 num_addends, u32 num_ops, p2_consumer &out) {
+    const u32 per = num_addends + 3;
+    for (u32 i = 0; i < num_ops; i++) {
+        u64 sum = v.w(per * i + num_addends);  // carry in
+        for (u32 j = 0; j < num_addends; j++) sum = gl_add(sum, v.w(per * i + j));
+        u64 res = v.w(per * i + num_addends + 1), carry = v.w(per * i + num_addends + 2);
+        out.emit(gl_sub(gl_add(gl_mul(carry, 1ULL << 32), res), sum));
+        u64 comb_res = 0, comb_carry = 0;
+        for (u32 j = 18; j-- > 0;) {
+            u64 l = v.w(per * num_ops + 18 * i + j);
+            out.emit(p2_range_product(l, 4));
+            if (j < 16)
+                comb_res = gl_add(gl_mul(comb_res, 4), l);
+            else
+                comb_carry = gl_add(gl_mul(comb_carry, 4), l);
+        }
+        out.emit(gl_sub(comb_res, res));
+        out.emit(gl_sub(comb_carry, carry));
+    }
+}
+
+// subtraction_u32.rs: per op (x, y, borrow_in, result, borrow_out), then 16 two-bit limbs of result
+ZKLC_D void p2_eval_u32_subtraction(const p2_vars &v, u32 num_ops, p2_consumer &out) {
+    for (u32 i = 0; i < num_ops; i++) {
+        u64 x = v.w(5 * i), y = v.w(5 * i + 1), bin = v.w(5 * i + 2), res = v.w(5 * i + 3), bout = v.w(5 * i + 4);
+        u64 initial = gl_sub(gl_sub(x, y), bin);
+        out.emit(gl_sub(res, gl_add(initial, gl_mul(bout, 1ULL << 32))));
+        u64 comb = 0;
+        for (u32 j = 16; j-- > 0;) {
+            u64 l = v.w(5 * num_ops + 16 * i + j);
+            out.emit(p2_range_product(l, 4));
+            comb = gl_add(gl_mul(comb, 4), l);
+        }
+        out.emit(gl_sub(comb, res));
+        out.emit(gl_mul(bout, gl_sub(1, bout)));
+    }
+}
+
+// range_check_u32.rs: n input limbs, each with 16 two-bit aux limbs
+ZKLC_D void p2_eval_u32_range_check(const p2_vars &v, u32 n, p2_consumer &out) {
+    for (u32 i = 0; i < n; i++) {
+        u64 sum = 0;
+        for (u32 j = 16; j-- > 0;) sum = gl_add(gl_mul(sum, 4), v.w(n + 16 * i + j));
+        out.emit(gl_sub(sum, v.w(i)));
+        for (u32 j = 0; j < 16; j++) out.emit(p2_range_product(v.w(n + 16 * i + j), 4));
+    }
+}
+
+// comparison.rs:106-190
+ZKLC_D void p2_eval_comparison(const p2_vars &v, u32 num_bits, u32 num_chunks, p2_consumer &out) {
+    const u32 chunk_bits = (num_bits + num_chunks - 1) / num_chunks;
+    const u32 chunk_size = 1u << chunk_bits;
+    u64 c1 = 0, c2 = 0;
+    for (u32 i = num_chunks; i-- > 0;) {
+        c1 = gl_add(gl_mul(c1, chunk_size), v.w(4 + i));
+        c2 = gl_add(gl_mul(c2, chunk_size), v.w(4 + num_chunks + i));
+    }
+    out.emit(gl_sub(c1, v.w(0)));
+    out.emit(gl_sub(c2, v.w(1)));
+    u64 msd = 0;
+    for (u32 i = 0; i < num_chunks; i++) {
+        u64 a = v.w(4 + i), b = v.w(4 + num_chunks + i);
+        out.emit(p2_range_product(a, chunk_size));
+        out.emit(p2_range_product(b, chunk_size));
+        u64 diff = gl_sub(b, a);
+        u64 dummy = v.w(4 + 2 * num_chunks + i), eq = v.w(4 + 3 * num_chunks + i);
+        out.emit(gl_sub(gl_mul(diff, dummy), gl_sub(1, eq)));
+        out.emit(gl_mul(eq, diff));
+        u64 inter = v.w(4 + 4 * num_chunks + i);
+        out.emit(gl_sub(inter, gl_mul(eq, msd)));
+        msd = gl_add(inter, gl_mul(gl_sub(1, eq), diff));
+    }
+    u64 msd_w = v.w(3);
+    out.emit(gl_sub(msd_w, msd));
+    u64 comb = 0;
+    for (u32 i = 0; i <= chunk_bits; i++) {
+        u64 bit = v.w(4 + 5 * num_chunks + i);
+        out.emit(gl_mul(bit, gl_sub(1, bit)));
+    }
+    for (u32 i = chunk_bits + 1; i-- > 0;) comb = gl_add(gl_double(comb), v.w(4 + 5 * num_chunks + i));
+    out.emit(gl_sub(gl_add(chunk_size, msd_w), comb));
+    out.emit(gl_sub(v.w(2), v.w(4 + 5 * num_chunks + chunk_bits)));
+}
+
+ZKLC_D void p2_eval_gate(const p2_gate &g, const p2_vars &v, const u64 *extra, p2_consumer &out) {
+    switch (g.type) {
+        case P2_NOOP: break;
+        case P2_CONSTANT: p2_eval_constant(v, g.p[0], out); break;
+        case P2_PUBLIC_INPUT: p2_eval_public_input(v, out); break;
+        case P2_ARITHMETIC: p2_eval_arithmetic(v, g.p[0], out); break;
+        case P2_ARITHMETIC_EXT: p2_eval_arithmetic_ext(v, g.p[0], out); break;
+        case P2_MUL_EXT: p2_eval_mul_ext(v, g.p[0], out); break;
+        case P2_BASE_SUM: p2_eval_base_sum(v, g.p[0], g.p[1], out); break;
+        case P2_POSEIDON: p2_eval_poseidon(v, out); break;
+        case P2_POSEIDON_MDS: p2_eval_poseidon_mds(v, out); break;
+        case P2_RANDOM_ACCESS: p2_eval_random_access(v, g.p[0], g.p[1], g.p[2], out); break;
+        case P2_REDUCING: p2_eval_reducing(v, g.p[0], false, out); break;
+        case P2_REDUCING_EXT: p2_eval_reducing(v, g.p[0], true, out); break;
+        case P2_EXPONENTIATION: p2_eval_exponentiation(v, g.p[0], out); break;
+        case P2_COSET_INTERPOLATION: p2_eval_coset_interpolation(v, g.p[0], g.p[1], extra + g.extra_off, out); break;
+        case P2_U32_ARITHMETIC: p2_eval_u32_arithmetic(v, g.p[0], out); break;
+        case P2_U32_ADD_MANY: p2_eval_u32_add_many(v, g.p[0], g.p[1], out); break;
+        case P2_U32_SUBTRACTION: p2_eval_u32_subtraction(v, g.p[0], out); break;
+        case P2_U32_RANGE_CHECK: p2_eval_u32_range_check(v, g.p[0], out); break;
+        case P2_COMPARISON: p2_eval_comparison(v, g.p[0], g.p[1], out); break;
+        default: break;
+    }
+}
+
+// evaluate_gates.go:34-57: prod_{i in group, i != row} (i - s) [* (UNUSED - s) when there are several selectors]
+ZKLC_D u64 p2_filter(u32 row, u32 start, u32 end, u64 s, bool many) {
+    u64 prod = 1;
+    for (u32 i = start; i < end; i++)
+        if (i != row) prod = gl_mul(prod, gl_sub(i, s));
+    if (many) prod = gl_mul(prod, gl_sub(P2_UNUSED_SELECTOR, s));
+    return prod;
+}

@@ -1,0 +1,104 @@
+// Host-side transcript and PoseidonGate witness rows (see plonky2_host.h).  Plain C++: poseidon_gl.cuh is written
+// for both compilers (common.cuh), so the transcript and the Merkle kernels share one Poseidon source.
+#include "plonky2_host.h"
+#include <string.h>
+#include "poseidon_gl.cuh"
+
+void zklc_host_poseidon_permute(uint64_t *s) { poseidon_gl_permute(s); }
+
+void zklc_host_poseidon_hash_no_pad(const uint64_t *in, size_t n, uint64_t *out4) {
+    u64 s[12] = {};
+    for (size_t off = 0; off < n; off += 8) {
+        for (size_t j = 0; j < 8 && off + j < n; j++) s[j] = in[off + j];
+        poseidon_gl_permute(s);
+    }
+    for (int i = 0; i < 4; i++) out4[i] = s[i];
+}
+
+void zklc_challenger::duplex() {
+    for (int i = 0; i < n_in; i++) state[i] = in[i];
+    n_in = 0;
+    poseidon_gl_permute(state);
+    for (int i = 0; i < 8; i++) out[i] = state[i];
+    n_out = 8;
+}
+void zklc_challenger::observe(uint64_t e) {
+    n_out = 0;
+    in[n_in++] = e;
+    if (n_in == 8) duplex();
+}
+void zklc_challenger::observe_many(const uint64_t *e, size_t n) {
+    for (size_t i = 0; i < n; i++) observe(e[i]);
+}
+void zklc_challenger::observe_hash(const uint8_t *h, int hasher) {
+    if (hasher == 0) {
+        uint64_t v[4];
+        memcpy(v, h, 32);
+        observe_many(v, 4);
+    } else {
+        for (int off = 0; off < 32; off += 7) {
+            uint64_t v = 0;
+            int len = 32 - off < 7 ? 32 - off : 7;
+            memcpy(&v, h + off, len);
+            observe(v);
+        }
+    }
+}
+uint64_t zklc_challenger::challenge() {
+    if (n_in || !n_out) duplex();
+    return out[--n_out];
+}
+
+// One PoseidonGate row per input state: wires 0..12 inputs, 12..24 outputs, 24 swap, 25..29 deltas,
+// 29..65 / 65..87 / 87..135 the S-box inputs (gnark-plonky2-verifier/plonk/gates/poseidon_gate.go:27-82).
+extern "C" int32_t zklc_poseidon_gl_gate_rows(const uint64_t *inputs, const uint64_t *swap, uint32_t n, uint64_t *rows) {
+    if (!inputs || !rows) return -1;
+    for (uint32_t k = 0; k < n; k++) {
+        const u64 *in = inputs + (size_t)k * 12;
+        u64 *w = rows + (size_t)k * 135;
+        u64 sw = swap ? swap[k] : 0;
+        if (sw > 1) return -1;
+        for (int i = 0; i < 12; i++) w[i] = in[i];
+        w[24] = sw;
+        u64 s[12];
+        for (int i = 0; i < 4; i++) {
+            u64 delta = sw ? gl_sub(in[i + 4], in[i]) : 0;
+            w[25 + i] = delta;
+            s[i] = gl_add(in[i], delta);
+            s[i + 4] = gl_sub(in[i + 4], delta);
+        }
+        for (int i = 8; i < 12; i++) s[i] = in[i];
+        for (int r = 0; r < 4; r++) {
+            for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PGL_RC[12 * r + i]);
+            if (r)
+                for (int i = 0; i < 12; i++) w[29 + 12 * (r - 1) + i] = s[i];
+            for (int i = 0; i < 12; i++) s[i] = pgl_sbox(s[i]);
+            pgl_mds(s);
+        }
+        for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PGL_FP_FIRST[i]);
+        u64 t[12];
+        t[0] = s[0];
+        for (int d = 1; d < 12; d++) t[d] = 0;
+        for (int r = 1; r < 12; r++)
+            for (int d = 1; d < 12; d++) t[d] = gl_add(t[d], gl_mul(s[r], PGL_FP_INIT[(r - 1) * 11 + d - 1]));
+        for (int i = 0; i < 12; i++) s[i] = t[i];
+        for (int r = 0; r < 22; r++) {
+            w[65 + r] = s[0];
+            u64 s0 = gl_add(pgl_sbox(s[0]), PGL_FP_RC[r]);
+            u64 d = gl_mul(s0, 25);
+            for (int j = 1; j < 12; j++) d = gl_add(d, gl_mul(s[j], PGL_FP_WHATS[r * 11 + j - 1]));
+            for (int j = 1; j < 12; j++) s[j] = gl_add(s[j], gl_mul(s0, PGL_FP_VS[r * 11 + j - 1]));
+            s[0] = d;
+        }
+        for (int r = 0; r < 4; r++) {
+            for (int i = 0; i < 12; i++) {
+                s[i] = gl_add(s[i], PGL_RC[12 * (26 + r) + i]);
+                w[87 + 12 * r + i] = s[i];
+                s[i] = pgl_sbox(s[i]);
+            }
+            pgl_mds(s);
+        }
+        for (int i = 0; i < 12; i++) w[12 + i] = s[i];
+    }
+    return 0;
+}

@@ -1,0 +1,1065 @@
+// plonky2 prover on gfx950: Z / partial products, quotient (gate constraints), openings, FRI, proof-of-work,
+// query openings -- everything of `prove_with_partition_witness` after the witness is known.
+//
+// Replaces the un-vendored plonky2-near@2244a9d `plonk/prover.rs`, `plonk/vanishing_poly.rs`, `fri/oracle.rs`,
+// `fri/prover.rs` behind near_bft_finality/src/prove_crypto/ed25519.rs:60,100 and recursion.rs:95.  The verifier
+// side of every formula used here is restated in the reference tree: gnark-plonky2-verifier/plonk/plonk.go:60-250
+// (vanishing polynomial), fri/fri.go:187-497 (domain order, combine, fold, final polynomial),
+// challenger/challenger.go:42-166 (transcript).
+//
+// Layout in HBM: every polynomial batch is POLY-MAJOR; LDE matrices are in bit-reversed index order (position p holds
+// the evaluation at g * w_N^bitrev(p)), which is the order of the Merkle leaves, so the commit kernels read them
+// directly and a wave of 64 consecutive points reads 512 contiguous bytes of every column.  FRI oracles are arrays of
+// extension elements (2 x u64), i.e. row-major leaves of 2 * arity words.  The Fiat-Shamir transcript (a few hundred
+// Poseidon permutations) runs on the host between kernels (plonky2_host.cpp).
+#include <chrono>
+#include <new>
+#include <vector>
+#include <string.h>
+#include "plonky2_gates.cuh"
+#include "plonky2_host.h"
+#include "zklc_internal.h"
+
+#define P2_THREADS 256
+
+struct p2_challenges {
+    u64 beta[P2_MAX_CH], gamma[P2_MAX_CH], alpha[P2_MAX_CH];
+};
+
+// ------------------------------------------------------------------------------------------------ small kernels
+__global__ void p2_pow_table_kernel(u64 *out, u64 base, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gl_pow(base, i);
+}
+
+// data[b][j] *= base^j
+__global__ void p2_scale_by_powers_kernel(u64 *data, u64 base, u64 n) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    u64 *p = data + (size_t)blockIdx.y * n + j;
+    *p = gl_mul(*p, gl_pow(base, j));
+}
+
+// out[j] = z^j (extension)
+__global__ void p2_ext_powers_kernel(gl2 *out, gl2 z, u64 n) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) out[j] = gl2_pow(z, j);
+}
+
+// ---------------------------------------------------------------------------------------- Z and partial products
+// prover.rs `wires_permutation_partial_products_and_zs`: per row the running products of the chunk quotients
+//   rp[k][i] = prod_{k' <= k} prod_{j in chunk k'} (w_j + beta k_j x_i + gamma) / (w_j + beta sigma_j(x_i) + gamma)
+__global__ void __launch_bounds__(P2_THREADS)
+p2_chunk_products_kernel(const u64 *__restrict__ wires, const u64 *__restrict__ sigmas, const u64 *__restrict__ subgroup,
+                         const u64 *__restrict__ k_is, u32 n, u32 routed, u32 qdf, u32 nchunks, u64 beta, u64 gamma,
+                         u64 *__restrict__ rp) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 x = subgroup[i];
+    u64 nums[16], dens[16];
+    for (u32 k = 0; k < nchunks; k++) {
+        u64 np = 1, dp = 1;
+        u32 end = (k + 1) * qdf < routed ? (k + 1) * qdf : routed;
+        for (u32 j = k * qdf; j < end; j++) {
+            u64 w = gl_add(wires[(size_t)j * n + i], gamma);
+            np = gl_mul(np, gl_add(w, gl_mul(beta, gl_mul(k_is[j], x))));
+            dp = gl_mul(dp, gl_add(w, gl_mul(beta, sigmas[(size_t)j * n + i])));
+        }
+        nums[k] = np;
+        dens[k] = dp;
+    }
+    // one inversion for all chunk denominators of the row
+    u64 pref[16];
+    u64 acc = 1;
+    for (u32 k = 0; k < nchunks; k++) {
+        pref[k] = acc;
+        acc = gl_mul(acc, dens[k]);
+    }
+    u64 inv = gl_inv(acc);
+    for (u32 k = nchunks; k-- > 0;) {
+        u64 dinv = gl_mul(inv, pref[k]);
+        inv = gl_mul(inv, dens[k]);
+        nums[k] = gl_mul(nums[k], dinv);
+    }
+    acc = 1;
+    for (u32 k = 0; k < nchunks; k++) {
+        acc = gl_mul(acc, nums[k]);
+        rp[(size_t)k * n + i] = acc;
+    }
+}
+
+// exclusive prefix PRODUCT over r[0..n): phase 1 = per-block (1024 elements) local scan + block totals
+#define P2_SCAN_ITEMS 4
+#define P2_SCAN_BLOCK (P2_THREADS * P2_SCAN_ITEMS)
+__global__ void __launch_bounds__(P2_THREADS) p2_scan_local_kernel(const u64 *__restrict__ r, u64 *__restrict__ excl,
+                                                                     u64 *__restrict__ totals, u32 n) {
+    __shared__ u64 sh[P2_THREADS];
+    u32 base = blockIdx.x * P2_SCAN_BLOCK + threadIdx.x * P2_SCAN_ITEMS;
+    u64 v[P2_SCAN_ITEMS], acc = 1;
+#pragma unroll
+    for (int k = 0; k < P2_SCAN_ITEMS; k++) {
+        v[k] = base + k < n ? r[base + k] : 1;
+        acc = gl_mul(acc, v[k]);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (u32 off = 1; off < P2_THREADS; off <<= 1) {
+        u64 t = threadIdx.x >= off ? sh[threadIdx.x - off] : 1;
+        __syncthreads();
+        sh[threadIdx.x] = gl_mul(sh[threadIdx.x], t);
+        __syncthreads();
+    }
+    u64 pre = threadIdx.x ? sh[threadIdx.x - 1] : 1;
+#pragma unroll
+    for (int k = 0; k < P2_SCAN_ITEMS; k++) {
+        if (base + k < n) excl[base + k] = pre;
+        pre = gl_mul(pre, v[k]);
+    }
+    if (threadIdx.x == P2_THREADS - 1) totals[blockIdx.x] = sh[P2_THREADS - 1];
+}
+// phase 2: exclusive scan of the block totals (single block, serial per thread over a strip)
+__global__ void __launch_bounds__(P2_THREADS) p2_scan_totals_kernel(u64 *totals, u32 nblocks, u64 *grand_total) {
+    __shared__ u64 sh[P2_THREADS];
+    u32 per = (nblocks + P2_THREADS - 1) / P2_THREADS;
+    u32 s = threadIdx.x * per, e = s + per < nblocks ? s + per : nblocks;
+    u64 acc = 1;
+    for (u32 i = s; i < e; i++) acc = gl_mul(acc, totals[i]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (u32 off = 1; off < P2_THREADS; off <<= 1) {
+        u64 t = threadIdx.x >= off ? sh[threadIdx.x - off] : 1;
+        __syncthreads();
+        sh[threadIdx.x] = gl_mul(sh[threadIdx.x], t);
+        __syncthreads();
+    }
+    u64 pre = threadIdx.x ? sh[threadIdx.x - 1] : 1;
+    for (u32 i = s; i < e; i++) {
+        u64 t = totals[i];
+        totals[i] = pre;
+        pre = gl_mul(pre, t);
+    }
+    if (threadIdx.x == P2_THREADS - 1) *grand_total = sh[P2_THREADS - 1];
+}
+// phase 3: Z[i] = block prefix * local prefix; partial product k = Z[i] * rp[k][i]
+__global__ void __launch_bounds__(P2_THREADS)
+p2_z_apply_kernel(const u64 *__restrict__ excl, const u64 *__restrict__ totals, const u64 *__restrict__ rp, u32 n, u32 npp,
+                  u64 *__restrict__ z_out, u64 *__restrict__ pp_out) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 z = gl_mul(excl[i], totals[i / P2_SCAN_BLOCK]);
+    z_out[i] = z;
+    for (u32 k = 0; k < npp; k++) pp_out[(size_t)k * n + i] = gl_mul(z, rp[(size_t)k * n + i]);
+}
+
+// ---------------------------------------------------------------------------------------------------- quotient
+struct p2_quotient_args {
+    const u64 *cs, *wires, *zs;     // LDE matrices (bit-reversed), stride N
+    const p2_gate *gates;
+    const u64 *extra, *k_is;
+    u32 lde_bits, degree_bits, rate_bits, num_constants, nsel, routed, nch, npp, qdf, num_gates;
+    u64 w_lde;                      // primitive 2^lde_bits-th root of unity
+    u64 zh_inv[16];                 // 1 / (x^n - 1) for the 2^rate_bits cosets of <w_n> inside g<w_N>
+    u64 n_field;                    // n as a field element
+    u64 pih[4];
+    p2_challenges ch;
+    u64 *out;                       // [nch][N]
+};
+
+// vanishing_poly.rs `eval_vanishing_poly_base_batch` at the point stored at position p, divided by Z_H
+__global__ void __launch_bounds__(P2_THREADS) p2_quotient_kernel(p2_quotient_args a) {
+    const size_t N = (size_t)1 << a.lde_bits;
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    u64 i = __brevll((u64)p) >> (64 - a.lde_bits);  // natural index on the coset
+    u64 x = gl_mul(GL_GENERATOR, gl_pow(a.w_lde, i));
+    u64 zh_inv = a.zh_inv[i & ((1u << a.rate_bits) - 1)];
+    // L_0(x) = (x^n - 1) / (n (x - 1))
+    u64 l0 = gl_mul(gl_inv(zh_inv), gl_inv(gl_mul(a.n_field, gl_sub(x, 1))));
+    u64 i_next = (i + (1ULL << a.rate_bits)) & (N - 1);
+    size_t p_next = (size_t)(__brevll(i_next) >> (64 - a.lde_bits));
+
+    p2_consumer out;
+    out.nch = a.nch;
+    for (int c = 0; c < P2_MAX_CH; c++) {
+        out.alpha[c] = a.ch.alpha[c];
+        out.apow[c] = 1;
+        out.acc[c] = 0;
+    }
+    // L_0(x) (Z(x) - 1)
+    for (u32 c = 0; c < a.nch; c++) out.emit(gl_mul(l0, gl_sub(a.zs[(size_t)c * N + p], 1)));
+    // partial products (plonk.go:84-119)
+    const u32 nchunks = a.npp + 1;
+    for (u32 c = 0; c < a.nch; c++) {
+        u64 beta = a.ch.beta[c], gamma = a.ch.gamma[c];
+        u64 prev = a.zs[(size_t)c * N + p];
+        for (u32 k = 0; k < nchunks; k++) {
+            u64 np = 1, dp = 1;
+            u32 end = (k + 1) * a.qdf < a.routed ? (k + 1) * a.qdf : a.routed;
+            for (u32 j = k * a.qdf; j < end; j++) {
+                u64 w = gl_add(a.wires[(size_t)j * N + p], gamma);
+                np = gl_mul(np, gl_add(w, gl_mul(beta, gl_mul(a.k_is[j], x))));
+                dp = gl_mul(dp, gl_add(w, gl_mul(beta, a.cs[(size_t)(a.num_constants + j) * N + p])));
+            }
+            u64 next = k + 1 < nchunks ? a.zs[(size_t)(a.nch + c * a.npp + k) * N + p] : a.zs[(size_t)c * N + p_next];
+            out.emit(gl_sub(gl_mul(prev, np), gl_mul(next, dp)));
+            prev = next;
+        }
+    }
+    // gate constraints, filtered (evaluate_gates.go:59-105)
+    p2_vars v;
+    v.wires = a.wires;
+    v.consts = a.cs;
+    v.stride = N;
+    v.p = p;
+    v.nsel = a.nsel;
+    for (int k = 0; k < 4; k++) v.pih[k] = a.pih[k];
+    u64 base_pow[P2_MAX_CH], total[P2_MAX_CH];
+    for (int c = 0; c < P2_MAX_CH; c++) {
+        base_pow[c] = out.apow[c];
+        total[c] = out.acc[c];
+    }
+    for (u32 g = 0; g < a.num_gates; g++) {
+        p2_gate gate = a.gates[g];
+        for (int c = 0; c < P2_MAX_CH; c++) {
+            out.apow[c] = base_pow[c];
+            out.acc[c] = 0;
+        }
+        p2_eval_gate(gate, v, a.extra, out);
+        u64 f = p2_filter(g, gate.group_start, gate.group_end, v.sel(gate.selector_index), a.nsel > 1);
+        for (int c = 0; c < P2_MAX_CH; c++) total[c] = gl_add(total[c], gl_mul(f, out.acc[c]));
+    }
+    for (u32 c = 0; c < a.nch; c++) a.out[(size_t)c * N + p] = gl_mul(total[c], zh_inv);
+}
+
+// ---------------------------------------------------------------------------------------------------- openings
+// out[b] = sum_j coeffs[b][j] * zpow[j] (* scale[j]);  one workgroup per polynomial
+__global__ void __launch_bounds__(P2_THREADS)
+p2_eval_at_ext_kernel(const u64 *__restrict__ coeffs, u32 n, const gl2 *__restrict__ zpow, const u64 *__restrict__ scale,
+                      gl2 *__restrict__ out) {
+    __shared__ gl2 sh[P2_THREADS];
+    const u64 *c = coeffs + (size_t)blockIdx.x * n;
+    gl2 acc = gl2_make(0, 0);
+    for (u32 j = threadIdx.x; j < n; j += P2_THREADS) {
+        u64 cj = c[j];
+        if (scale) cj = gl_mul(cj, scale[j]);
+        acc = gl2_add(acc, gl2_scale(zpow[j], cj));
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (u32 off = P2_THREADS / 2; off; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] = gl2_add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
+// -------------------------------------------------------------------------------------------------------- FRI
+struct p2_fri_combine_args {
+    const u64 *mats[4];   // the four committed LDE matrices (bit-reversed), stride N
+    u32 widths[4];
+    u32 lde_bits, nch;
+    u64 w_lde;
+    gl2 alpha, zeta, g_zeta, y0, y1, alpha_pow_nch;
+    gl2 *out;             // [N] extension elements
+};
+// fri/oracle.rs `prove_openings` in evaluation form (= fri.go:208-251 on the verifier side):
+//   out(x) = alpha^nch * (sum_i alpha^i p_i(x) - y0) / (x - zeta) + (sum_{i<nch} alpha^i z_i(x) - y1) / (x - g zeta)
+__global__ void __launch_bounds__(P2_THREADS) p2_fri_combine_kernel(p2_fri_combine_args a) {
+    const size_t N = (size_t)1 << a.lde_bits;
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    u64 i = __brevll((u64)p) >> (64 - a.lde_bits);
+    u64 x = gl_mul(GL_GENERATOR, gl_pow(a.w_lde, i));
+    gl2 acc = gl2_make(0, 0);
+    for (int m = 3; m >= 0; m--) {
+        const u64 *mat = a.mats[m];
+        for (u32 j = a.widths[m]; j-- > 0;) acc = gl2_add_base(gl2_mul(acc, a.alpha), mat[(size_t)j * N + p]);
+    }
+    gl2 acc1 = gl2_make(0, 0);
+    for (u32 j = a.nch; j-- > 0;) acc1 = gl2_add_base(gl2_mul(acc1, a.alpha), a.mats[2][(size_t)j * N + p]);
+    gl2 q0 = gl2_mul(gl2_sub(acc, a.y0), gl2_inv(gl2_sub(gl2_make(x, 0), a.zeta)));
+    gl2 q1 = gl2_mul(gl2_sub(acc1, a.y1), gl2_inv(gl2_sub(gl2_make(x, 0), a.g_zeta)));
+    a.out[p] = gl2_add(gl2_mul(q0, a.alpha_pow_nch), q1);
+}
+
+// One FRI reduction in evaluation form.  in: 2^log_m values on shift*<w_M>, bit-reversed; chunk l (2^a consecutive
+// values) holds P on the coset x*<w_A>, x = shift * w_M^bitrev(l) (value e at x * w_A^bitrev_a(e)).  With
+// P(X) = sum_i X^i P_i(X^A):  c_i = (1/A) sum_j P(x w_A^j) w_A^(-ij) = x^i P_i(x^A)  and the folded value is
+// sum_i beta^i P_i(x^A) = sum_i (beta / x)^i c_i   (fri/prover.rs folds the coefficients; fri.go:314-384 interpolates).
+__global__ void __launch_bounds__(P2_THREADS)
+p2_fri_fold_kernel(const gl2 *__restrict__ in, gl2 *__restrict__ out, u32 log_m, u32 a_bits, u64 shift, u64 w_m, u64 w_a_inv,
+                   u64 a_inv, gl2 beta) {
+    __shared__ u64 tw[64];
+    const u32 A = 1u << a_bits;
+    if (threadIdx.x < A) tw[threadIdx.x] = gl_pow(w_a_inv, threadIdx.x);
+    __syncthreads();
+    u32 chunks = 1u << (log_m - a_bits);
+    u32 l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= chunks) return;
+    u32 m = log_m == a_bits ? 0 : (u32)(__brevll((u64)l) >> (64 - (log_m - a_bits)));
+    u64 x = gl_mul(shift, gl_pow(w_m, m));
+    gl2 r = gl2_scale(beta, gl_inv(x));
+    const gl2 *v = in + (size_t)l * A;
+    gl2 acc = gl2_make(0, 0);
+    for (u32 i = A; i-- > 0;) {
+        gl2 c = gl2_make(0, 0);
+        for (u32 e = 0; e < A; e++) {
+            u32 j = __brev(e) >> (32 - a_bits);
+            c = gl2_add(c, gl2_scale(v[e], tw[(i * j) & (A - 1)]));
+        }
+        acc = gl2_add(gl2_mul(acc, r), c);
+    }
+    out[l] = gl2_scale(acc, a_inv);
+}
+
+// final polynomial: coefficients of the last oracle (2^log_m values on shift*<w_M>, bit-reversed), naive O(M^2)
+__global__ void __launch_bounds__(P2_THREADS)
+p2_fri_final_poly_kernel(const gl2 *__restrict__ in, gl2 *__restrict__ out, u32 log_m, u64 shift_inv, u64 w_m_inv, u64 m_inv) {
+    u32 M = 1u << log_m;
+    u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= M) return;
+    u64 wk = gl_pow(w_m_inv, k);
+    gl2 acc = gl2_make(0, 0);
+    u64 t = 1;
+    for (u32 i = 0; i < M; i++) {
+        u32 pos = log_m ? (u32)(__brevll((u64)i) >> (64 - log_m)) : 0;
+        acc = gl2_add(acc, gl2_scale(in[pos], t));
+        t = gl_mul(t, wk);
+    }
+    out[k] = gl2_scale(acc, gl_mul(m_inv, gl_pow(shift_inv, k)));
+}
+
+// proof of work (fri/prover.rs `fri_proof_of_work`; verifier check fri.go:75-80): lowest witness w such that the
+// challenger, after observing w, answers with a challenge < 2^(64 - pow_bits)
+struct p2_pow_args {
+    u64 state[12];
+    u64 in[8];
+    u32 n_in, pow_bits;
+    u64 base;
+    unsigned long long *found;
+};
+__global__ void __launch_bounds__(P2_THREADS) p2_pow_kernel(p2_pow_args a) {
+    u64 w = a.base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = a.state[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if ((u32)i < a.n_in) s[i] = a.in[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if ((u32)i == a.n_in) s[i] = w;
+    poseidon_gl_permute(s);
+    if ((s[7] >> (64 - a.pow_bits)) == 0) atomicMin(a.found, (unsigned long long)w);
+}
+
+// query openings: strided gathers described by the host
+struct p2_gather {
+    const u64 *src;
+    u64 stride;
+    u32 count, dst;
+};
+__global__ void p2_gather_kernel(const p2_gather *__restrict__ d, u32 nd, u64 *__restrict__ out) {
+    u32 g = blockIdx.x;
+    if (g >= nd) return;
+    p2_gather e = d[g];
+    for (u32 i = threadIdx.x; i < e.count; i += blockDim.x) out[e.dst + i] = e.src[(size_t)i * e.stride];
+}
+
+// ----------------------------------------------------------------------------------------------------- host side
+static u64 h_mul(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % GL_P); }
+static u64 h_add(u64 a, u64 b) { return (u64)(((unsigned __int128)a + b) % GL_P); }
+static u64 h_sub(u64 a, u64 b) { return a >= b ? a - b : a + GL_P - b; }
+static u64 h_pow(u64 a, u64 e) {
+    u64 r = 1;
+    while (e) {
+        if (e & 1) r = h_mul(r, a);
+        a = h_mul(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+static u64 h_inv(u64 a) { return h_pow(a, GL_P - 2); }
+static u64 h_root(u32 log_n) { return h_pow(GL_POWER_OF_TWO_GENERATOR, 1ULL << (32 - log_n)); }
+static gl2 h2_mul(gl2 x, gl2 y) {
+    return gl2_make(h_add(h_mul(x.a, y.a), h_mul(7, h_mul(x.b, y.b))), h_add(h_mul(x.a, y.b), h_mul(x.b, y.a)));
+}
+static gl2 h2_add(gl2 x, gl2 y) { return gl2_make(h_add(x.a, y.a), h_add(x.b, y.b)); }
+static gl2 h2_pow(gl2 x, u64 e) {
+    gl2 r = gl2_make(1, 0);
+    while (e) {
+        if (e & 1) r = h2_mul(r, x);
+        x = h2_mul(x, x);
+        e >>= 1;
+    }
+    return r;
+}
+
+struct p2_batch {
+    u32 width = 0;
+    u64 *coeffs = nullptr, *lde = nullptr, *tree = nullptr;
+};
+
+struct zklc_plonky2_circuit {
+    zklc_ctx *ctx = nullptr;
+    zklc_plonky2_params P;
+    u32 n = 0, N = 0, lde_bits = 0, nchunks = 0;
+    std::vector<p2_gate> gates;
+    p2_gate *d_gates = nullptr;
+    u64 *d_extra = nullptr, *d_kis = nullptr, *d_subgroup = nullptr, *d_sigma_vals = nullptr;
+    p2_batch cs, wires, zs, quot;
+    u64 *d_wire_vals = nullptr;       // witness values (routed columns are needed after the iNTT)
+    u64 *d_rp = nullptr, *d_excl = nullptr, *d_totals = nullptr, *d_grand = nullptr;
+    u64 *d_qv = nullptr;              // quotient values [nch][N]
+    gl2 *d_zpow = nullptr, *d_open = nullptr;
+    gl2 *d_fri[9] = {};               // FRI oracles (extension values), [0] has N elements
+    u64 *d_fri_tree[8] = {};
+    gl2 *d_final = nullptr;
+    unsigned long long *d_found = nullptr;
+    p2_gather *d_gather = nullptr;
+    u64 *d_gather_out = nullptr;
+    size_t gather_cap = 0, gather_out_words = 0;
+    std::vector<uint8_t> cap_bytes;
+    uint8_t digest[32];
+    std::vector<u64> last_challenges;
+    double timings[8] = {};
+    u64 tree_words = 0;
+    std::vector<void *> allocs;
+};
+
+static int32_t p2_alloc(zklc_plonky2_circuit *c, void **p, size_t bytes) {
+    zklc_ctx *ctx = c->ctx;
+    ZKLC_HIP(ctx, hipMalloc(p, bytes ? bytes : 8));
+    c->allocs.push_back(*p);
+    return ZKLC_OK;
+}
+#define P2_ALLOC(c, ptr, bytes)                                      \
+    do {                                                             \
+        int32_t rc__ = p2_alloc((c), (void **)&(ptr), (bytes));      \
+        if (rc__) return rc__;                                       \
+    } while (0)
+#define P2_RC(call)               \
+    do {                          \
+        int32_t rc__ = (call);    \
+        if (rc__) return rc__;    \
+    } while (0)
+
+static inline u64 *p2_tree_level(u64 *tree, u32 log_leaves, u32 level) {
+    u64 off = 0;
+    for (u32 j = 0; j < level; j++) off += 4ULL << (log_leaves - j);
+    return tree + off;
+}
+
+static int32_t p2_merkle(zklc_plonky2_circuit *c, hipStream_t st, const u64 *mat, u64 stride, u64 leaf_stride, u32 log_leaves,
+                         u32 width, u64 *tree) {
+    u32 cap_h = c->P.cap_height < log_leaves ? c->P.cap_height : log_leaves;
+    if (c->P.hasher == ZKLC_HASHER_POSEIDON_GL)
+        return zklc_gl_merkle_commit_strided(c->ctx, st, mat, stride, leaf_stride, log_leaves, width, cap_h, tree);
+    return zklc_bn254_merkle_commit_strided(c->ctx, st, mat, stride, leaf_stride, log_leaves, width, cap_h, tree);
+}
+
+// coefficients (natural order, [width][n]) -> LDE (bit-reversed) -> Merkle tree; cap copied to the host
+static int32_t p2_commit_coeffs(zklc_plonky2_circuit *c, hipStream_t st, p2_batch &b, std::vector<uint8_t> &cap) {
+    zklc_ctx *ctx = c->ctx;
+    P2_RC(zklc_gl_lde_dev(ctx, st, b.coeffs, c->P.degree_bits, c->P.rate_bits, b.width, GL_GENERATOR, b.lde, ZKLC_NTT_OUT_BITREV));
+    P2_RC(p2_merkle(c, st, b.lde, c->N, 1, c->lde_bits, b.width, b.tree));
+    u32 cap_h = c->P.cap_height < c->lde_bits ? c->P.cap_height : c->lde_bits;
+    cap.resize((size_t)32 << cap_h);
+    ZKLC_HIP(ctx, hipMemcpyAsync(cap.data(), p2_tree_level(b.tree, c->lde_bits, c->lde_bits - cap_h), cap.size(),
+                                 hipMemcpyDeviceToHost, st));
+    ZKLC_HIP(ctx, hipStreamSynchronize(st));
+    return ZKLC_OK;
+}
+// values on the subgroup (natural order, in b.coeffs) -> coefficients in place, then commit
+static int32_t p2_commit_values(zklc_plonky2_circuit *c, hipStream_t st, p2_batch &b, std::vector<uint8_t> &cap) {
+    P2_RC(zklc_gl_ntt_dev(c->ctx, st, b.coeffs, c->P.degree_bits, b.width, ZKLC_NTT_INVERSE, 0));
+    return p2_commit_coeffs(c, st, b, cap);
+}
+
+// C::Hasher::hash_no_pad of a short Goldilocks vector -> 32 bytes
+static int32_t p2_hash_no_pad(zklc_plonky2_circuit *c, hipStream_t st, const std::vector<u64> &v, uint8_t *out32) {
+    zklc_ctx *ctx = c->ctx;
+    if (c->P.hasher == ZKLC_HASHER_POSEIDON_GL) {
+        u64 h[4];
+        zklc_host_poseidon_hash_no_pad(v.data(), v.size(), h);
+        memcpy(out32, h, 32);
+        return ZKLC_OK;
+    }
+    // Poseidon-BN128: one leaf of width len > 3 through the leaf kernel (hash_or_noop == hash_no_pad for len > 3)
+    if (v.size() <= 3) return ZKLC_ERR_INVALID_ARG;
+    void *d;
+    P2_RC(zklc_stage(ctx, 6, v.size() * 8 + 64, &d));
+    u64 *dv = (u64 *)d;
+    ZKLC_HIP(ctx, hipMemcpyAsync(dv + 8, v.data(), v.size() * 8, hipMemcpyHostToDevice, st));
+    P2_RC(zklc_bn254_merkle_commit_strided(ctx, st, dv + 8, 1, 0, 0, (u32)v.size(), 0, dv));
+    ZKLC_HIP(ctx, hipMemcpyAsync(out32, dv, 32, hipMemcpyDeviceToHost, st));
+    ZKLC_HIP(ctx, hipStreamSynchronize(st));
+    return ZKLC_OK;
+}
+
+extern "C" void zklc_plonky2_circuit_destroy(zklc_plonky2_circuit *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    for (void *p : c->allocs) (void)hipFree(p);
+    delete c;
+}
+
+static int32_t p2_create(zklc_ctx *ctx, const zklc_plonky2_params *params, const zklc_plonky2_gate *gates, const uint64_t *gate_extra,
+                         uint32_t gate_extra_words, const uint64_t *k_is, const uint64_t *constants, const uint64_t *sigmas,
+                         zklc_plonky2_circuit *c) {
+    const zklc_plonky2_params &P = *params;
+    c->ctx = ctx;
+    c->P = P;
+    c->n = 1u << P.degree_bits;
+    c->lde_bits = P.degree_bits + P.rate_bits;
+    c->N = 1u << c->lde_bits;
+    c->nchunks = P.num_partial_products + 1;
+    const u32 n = c->n, N = c->N;
+    hipStream_t st = ctx->stream;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    c->gates.resize(P.num_gates);
+    for (u32 i = 0; i < P.num_gates; i++) {
+        p2_gate g;
+        g.type = gates[i].type;
+        for (int k = 0; k < 4; k++) g.p[k] = gates[i].p[k];
+        g.selector_index = gates[i].selector_index;
+        g.group_start = gates[i].group_start;
+        g.group_end = gates[i].group_end;
+        g.extra_off = gates[i].extra_off;
+        if (g.type >= P2_NUM_GATE_TYPES || g.selector_index >= P.num_selectors) return ZKLC_ERR_INVALID_ARG;
+        if (g.type == P2_RANDOM_ACCESS && g.p[0] > 6) return ZKLC_ERR_INVALID_ARG;
+        if (g.type == P2_COSET_INTERPOLATION && (g.p[0] > 5 || g.p[1] < 2 || g.extra_off + (2u << g.p[0]) > gate_extra_words))
+            return ZKLC_ERR_INVALID_ARG;
+        c->gates[i] = g;
+    }
+    P2_ALLOC(c, c->d_gates, sizeof(p2_gate) * P.num_gates);
+    ZKLC_HIP(ctx, hipMemcpyAsync(c->d_gates, c->gates.data(), sizeof(p2_gate) * P.num_gates, hipMemcpyHostToDevice, st));
+    P2_ALLOC(c, c->d_extra, (size_t)gate_extra_words * 8);
+    if (gate_extra_words) ZKLC_HIP(ctx, hipMemcpyAsync(c->d_extra, gate_extra, (size_t)gate_extra_words * 8, hipMemcpyHostToDevice, st));
+    P2_ALLOC(c, c->d_kis, (size_t)P.num_routed_wires * 8);
+    ZKLC_HIP(ctx, hipMemcpyAsync(c->d_kis, k_is, (size_t)P.num_routed_wires * 8, hipMemcpyHostToDevice, st));
+    P2_ALLOC(c, c->d_subgroup, (size_t)n * 8);
+    hipLaunchKernelGGL(p2_pow_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->d_subgroup, h_root(P.degree_bits), (u64)n);
+    ZKLC_HIP(ctx, hipGetLastError());
+
+    c->tree_words = zklc_gl_merkle_tree_words(c->lde_bits, P.cap_height < c->lde_bits ? P.cap_height : c->lde_bits);
+    auto alloc_batch = [&](p2_batch &b, u32 width) -> int32_t {
+        b.width = width;
+        P2_ALLOC(c, b.coeffs, (size_t)width * n * 8);
+        P2_ALLOC(c, b.lde, (size_t)width * N * 8);
+        P2_ALLOC(c, b.tree, c->tree_words * 8);
+        return ZKLC_OK;
+    };
+    const u32 nch = P.num_challenges;
+    P2_RC(alloc_batch(c->cs, P.num_constants + P.num_routed_wires));
+    P2_RC(alloc_batch(c->wires, P.num_wires));
+    P2_RC(alloc_batch(c->zs, nch * (1 + P.num_partial_products)));
+    // quotient coefficients are produced in place in d_qv ([nch][N] == [nch * qdf][n])
+    c->quot.width = nch * P.quotient_degree_factor;
+    P2_ALLOC(c, c->d_qv, (size_t)nch * N * 8);
+    c->quot.coeffs = c->d_qv;
+    P2_ALLOC(c, c->quot.lde, (size_t)c->quot.width * N * 8);
+    P2_ALLOC(c, c->quot.tree, c->tree_words * 8);
+    P2_ALLOC(c, c->d_wire_vals, (size_t)P.num_wires * n * 8);
+    P2_ALLOC(c, c->d_sigma_vals, (size_t)P.num_routed_wires * n * 8);
+    P2_ALLOC(c, c->d_rp, (size_t)c->nchunks * n * 8);
+    P2_ALLOC(c, c->d_excl, (size_t)n * 8);
+    P2_ALLOC(c, c->d_totals, (size_t)((n + P2_SCAN_BLOCK - 1) / P2_SCAN_BLOCK) * 8);
+    P2_ALLOC(c, c->d_grand, 8);
+    P2_ALLOC(c, c->d_zpow, (size_t)n * sizeof(gl2));
+    u32 total_polys = c->cs.width + c->wires.width + c->zs.width + c->quot.width + nch;
+    P2_ALLOC(c, c->d_open, (size_t)total_polys * sizeof(gl2));
+    // FRI oracles
+    u32 bits = c->lde_bits;
+    P2_ALLOC(c, c->d_fri[0], (size_t)N * sizeof(gl2));
+    for (u32 r = 0; r < P.num_arities; r++) {
+        u32 leaves_bits = bits - P.arity_bits[r];
+        u32 cap_h = P.cap_height < leaves_bits ? P.cap_height : leaves_bits;
+        P2_ALLOC(c, c->d_fri_tree[r], zklc_gl_merkle_tree_words(leaves_bits, cap_h) * 8);
+        bits = leaves_bits;
+        P2_ALLOC(c, c->d_fri[r + 1], ((size_t)1 << bits) * sizeof(gl2));
+    }
+    P2_ALLOC(c, c->d_final, ((size_t)1 << bits) * sizeof(gl2));
+    P2_ALLOC(c, c->d_found, 8);
+
+    // preprocessed polynomials: constants then sigmas (values) -> coefficients -> LDE -> Merkle
+    size_t cbytes = (size_t)P.num_constants * n * 8, sbytes = (size_t)P.num_routed_wires * n * 8;
+    ZKLC_HIP(ctx, hipMemcpyAsync(c->cs.coeffs, constants, cbytes, hipMemcpyHostToDevice, st));
+    ZKLC_HIP(ctx, hipMemcpyAsync(c->cs.coeffs + (size_t)P.num_constants * n, sigmas, sbytes, hipMemcpyHostToDevice, st));
+    ZKLC_HIP(ctx, hipMemcpyAsync(c->d_sigma_vals, sigmas, sbytes, hipMemcpyHostToDevice, st));
+    P2_RC(p2_commit_values(c, st, c->cs, c->cap_bytes));
+
+    // circuit digest = hash_no_pad(cap as field elements || hash_pad([]) || degree_bits)  (plonky2 circuit_builder.rs `build`)
+    auto hash_to_vec = [&](const uint8_t *h, std::vector<u64> &out) {
+        if (P.hasher == ZKLC_HASHER_POSEIDON_GL) {
+            u64 v[4];
+            memcpy(v, h, 32);
+            out.insert(out.end(), v, v + 4);
+        } else {
+            for (int off = 0; off < 32; off += 7) {
+                u64 v = 0;
+                memcpy(&v, h + off, 32 - off < 7 ? 32 - off : 7);
+                out.push_back(v);
+            }
+        }
+    };
+    std::vector<u64> parts;
+    for (size_t i = 0; i < c->cap_bytes.size(); i += 32) hash_to_vec(c->cap_bytes.data() + i, parts);
+    std::vector<u64> pad;
+    pad.push_back(1);
+    u32 pad_to = P.hasher == ZKLC_HASHER_POSEIDON_GL ? 8 : 9;
+    while ((pad.size() + 1) % pad_to) pad.push_back(0);
+    pad.push_back(1);
+    uint8_t dsep[32];
+    P2_RC(p2_hash_no_pad(c, st, pad, dsep));
+    hash_to_vec(dsep, parts);
+    parts.push_back(P.degree_bits);
+    P2_RC(p2_hash_no_pad(c, st, parts, c->digest));
+    return ZKLC_OK;
+}
+
+extern "C" int32_t zklc_plonky2_circuit_create(zklc_ctx *ctx, const zklc_plonky2_params *params, const zklc_plonky2_gate *gates,
+                                               const uint64_t *gate_extra, uint32_t gate_extra_words, const uint64_t *k_is,
+                                               const uint64_t *constants, const uint64_t *sigmas, zklc_plonky2_circuit **out) {
+    if (!ctx || !params || !gates || !k_is || !constants || !sigmas || !out) return ZKLC_ERR_INVALID_ARG;
+    const zklc_plonky2_params &P = *params;
+    if (P.num_challenges == 0 || P.num_challenges > P2_MAX_CH || P.degree_bits == 0 || P.degree_bits + P.rate_bits > ZKLC_GL_MAX_LOG ||
+        P.rate_bits > 4 || P.quotient_degree_factor != (1u << P.rate_bits) || P.num_arities > 8 || P.hasher > 1 ||
+        P.num_routed_wires > P.num_wires || P.num_selectors == 0 || P.num_selectors > P.num_constants || P.num_gates == 0 ||
+        P.num_partial_products + 1 > 16 || (P.num_partial_products + 1) * P.quotient_degree_factor < P.num_routed_wires ||
+        P.proof_of_work_bits == 0 || P.proof_of_work_bits > 40)
+        return ZKLC_ERR_INVALID_ARG;
+    u32 bits = P.degree_bits + P.rate_bits;
+    for (u32 r = 0; r < P.num_arities; r++) {
+        if (P.arity_bits[r] == 0 || P.arity_bits[r] > 5 || P.arity_bits[r] > bits) return ZKLC_ERR_INVALID_ARG;
+        bits -= P.arity_bits[r];
+    }
+    if (bits < P.rate_bits) return ZKLC_ERR_INVALID_ARG;
+    zklc_plonky2_circuit *c = new (std::nothrow) zklc_plonky2_circuit();
+    if (!c) return ZKLC_ERR_OOM;
+    int32_t rc = p2_create(ctx, params, gates, gate_extra, gate_extra_words, k_is, constants, sigmas, c);
+    if (rc) {
+        zklc_plonky2_circuit_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return ZKLC_OK;
+}
+
+extern "C" int32_t zklc_plonky2_verifier_data(zklc_plonky2_circuit *c, uint8_t *cap_out, uint8_t *digest_out) {
+    if (!c || !cap_out || !digest_out) return ZKLC_ERR_INVALID_ARG;
+    memcpy(cap_out, c->cap_bytes.data(), c->cap_bytes.size());
+    memcpy(digest_out, c->digest, 32);
+    return ZKLC_OK;
+}
+
+// ---- proof layout (plonky2 util/serialization.rs `write_proof_with_public_inputs`)
+struct p2_layout {
+    u32 cap_n, depth0;
+    size_t per_round_words;    // u64 words gathered per query round (leaves, siblings, step evals, step siblings)
+    size_t bytes;
+};
+static p2_layout p2_proof_layout(const zklc_plonky2_circuit *c) {
+    const zklc_plonky2_params &P = c->P;
+    p2_layout L;
+    u32 cap_h = P.cap_height < c->lde_bits ? P.cap_height : c->lde_bits;
+    L.cap_n = 1u << cap_h;
+    L.depth0 = c->lde_bits - cap_h;
+    u32 widths[4] = {c->cs.width, c->wires.width, c->zs.width, c->quot.width};
+    size_t openings = c->cs.width + c->wires.width + c->zs.width + c->quot.width + P.num_challenges;
+    size_t bytes = 3 * (size_t)L.cap_n * 32 + openings * 16;
+    size_t per_bytes = 0, per_words = 0;
+    for (int k = 0; k < 4; k++) {
+        per_bytes += 8 * (size_t)widths[k] + 1 + 32 * (size_t)L.depth0;
+        per_words += widths[k] + 4 * (size_t)L.depth0;
+    }
+    u32 bits = c->lde_bits;
+    for (u32 r = 0; r < P.num_arities; r++) {
+        bits -= P.arity_bits[r];
+        u32 ch = P.cap_height < bits ? P.cap_height : bits;
+        bytes += (size_t)32 << ch;
+        per_bytes += 16 * ((size_t)1 << P.arity_bits[r]) + 1 + 32 * (size_t)(bits - ch);
+        per_words += 2 * ((size_t)1 << P.arity_bits[r]) + 4 * (size_t)(bits - ch);
+    }
+    bytes += per_bytes * P.num_query_rounds;
+    bytes += 16 * ((size_t)1 << (bits - P.rate_bits)) + 8 + 8 + 8 * (size_t)P.num_public_inputs;
+    L.per_round_words = per_words;
+    L.bytes = bytes;
+    return L;
+}
+
+extern "C" uint64_t zklc_plonky2_proof_bytes(zklc_plonky2_circuit *c) { return c ? p2_proof_layout(c).bytes : 0; }
+
+extern "C" uint32_t zklc_plonky2_last_challenges(zklc_plonky2_circuit *c, uint64_t *out, uint32_t cap) {
+    if (!c || !out) return 0;
+    u32 k = (u32)c->last_challenges.size() < cap ? (u32)c->last_challenges.size() : cap;
+    memcpy(out, c->last_challenges.data(), (size_t)k * 8);
+    return k;
+}
+extern "C" uint32_t zklc_plonky2_last_timings(zklc_plonky2_circuit *c, double *out_ms, uint32_t cap) {
+    if (!c || !out_ms) return 0;
+    u32 k = cap < 8 ? cap : 8;
+    memcpy(out_ms, c->timings, (size_t)k * sizeof(double));
+    return k;
+}
+
+static double p2_now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static void p2_observe_cap(zklc_challenger &ch, const std::vector<uint8_t> &cap, int hasher) {
+    for (size_t i = 0; i < cap.size(); i += 32) ch.observe_hash(cap.data() + i, hasher);
+}
+
+extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plonky2_circuit *c, const uint64_t *d_wires,
+                                          const uint64_t *public_inputs, uint8_t *proof_out, uint64_t proof_cap, uint64_t *proof_len) {
+    if (!ctx || !c || c->ctx != ctx || !d_wires || !proof_out || !proof_len) return ZKLC_ERR_INVALID_ARG;
+    const zklc_plonky2_params &P = c->P;
+    if (P.num_public_inputs && !public_inputs) return ZKLC_ERR_INVALID_ARG;
+    const p2_layout L = p2_proof_layout(c);
+    if (proof_cap < L.bytes) return ZKLC_ERR_INVALID_ARG;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = zklc_pick_stream(ctx, stream);
+    const u32 n = c->n, N = c->N, nch = P.num_challenges, npp = P.num_partial_products;
+    const int hasher = (int)P.hasher;
+    double t0 = p2_now_ms(), t_prev = t0;
+    auto lap = [&](int slot) {
+        double t = p2_now_ms();
+        c->timings[slot] = t - t_prev;
+        t_prev = t;
+    };
+    c->last_challenges.clear();
+
+    // ---- transcript start
+    u64 pih[4];
+    zklc_host_poseidon_hash_no_pad(public_inputs, P.num_public_inputs, pih);
+    zklc_challenger ch;
+    ch.observe_hash(c->digest, hasher);
+    ch.observe_many(pih, 4);
+
+    // ---- wires commitment
+    std::vector<uint8_t> wires_cap, zs_cap, quot_cap;
+    ZKLC_HIP(ctx, hipMemcpyAsync(c->wires.coeffs, d_wires, (size_t)P.num_wires * n * 8, hipMemcpyDeviceToDevice, st));
+    P2_RC(p2_commit_values(c, st, c->wires, wires_cap));
+    p2_observe_cap(ch, wires_cap, hasher);
+    p2_challenges chal = {};
+    for (u32 k = 0; k < nch; k++) chal.beta[k] = ch.challenge();
+    for (u32 k = 0; k < nch; k++) chal.gamma[k] = ch.challenge();
+    lap(0);
+
+    // ---- Z and partial products (values written into zs.coeffs, then interpolated in place)
+    u32 nblocks = (n + P2_SCAN_BLOCK - 1) / P2_SCAN_BLOCK;
+    u64 grand[P2_MAX_CH] = {1, 1};
+    for (u32 k = 0; k < nch; k++) {
+        hipLaunchKernelGGL(p2_chunk_products_kernel, dim3((n + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, d_wires,
+                           (const u64 *)c->d_sigma_vals, (const u64 *)c->d_subgroup, (const u64 *)c->d_kis, n, P.num_routed_wires,
+                           P.quotient_degree_factor, c->nchunks, chal.beta[k], chal.gamma[k], c->d_rp);
+        hipLaunchKernelGGL(p2_scan_local_kernel, dim3(nblocks), dim3(P2_THREADS), 0, st, (const u64 *)(c->d_rp + (size_t)npp * n),
+                           c->d_excl, c->d_totals, n);
+        hipLaunchKernelGGL(p2_scan_totals_kernel, dim3(1), dim3(P2_THREADS), 0, st, c->d_totals, nblocks, c->d_grand);
+        hipLaunchKernelGGL(p2_z_apply_kernel, dim3((n + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, (const u64 *)c->d_excl,
+                           (const u64 *)c->d_totals, (const u64 *)c->d_rp, n, npp, c->zs.coeffs + (size_t)k * n,
+                           c->zs.coeffs + (size_t)(nch + k * npp) * n);
+        ZKLC_HIP(ctx, hipGetLastError());
+        ZKLC_HIP(ctx, hipMemcpyAsync(&grand[k], c->d_grand, 8, hipMemcpyDeviceToHost, st));
+    }
+    P2_RC(p2_commit_values(c, st, c->zs, zs_cap));
+    for (u32 k = 0; k < nch; k++)
+        if (grand[k] != 1) {
+            ctx->last_err = "plonky2: the witness violates the copy constraints (permutation product != 1)";
+            return ZKLC_ERR_INVALID_ARG;
+        }
+    p2_observe_cap(ch, zs_cap, hasher);
+    for (u32 k = 0; k < nch; k++) chal.alpha[k] = ch.challenge();
+    lap(1);
+
+    // ---- quotient
+    {
+        p2_quotient_args a = {};
+        a.cs = c->cs.lde;
+        a.wires = c->wires.lde;
+        a.zs = c->zs.lde;
+        a.gates = c->d_gates;
+        a.extra = c->d_extra;
+        a.k_is = c->d_kis;
+        a.lde_bits = c->lde_bits;
+        a.degree_bits = P.degree_bits;
+        a.rate_bits = P.rate_bits;
+        a.num_constants = P.num_constants;
+        a.nsel = P.num_selectors;
+        a.routed = P.num_routed_wires;
+        a.nch = nch;
+        a.npp = npp;
+        a.qdf = P.quotient_degree_factor;
+        a.num_gates = P.num_gates;
+        a.w_lde = h_root(c->lde_bits);
+        u64 gn = h_pow(GL_GENERATOR, n), w_r = h_root(P.rate_bits);
+        for (u32 k = 0; k < (1u << P.rate_bits); k++) a.zh_inv[k] = h_inv(h_sub(h_mul(gn, h_pow(w_r, k)), 1));
+        a.n_field = n;
+        for (int k = 0; k < 4; k++) a.pih[k] = pih[k];
+        a.ch = chal;
+        a.out = c->d_qv;
+        hipLaunchKernelGGL(p2_quotient_kernel, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a);
+        ZKLC_HIP(ctx, hipGetLastError());
+        // values on g<w_N> (bit-reversed) -> coefficients: inverse DIT, then undo the coset shift
+        P2_RC(zklc_gl_ntt_dev(ctx, st, c->d_qv, c->lde_bits, nch, ZKLC_NTT_INVERSE | ZKLC_NTT_IN_BITREV, 0));
+        hipLaunchKernelGGL(p2_scale_by_powers_kernel, dim3((N + 255) / 256, nch), dim3(256), 0, st, c->d_qv, h_inv(GL_GENERATOR), (u64)N);
+        ZKLC_HIP(ctx, hipGetLastError());
+        P2_RC(p2_commit_coeffs(c, st, c->quot, quot_cap));
+    }
+    p2_observe_cap(ch, quot_cap, hasher);
+    gl2 zeta;
+    zeta.a = ch.challenge();
+    zeta.b = ch.challenge();
+    lap(2);
+
+    // ---- openings at zeta (all polynomials) and g*zeta (Zs)
+    const u32 w0 = c->cs.width, w1 = c->wires.width, w2 = c->zs.width, w3 = c->quot.width;
+    const u32 n_open = w0 + w1 + w2 + w3 + nch;
+    std::vector<gl2> open(n_open);
+    {
+        hipLaunchKernelGGL(p2_ext_powers_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->d_zpow, zeta, (u64)n);
+        const p2_batch *bs[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
+        u32 off = 0;
+        for (int k = 0; k < 4; k++) {
+            hipLaunchKernelGGL(p2_eval_at_ext_kernel, dim3(bs[k]->width), dim3(P2_THREADS), 0, st, (const u64 *)bs[k]->coeffs, n,
+                               (const gl2 *)c->d_zpow, (const u64 *)nullptr, c->d_open + off);
+            off += bs[k]->width;
+        }
+        hipLaunchKernelGGL(p2_eval_at_ext_kernel, dim3(nch), dim3(P2_THREADS), 0, st, (const u64 *)c->zs.coeffs, n,
+                           (const gl2 *)c->d_zpow, (const u64 *)c->d_subgroup, c->d_open + off);
+        ZKLC_HIP(ctx, hipGetLastError());
+        ZKLC_HIP(ctx, hipMemcpyAsync(open.data(), c->d_open, (size_t)n_open * sizeof(gl2), hipMemcpyDeviceToHost, st));
+        ZKLC_HIP(ctx, hipStreamSynchronize(st));
+    }
+    // transcript order = FriOpenings: batch at zeta (constants, sigmas, wires, zs, partial products, quotient), then zs_next
+    for (u32 i = 0; i < n_open; i++) {
+        ch.observe(open[i].a);
+        ch.observe(open[i].b);
+    }
+    gl2 fri_alpha;
+    fri_alpha.a = ch.challenge();
+    fri_alpha.b = ch.challenge();
+    lap(3);
+
+    // ---- FRI: batched quotient in evaluation form, commit phase
+    std::vector<std::vector<uint8_t>> fri_caps(P.num_arities);
+    std::vector<gl2> fri_betas(P.num_arities);
+    u32 final_bits;
+    {
+        p2_fri_combine_args a = {};
+        a.mats[0] = c->cs.lde;
+        a.mats[1] = c->wires.lde;
+        a.mats[2] = c->zs.lde;
+        a.mats[3] = c->quot.lde;
+        a.widths[0] = w0;
+        a.widths[1] = w1;
+        a.widths[2] = w2;
+        a.widths[3] = w3;
+        a.lde_bits = c->lde_bits;
+        a.nch = nch;
+        a.w_lde = h_root(c->lde_bits);
+        a.alpha = fri_alpha;
+        a.zeta = zeta;
+        a.g_zeta = gl2_make(h_mul(zeta.a, h_root(P.degree_bits)), h_mul(zeta.b, h_root(P.degree_bits)));
+        gl2 y0 = gl2_make(0, 0), y1 = gl2_make(0, 0);
+        for (u32 i = w0 + w1 + w2 + w3; i-- > 0;) y0 = h2_add(h2_mul(y0, fri_alpha), open[i]);
+        for (u32 i = nch; i-- > 0;) y1 = h2_add(h2_mul(y1, fri_alpha), open[w0 + w1 + w2 + w3 + i]);
+        a.y0 = y0;
+        a.y1 = y1;
+        a.alpha_pow_nch = h2_pow(fri_alpha, nch);
+        a.out = c->d_fri[0];
+        hipLaunchKernelGGL(p2_fri_combine_kernel, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a);
+        ZKLC_HIP(ctx, hipGetLastError());
+        u32 bits = c->lde_bits;
+        u64 shift = GL_GENERATOR;
+        for (u32 r = 0; r < P.num_arities; r++) {
+            u32 ab = P.arity_bits[r], A = 1u << ab;
+            u32 leaves_bits = bits - ab;
+            P2_RC(p2_merkle(c, st, (const u64 *)c->d_fri[r], 1, 2 * A, leaves_bits, 2 * A, c->d_fri_tree[r]));
+            u32 cap_h = P.cap_height < leaves_bits ? P.cap_height : leaves_bits;
+            fri_caps[r].resize((size_t)32 << cap_h);
+            ZKLC_HIP(ctx, hipMemcpyAsync(fri_caps[r].data(), p2_tree_level(c->d_fri_tree[r], leaves_bits, leaves_bits - cap_h),
+                                         fri_caps[r].size(), hipMemcpyDeviceToHost, st));
+            ZKLC_HIP(ctx, hipStreamSynchronize(st));
+            p2_observe_cap(ch, fri_caps[r], hasher);
+            fri_betas[r].a = ch.challenge();
+            fri_betas[r].b = ch.challenge();
+            u32 chunks = 1u << leaves_bits;
+            hipLaunchKernelGGL(p2_fri_fold_kernel, dim3((chunks + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st,
+                               (const gl2 *)c->d_fri[r], c->d_fri[r + 1], bits, ab, shift, h_root(bits), h_inv(h_root(ab)),
+                               h_inv(A), fri_betas[r]);
+            ZKLC_HIP(ctx, hipGetLastError());
+            shift = h_pow(shift, A);
+            bits = leaves_bits;
+        }
+        final_bits = bits;
+        u32 M = 1u << bits;
+        hipLaunchKernelGGL(p2_fri_final_poly_kernel, dim3((M + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st,
+                           (const gl2 *)c->d_fri[P.num_arities], c->d_final, bits, h_inv(shift), h_inv(h_root(bits)), h_inv(M));
+        ZKLC_HIP(ctx, hipGetLastError());
+    }
+    std::vector<gl2> final_poly((size_t)1 << final_bits);
+    ZKLC_HIP(ctx, hipMemcpyAsync(final_poly.data(), c->d_final, final_poly.size() * sizeof(gl2), hipMemcpyDeviceToHost, st));
+    ZKLC_HIP(ctx, hipStreamSynchronize(st));
+    const u32 final_len = 1u << (final_bits - P.rate_bits);
+    for (size_t i = final_len; i < final_poly.size(); i++)
+        if (final_poly[i].a || final_poly[i].b) {
+            ctx->last_err = "plonky2: FRI final polynomial has a non-zero high coefficient (witness does not satisfy the circuit)";
+            return ZKLC_ERR_INVALID_ARG;
+        }
+    for (u32 i = 0; i < final_len; i++) {
+        ch.observe(final_poly[i].a);
+        ch.observe(final_poly[i].b);
+    }
+    lap(4);
+
+    // ---- proof of work
+    u64 pow_witness;
+    {
+        p2_pow_args a = {};
+        for (int i = 0; i < 12; i++) a.state[i] = ch.state[i];
+        for (int i = 0; i < ch.n_in; i++) a.in[i] = ch.in[i];
+        a.n_in = ch.n_in;
+        a.pow_bits = P.proof_of_work_bits;
+        a.found = c->d_found;
+        const u64 batch = 1ULL << 20;
+        unsigned long long found = ~0ULL;
+        for (u64 base = 0;; base += batch) {
+            ZKLC_HIP(ctx, hipMemsetAsync(c->d_found, 0xFF, 8, st));
+            a.base = base;
+            hipLaunchKernelGGL(p2_pow_kernel, dim3((unsigned)(batch / P2_THREADS)), dim3(P2_THREADS), 0, st, a);
+            ZKLC_HIP(ctx, hipGetLastError());
+            ZKLC_HIP(ctx, hipMemcpyAsync(&found, c->d_found, 8, hipMemcpyDeviceToHost, st));
+            ZKLC_HIP(ctx, hipStreamSynchronize(st));
+            if (found != ~0ULL) break;
+            if (base > (1ULL << 50)) return ZKLC_ERR_INVALID_ARG;
+        }
+        pow_witness = found;
+        ch.observe(pow_witness);
+        u64 resp = ch.challenge();
+        if (resp >> (64 - P.proof_of_work_bits)) {
+            ctx->last_err = "plonky2: proof-of-work response mismatch between the kernel and the host transcript";
+            return ZKLC_ERR_HIP;
+        }
+    }
+    lap(5);
+
+    // ---- query rounds: gather leaves, Merkle paths and FRI cosets
+    std::vector<u64> qwords(L.per_round_words * P.num_query_rounds);
+    {
+        std::vector<p2_gather> gs;
+        const p2_batch *bs[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
+        size_t dst = 0;
+        for (u32 q = 0; q < P.num_query_rounds; q++) {
+            u64 x_index = ch.challenge() & (N - 1);
+            for (int k = 0; k < 4; k++) {
+                gs.push_back({bs[k]->lde + x_index, (u64)N, bs[k]->width, (u32)dst});
+                dst += bs[k]->width;
+                for (u32 l = 0; l < L.depth0; l++) {
+                    gs.push_back({p2_tree_level(bs[k]->tree, c->lde_bits, l) + 4 * ((x_index >> l) ^ 1), 1, 4, (u32)dst});
+                    dst += 4;
+                }
+            }
+            u32 bits = c->lde_bits;
+            u64 idx = x_index;
+            for (u32 r = 0; r < P.num_arities; r++) {
+                u32 ab = P.arity_bits[r];
+                idx >>= ab;
+                bits -= ab;
+                gs.push_back({(const u64 *)(c->d_fri[r] + (idx << ab)), 1, 2u << ab, (u32)dst});
+                dst += 2u << ab;
+                u32 cap_h = P.cap_height < bits ? P.cap_height : bits;
+                for (u32 l = 0; l < bits - cap_h; l++) {
+                    gs.push_back({p2_tree_level(c->d_fri_tree[r], bits, l) + 4 * ((idx >> l) ^ 1), 1, 4, (u32)dst});
+                    dst += 4;
+                }
+            }
+        }
+        if (dst != qwords.size()) return ZKLC_ERR_INVALID_ARG;
+        if (c->gather_cap < gs.size()) {
+            P2_ALLOC(c, c->d_gather, gs.size() * sizeof(p2_gather));
+            c->gather_cap = gs.size();
+        }
+        if (c->gather_out_words < qwords.size()) {
+            P2_ALLOC(c, c->d_gather_out, qwords.size() * 8);
+            c->gather_out_words = qwords.size();
+        }
+        ZKLC_HIP(ctx, hipMemcpyAsync(c->d_gather, gs.data(), gs.size() * sizeof(p2_gather), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(p2_gather_kernel, dim3((unsigned)gs.size()), dim3(64), 0, st, (const p2_gather *)c->d_gather, (u32)gs.size(),
+                           c->d_gather_out);
+        ZKLC_HIP(ctx, hipGetLastError());
+        ZKLC_HIP(ctx, hipMemcpyAsync(qwords.data(), c->d_gather_out, qwords.size() * 8, hipMemcpyDeviceToHost, st));
+        ZKLC_HIP(ctx, hipStreamSynchronize(st));
+    }
+
+    // ---- serialise
+    uint8_t *o = proof_out;
+    auto put = [&](const void *p, size_t nbytes) {
+        memcpy(o, p, nbytes);
+        o += nbytes;
+    };
+    put(wires_cap.data(), wires_cap.size());
+    put(zs_cap.data(), zs_cap.size());
+    put(quot_cap.data(), quot_cap.size());
+    // openings: constants, sigmas, wires, zs, zs_next, partial products, quotient
+    put(open.data(), (size_t)(w0 + w1 + nch) * 16);
+    put(open.data() + (w0 + w1 + w2 + w3), (size_t)nch * 16);
+    put(open.data() + (w0 + w1 + nch), (size_t)(w2 - nch + w3) * 16);
+    for (u32 r = 0; r < P.num_arities; r++) put(fri_caps[r].data(), fri_caps[r].size());
+    {
+        const u64 *w = qwords.data();
+        u32 widths[4] = {w0, w1, w2, w3};
+        for (u32 q = 0; q < P.num_query_rounds; q++) {
+            for (int k = 0; k < 4; k++) {
+                put(w, 8 * (size_t)widths[k]);
+                w += widths[k];
+                *o++ = (uint8_t)L.depth0;
+                put(w, 32 * (size_t)L.depth0);
+                w += 4 * (size_t)L.depth0;
+            }
+            u32 bits = c->lde_bits;
+            for (u32 r = 0; r < P.num_arities; r++) {
+                u32 ab = P.arity_bits[r];
+                bits -= ab;
+                put(w, 16 * ((size_t)1 << ab));
+                w += 2 * ((size_t)1 << ab);
+                u32 cap_h = P.cap_height < bits ? P.cap_height : bits;
+                *o++ = (uint8_t)(bits - cap_h);
+                put(w, 32 * (size_t)(bits - cap_h));
+                w += 4 * (size_t)(bits - cap_h);
+            }
+        }
+    }
+    put(final_poly.data(), (size_t)final_len * 16);
+    put(&pow_witness, 8);
+    u64 npi = P.num_public_inputs;
+    put(&npi, 8);
+    put(public_inputs, 8 * (size_t)npi);
+    if ((size_t)(o - proof_out) != L.bytes) return ZKLC_ERR_INVALID_ARG;
+    *proof_len = L.bytes;
+    lap(6);
+    c->timings[7] = p2_now_ms() - t0;
+    for (u32 k = 0; k < nch; k++) c->last_challenges.push_back(chal.beta[k]);
+    for (u32 k = 0; k < nch; k++) c->last_challenges.push_back(chal.gamma[k]);
+    for (u32 k = 0; k < nch; k++) c->last_challenges.push_back(chal.alpha[k]);
+    c->last_challenges.push_back(zeta.a);
+    c->last_challenges.push_back(zeta.b);
+    c->last_challenges.push_back(fri_alpha.a);
+    c->last_challenges.push_back(fri_alpha.b);
+    for (u32 r = 0; r < P.num_arities; r++) {
+        c->last_challenges.push_back(fri_betas[r].a);
+        c->last_challenges.push_back(fri_betas[r].b);
+    }
+    return ZKLC_OK;
+}
+
+extern "C" int32_t zklc_plonky2_prove(zklc_ctx *ctx, zklc_plonky2_circuit *c, const uint64_t *wires, const uint64_t *public_inputs,
+                                      uint8_t *proof_out, uint64_t proof_cap, uint64_t *proof_len) {
+    if (!ctx || !c || c->ctx != ctx || !wires) return ZKLC_ERR_INVALID_ARG;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t bytes = (size_t)c->P.num_wires * c->n * 8;
+    ZKLC_HIP(ctx, hipMemcpyAsync(c->d_wire_vals, wires, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return zklc_plonky2_prove_dev(ctx, ctx->stream, c, c->d_wire_vals, public_inputs, proof_out, proof_cap, proof_len);
+}

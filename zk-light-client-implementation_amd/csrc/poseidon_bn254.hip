@@ -30,11 +30,12 @@ __global__ void __launch_bounds__(64) poseidon_bn254_permute_kernel(u64 *states,
 }
 
 __global__ void __launch_bounds__(64)
-bn254_hash_leaves_kernel(const u64 *__restrict__ mat, size_t stride, u32 width, u32 n_leaves, u64 *__restrict__ digests) {
+bn254_hash_leaves_kernel(const u64 *__restrict__ mat, size_t stride, size_t leaf_stride, u32 width, u32 n_leaves,
+                         u64 *__restrict__ digests) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_leaves) return;
     u32 h[8];
-    poseidon_bn254_hash_or_noop(mat + i, stride, width, h);
+    poseidon_bn254_hash_or_noop(mat + (size_t)i * leaf_stride, stride, width, h);
     uint4 *o = reinterpret_cast<uint4 *>(digests + (size_t)i * 4);
     o[0] = make_uint4(h[0], h[1], h[2], h[3]);
     o[1] = make_uint4(h[4], h[5], h[6], h[7]);
@@ -80,10 +81,15 @@ extern "C" int32_t zklc_bn254_merkle_commit_dev(zklc_ctx *ctx, void *stream, con
                                                 uint32_t width, uint32_t cap_height, uint64_t *d_tree) {
     if (!ctx || !d_mat || !d_tree || log_leaves > 30 || cap_height > log_leaves || width == 0) return ZKLC_ERR_INVALID_ARG;
     if (stride < (1ULL << log_leaves)) return ZKLC_ERR_INVALID_ARG;
+    return zklc_bn254_merkle_commit_strided(ctx, zklc_pick_stream(ctx, stream), d_mat, stride, 1, log_leaves, width, cap_height, d_tree);
+}
+
+int32_t zklc_bn254_merkle_commit_strided(zklc_ctx *ctx, hipStream_t st, const uint64_t *d_mat, uint64_t stride, uint64_t leaf_stride,
+                                         uint32_t log_leaves, uint32_t width, uint32_t cap_height, uint64_t *d_tree) {
     ZKLC_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = zklc_pick_stream(ctx, stream);
     u32 n = 1u << log_leaves;
-    hipLaunchKernelGGL(bn254_hash_leaves_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_mat, (size_t)stride, width, n, d_tree);
+    hipLaunchKernelGGL(bn254_hash_leaves_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_mat, (size_t)stride, (size_t)leaf_stride,
+                       width, n, d_tree);
     ZKLC_HIP(ctx, hipGetLastError());
     u64 *level = d_tree;
     for (u32 l = 0; l < log_leaves - cap_height; l++) {

@@ -49,3 +49,10 @@ inline hipStream_t zklc_pick_stream(zklc_ctx *, void *s) { return (hipStream_t)s
 int32_t zklc_ed25519_init(zklc_ctx *ctx);
 void zklc_ed25519_fini(zklc_ctx *ctx);
 void zklc_gl_fini(zklc_ctx *ctx);
+
+// Merkle commit with an explicit leaf layout: element q of leaf i at d_mat[q * stride + i * leaf_stride]
+// (poly-major LDE matrices: leaf_stride 1; row-major FRI leaves: stride 1, leaf_stride = width)
+int32_t zklc_gl_merkle_commit_strided(zklc_ctx *ctx, hipStream_t st, const uint64_t *d_mat, uint64_t stride, uint64_t leaf_stride,
+                                      uint32_t log_leaves, uint32_t width, uint32_t cap_height, uint64_t *d_tree);
+int32_t zklc_bn254_merkle_commit_strided(zklc_ctx *ctx, hipStream_t st, const uint64_t *d_mat, uint64_t stride, uint64_t leaf_stride,
+                                         uint32_t log_leaves, uint32_t width, uint32_t cap_height, uint64_t *d_tree);

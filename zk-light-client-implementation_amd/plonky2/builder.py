@@ -1,0 +1,386 @@
+"""Host-side circuit builder: the subset of plonky2's `CircuitBuilder` the signature-aggregation circuits use.
+
+Mirrors the API the reference calls on the un-vendored plonky2 fork (wormhole-foundation/plonky2-near@2244a9d):
+  CircuitBuilder::new(config)           near_bft_finality/src/prove_crypto/ed25519.rs:29-33, recursion.rs:36
+  add_virtual_target / register_public_input / connect / constant / add / mul / mul_add / arithmetic
+  hash_n_to_hash_no_pad                 (PoseidonGate rows)
+  split_le (BaseSumGate), add_u32/mul_u32 via U32ArithmeticGate (crypto/plonky2_u32/src/gadgets/arithmetic_u32.rs)
+  build() -> CircuitData                ed25519.rs:33,75, recursion.rs:94
+`CircuitData.prove(inputs)` (ed25519.rs:60,100, recursion.rs:95) runs the witness generators on the host and
+hands the wire matrix to the GPU prover (prover.py -> zklc_plonky2_prove).
+
+What `build()` produces is the prover's view of the circuit (plonky2 `ProverOnlyCircuitData` + `CommonCircuitData`):
+selector + constant polynomials, sigma polynomials from the copy constraints, k_is, the gate list sorted by
+(degree, id) and the selector groups -- the same construction as the fork's `selector_polynomials` /
+`WirePartition::get_sigma_polys`, so `common_data()` has the schema of the reference's common_data.json.
+"""
+import numpy as np
+
+from . import gates as G
+
+P = 2**64 - 2**32 + 1
+UNUSED_SELECTOR = (1 << 32) - 1
+GENERATOR = 7
+POWER_OF_TWO_GENERATOR = 1753635133440165772
+
+
+def standard_recursion_config():
+    """CircuitConfig::standard_recursion_config() as serialised in the reference's common_data.json "config"."""
+    fri = {"rate_bits": 3, "cap_height": 4, "proof_of_work_bits": 16, "reduction_strategy": {"ConstantArityBits": [4, 5]},
+           "num_query_rounds": 28}
+    return {"num_wires": 135, "num_routed_wires": 80, "num_constants": 2, "use_base_arithmetic_gate": True, "security_bits": 100,
+            "num_challenges": 2, "zero_knowledge": False, "max_quotient_degree_factor": 8, "fri_config": fri}
+
+
+def wide_ecc_config():
+    """CircuitConfig::wide_ecc_config() (near_bft_finality/src/prove_crypto/ed25519.rs:29): 234 wires."""
+    c = standard_recursion_config()
+    c["num_wires"] = 234
+    return c
+
+
+def root_of_unity(log_n):
+    return pow(POWER_OF_TWO_GENERATOR, 1 << (32 - log_n), P)
+
+
+class Target:
+    __slots__ = ("row", "col", "idx")
+
+    def __init__(self, row=None, col=None, idx=None):
+        self.row, self.col, self.idx = row, col, idx
+
+    def key(self):
+        return ("w", self.row, self.col) if self.idx is None else ("v", self.idx)
+
+    def __repr__(self):
+        return "Wire(%d,%d)" % (self.row, self.col) if self.idx is None else "Virtual(%d)" % self.idx
+
+
+class CircuitBuilder:
+    def __init__(self, config=None):
+        self.config = config or standard_recursion_config()
+        self.rows = []            # (gate, constants)
+        self.n_virtual = 0
+        self.parent = {}          # union-find over target keys
+        self.generators = []      # (input targets, fn(values) -> [(target, value)])
+        self.public_inputs = []
+        self._const_targets = {}
+        self._arith_slot = {}     # (c0, c1) -> (row, next op)
+        self._u32_slot = None
+        self._const_slot = None
+        self._ra_slot = {}
+
+    # ---- targets / copy constraints
+    def add_virtual_target(self):
+        t = Target(idx=self.n_virtual)
+        self.n_virtual += 1
+        return t
+
+    def add_virtual_targets(self, n):
+        return [self.add_virtual_target() for _ in range(n)]
+
+    def add_virtual_public_input(self):
+        t = self.add_virtual_target()
+        self.register_public_input(t)
+        return t
+
+    def register_public_input(self, t):
+        self.public_inputs.append(t)
+
+    def _find(self, k):
+        p = self.parent
+        root = k
+        while p.get(root, root) != root:
+            root = p[root]
+        while p.get(k, k) != root:
+            p[k], k = root, p[k]
+        return root
+
+    def connect(self, a, b):
+        ra, rb = self._find(a.key()), self._find(b.key())
+        if ra != rb:
+            self.parent[ra] = rb
+
+    def add_gate(self, gate, constants=()):
+        assert gate.num_wires <= self.config["num_wires"], "gate %s needs %d wires" % (gate.id(), gate.num_wires)
+        self.rows.append((gate, [c % P for c in constants]))
+        return len(self.rows) - 1
+
+    def add_generator(self, inputs, fn):
+        self.generators.append((list(inputs), fn))
+
+    # ---- constants
+    def constant(self, c):
+        c %= P
+        if c in self._const_targets:
+            return self._const_targets[c]
+        nc = self.config["num_constants"]
+        if self._const_slot is None or self._const_slot[1] == nc:
+            self._const_slot = [self.add_gate(G.ConstantGate(nc), [0] * nc), 0]
+        row, k = self._const_slot
+        self.rows[row][1][k] = c
+        self._const_slot[1] += 1
+        t = Target(row, k)
+        self.add_generator([], lambda v, t=t, c=c: [(t, c)])
+        self._const_targets[c] = t
+        return t
+
+    def zero(self):
+        return self.constant(0)
+
+    def one(self):
+        return self.constant(1)
+
+    # ---- arithmetic (ArithmeticGate: out = c0*m0*m1 + c1*addend)
+    def arithmetic(self, c0, m0, m1, c1, addend):
+        c0 %= P
+        c1 %= P
+        gate = G.ArithmeticGate.new_from_config(self.config)
+        slot = self._arith_slot.get((c0, c1))
+        if slot is None or slot[1] == gate.num_ops:
+            slot = [self.add_gate(gate, [c0, c1]), 0]
+            self._arith_slot[(c0, c1)] = slot
+        row, i = slot
+        slot[1] += 1
+        w = [Target(row, 4 * i + k) for k in range(4)]
+        self.connect(m0, w[0])
+        self.connect(m1, w[1])
+        self.connect(addend, w[2])
+        self.add_generator([w[0], w[1], w[2]],
+                           lambda v, w=w, c0=c0, c1=c1: [(w[3], (c0 * v[0] * v[1] + c1 * v[2]) % P)])
+        return w[3]
+
+    def mul(self, a, b):
+        return self.arithmetic(1, a, b, 0, self.zero())
+
+    def add(self, a, b):
+        return self.arithmetic(1, a, self.one(), 1, b)
+
+    def sub(self, a, b):
+        return self.arithmetic(1, a, self.one(), P - 1, b)
+
+    def mul_add(self, a, b, c):
+        return self.arithmetic(1, a, b, 1, c)
+
+    def mul_const(self, c, a):
+        return self.arithmetic(c, a, self.one(), 0, self.zero())
+
+    # ---- BaseSumGate: little-endian bit decomposition (split_le)
+    def split_le(self, x, num_bits):
+        gate = G.BaseSumGate(num_bits, 2)
+        row = self.add_gate(gate)
+        s = Target(row, 0)
+        self.connect(x, s)
+        bits = [Target(row, 1 + i) for i in range(num_bits)]
+
+        def gen(v, bits=bits, num_bits=num_bits):
+            assert v[0] < (1 << num_bits), "split_le: value does not fit"
+            return [(bits[i], (v[0] >> i) & 1) for i in range(num_bits)]
+        self.add_generator([s], gen)
+        return bits
+
+    # ---- U32ArithmeticGate: (lo, hi) = m0*m1 + addend on 32-bit values
+    def mul_add_u32(self, m0, m1, addend):
+        gate = G.U32ArithmeticGate.new_from_config(self.config)
+        if self._u32_slot is None or self._u32_slot[1] == gate.num_ops:
+            self._u32_slot = [self.add_gate(gate), 0]
+        row, i = self._u32_slot
+        self._u32_slot[1] += 1
+        w = [Target(row, 6 * i + k) for k in range(6)]
+        limbs = [Target(row, 6 * gate.num_ops + 32 * i + j) for j in range(32)]
+        self.connect(m0, w[0])
+        self.connect(m1, w[1])
+        self.connect(addend, w[2])
+
+        def gen(v, w=w, limbs=limbs):
+            out = v[0] * v[1] + v[2]
+            assert out < (1 << 64) and out < P
+            lo, hi = out & 0xFFFFFFFF, out >> 32
+            diff = (0xFFFFFFFF - hi) % P
+            inv = pow(diff, P - 2, P) if diff else 0   # arithmetic_u32.rs generator: inverse of (u32::MAX - hi), or 0
+            res = [(w[3], lo), (w[4], hi), (w[5], inv)]
+            res += [(limbs[j], (out >> (2 * j)) & 3) for j in range(32)]
+            return res
+        self.add_generator(w[:3], gen)
+        return w[3], w[4]
+
+    # ---- Poseidon (PoseidonGate rows); witness rows come from the library (zklc_poseidon_gl_gate_rows)
+    def permute(self, state12):
+        row = self.add_gate(G.PoseidonGate())
+        ins = [Target(row, i) for i in range(12)]
+        for a, b in zip(state12, ins):
+            self.connect(a, b)
+        swap = Target(row, G.PoseidonGate.WIRE_SWAP)
+        self.connect(swap, self.zero())
+
+        def gen(v, row=row):
+            from .prover import poseidon_gate_rows
+            r = poseidon_gate_rows(np.array([v], dtype=np.uint64), np.zeros(1, dtype=np.uint64))[0]
+            return [(Target(row, c), int(r[c])) for c in range(12, 135) if c != 24]
+        self.add_generator(ins, gen)
+        return [Target(row, 12 + i) for i in range(12)]
+
+    def hash_n_to_hash_no_pad(self, inputs):
+        """overwrite-mode sponge, rate 8 (poseidon/goldilocks.go:41-68)"""
+        z = self.zero()
+        state = [z] * 12
+        for i in range(0, len(inputs), 8):
+            chunk = inputs[i:i + 8]
+            state = list(chunk) + state[len(chunk):]
+            state = self.permute(state)
+        return state[:4]
+
+    # ---- build
+    def build(self):
+        cfg = self.config
+        # public inputs hash wired into a PublicInputGate (plonky2 `CircuitBuilder::build`)
+        pi_hash = self.hash_n_to_hash_no_pad(self.public_inputs)
+        pi_row = self.add_gate(G.PublicInputGate())
+        for i in range(4):
+            self.connect(pi_hash[i], Target(pi_row, i))
+        # pad to a power of two (and to a degree FRI can handle: lde size >= 2^cap_height)
+        min_rows = max(1 << max(0, cfg["fri_config"]["cap_height"] - cfg["fri_config"]["rate_bits"]), 2)
+        while len(self.rows) < min_rows or len(self.rows) & (len(self.rows) - 1):
+            self.add_gate(G.NoopGate())
+        return CircuitData(self)
+
+
+def fri_reduction_arity_bits(cfg, degree_bits):
+    """FriReductionStrategy::ConstantArityBits(arity, final_poly_bits).reduction_arity_bits (plonky2 fri/reduction_strategies.rs)"""
+    arity_bits, final_poly_bits = cfg["fri_config"]["reduction_strategy"]["ConstantArityBits"]
+    rate_bits, cap_height = cfg["fri_config"]["rate_bits"], cfg["fri_config"]["cap_height"]
+    out = []
+    while degree_bits > final_poly_bits and degree_bits + rate_bits - arity_bits >= cap_height:
+        out.append(arity_bits)
+        degree_bits -= arity_bits
+    return out
+
+
+class CircuitData:
+    """Prover-side circuit: sorted gates, selector groups, constants, sigmas (numpy u64, poly-major) + witness program."""
+
+    def __init__(self, b):
+        cfg = self.config = b.config
+        self.builder = b
+        n = self.n = len(b.rows)
+        self.degree_bits = n.bit_length() - 1
+        qdf = self.quotient_degree_factor = cfg["max_quotient_degree_factor"]
+        # gates sorted by (degree, id); selector groups (plonky2 plonk/circuit_builder.rs + gates/selectors.rs)
+        uniq = sorted({g for g, _ in b.rows}, key=lambda g: (g.degree, g.id()))
+        self.gates = uniq
+        index = {g: i for i, g in enumerate(uniq)}
+        max_degree = qdf + 1
+        if uniq[-1].degree + len(uniq) - 1 <= max_degree:
+            groups = [(0, len(uniq))]
+        else:
+            assert uniq[-1].degree < max_degree, "gate degree too high for the quotient degree factor"
+            groups, start = [], 0
+            while start < len(uniq):
+                size = 0
+                while start + size < len(uniq) and size + uniq[start + size].degree < max_degree:
+                    size += 1
+                groups.append((start, start + size))
+                start += size
+        self.groups = groups
+        group_of = [next(j for j, (s, e) in enumerate(groups) if s <= i < e) for i in range(len(uniq))]
+        self.selector_indices = group_of
+        nsel = len(groups)
+        ngc = max(g.num_constants for g in uniq)
+        self.num_constants = nsel + ngc
+        consts = np.zeros((self.num_constants, n), dtype=np.uint64)
+        for r, (g, cs) in enumerate(b.rows):
+            i = index[g]
+            for s in range(nsel):
+                consts[s, r] = i if s == group_of[i] else UNUSED_SELECTOR
+            for k, c in enumerate(cs):
+                consts[nsel + k, r] = c
+        self.constants = consts
+        self.num_gate_constraints = max(g.num_constraints for g in uniq)
+        routed = cfg["num_routed_wires"]
+        self.num_partial_products = -(-routed // qdf) - 1
+        self.k_is = [pow(GENERATOR, i, P) for i in range(routed)]
+        w = root_of_unity(self.degree_bits)
+        sub = [1] * n
+        for i in range(1, n):
+            sub[i] = sub[i - 1] * w % P
+        self.subgroup = sub
+        # sigma polynomials: every routed wire maps to the next wire of its copy class (cyclically)
+        classes = {}
+        for k in list(b.parent):
+            if k[0] == "w":
+                classes.setdefault(b._find(k), []).append((k[2], k[1]))   # (col, row)
+        sig_col = np.tile(np.arange(routed, dtype=np.int64)[:, None], (1, n))
+        sig_row = np.tile(np.arange(n, dtype=np.int64)[None, :], (routed, 1))
+        for members in classes.values():
+            members.sort()
+            assert all(c < routed for c, _ in members), "copy constraint on a non-routed wire"
+            for (c0, r0), (c1, r1) in zip(members, members[1:] + members[:1]):
+                sig_col[c0, r0], sig_row[c0, r0] = c1, r1
+        k_arr = np.array(self.k_is, dtype=object)
+        sub_arr = np.array(sub, dtype=object)
+        self.sigmas = np.array((k_arr[sig_col] * sub_arr[sig_row]) % P, dtype=np.uint64)
+        self.fri_arity_bits = fri_reduction_arity_bits(cfg, self.degree_bits)
+        self.num_public_inputs = len(b.public_inputs)
+
+    def prover(self, ctx, hasher=0):
+        """upload + preprocess the circuit on `ctx`'s GPU (zklc_plonky2_circuit_create)"""
+        from .prover import Prover
+        return Prover(ctx, self, hasher)
+
+    def common_data(self):
+        """same schema as the reference's common_data.json (near_bft_finality/src/bin/prove_block.rs:320-458 writes it)"""
+        cfg = self.config
+        return {
+            "config": cfg,
+            "fri_params": {"config": cfg["fri_config"], "hiding": False, "degree_bits": self.degree_bits,
+                           "reduction_arity_bits": self.fri_arity_bits},
+            "gates": [g.id() for g in self.gates],
+            "selectors_info": {"selector_indices": self.selector_indices,
+                               "groups": [{"start": s, "end": e} for s, e in self.groups]},
+            "quotient_degree_factor": self.quotient_degree_factor,
+            "num_gate_constraints": self.num_gate_constraints,
+            "num_constants": self.num_constants,
+            "num_public_inputs": self.num_public_inputs,
+            "k_is": self.k_is,
+            "num_partial_products": self.num_partial_products,
+            "num_lookup_polys": 0, "num_lookup_selectors": 0, "luts": [],
+        }
+
+    # ---- witness generation (plonky2 `generate_partial_witness`): run generators until no progress
+    def generate_witness(self, inputs):
+        """inputs: {Target: value}.  Returns (wires u64[num_wires, n], public input values)."""
+        b = self.builder
+        vals = {}
+
+        def setv(t, v):
+            k = b._find(t.key())
+            v %= P
+            if k in vals:
+                assert vals[k] == v, "copy constraint violated at %r: %d != %d" % (t, vals[k], v)
+            vals[k] = v
+
+        for t, v in inputs.items():
+            setv(t, v)
+        pending = list(b.generators)
+        while pending:
+            rest = []
+            for ins, fn in pending:
+                ks = [b._find(t.key()) for t in ins]
+                if all(k in vals for k in ks):
+                    for t, v in fn([vals[k] for k in ks]):
+                        setv(t, v)
+                else:
+                    rest.append((ins, fn))
+            assert len(rest) < len(pending), "witness generation stuck: %d generators without inputs" % len(rest)
+            pending = rest
+        wires = np.zeros((self.config["num_wires"], self.n), dtype=np.uint64)
+        for k, v in vals.items():
+            if k[0] == "w":
+                wires[k[2], k[1]] = v
+        for k in b.parent:
+            if k[0] == "w":
+                r = b._find(k)
+                if r in vals:
+                    wires[k[2], k[1]] = vals[r]
+        pis = [vals[b._find(t.key())] for t in b.public_inputs]
+        return wires, pis

@@ -1,0 +1,274 @@
+"""Gate descriptors of the plonky2 circuits on the signature-aggregation path (host side).
+
+A descriptor carries what the circuit builder and the GPU prover need to know about a gate type:
+its id string (the exact `Gate::id()` text that appears in the reference's common_data.json, e.g.
+near_bft_finality/proofs/random/CGZP.../common_data.json "gates"), wire/constant/constraint counts,
+constraint degree, and the (type code, parameters) pair handed to the C ABI
+(include/zklc.h `zklc_plonky2_gate`).  The constraint evaluators themselves are HIP device code
+(csrc/plonky2_gates.cuh); nothing here evaluates a constraint.
+
+Standard gates: plonky2-near@2244a9d `plonky2/src/gates/*` (un-vendored; layouts as restated in
+gnark-plonky2-verifier/plonk/gates/*.go).  u32 gates: crypto/plonky2_u32/src/gates/*.rs (in-tree).
+"""
+import re
+
+# type codes shared with csrc/plonky2_gates.cuh
+NOOP, CONSTANT, PUBLIC_INPUT, ARITHMETIC, ARITHMETIC_EXT, MUL_EXT, BASE_SUM, POSEIDON, POSEIDON_MDS, RANDOM_ACCESS, \
+    REDUCING, REDUCING_EXT, EXPONENTIATION, COSET_INTERPOLATION, U32_ARITHMETIC, U32_ADD_MANY, U32_SUBTRACTION, \
+    U32_RANGE_CHECK, COMPARISON = range(19)
+
+_PH = "PhantomData<plonky2_field::goldilocks_field::GoldilocksField>"
+
+
+class Gate:
+    num_constants = 0
+    params = (0, 0, 0, 0)
+    extra = ()          # u64 table handed to the device (CosetInterpolationGate weights)
+
+    def id(self):
+        raise NotImplementedError
+
+    def __eq__(self, o):
+        return isinstance(o, Gate) and self.id() == o.id()
+
+    def __hash__(self):
+        return hash(self.id())
+
+    def __repr__(self):
+        return self.id()
+
+
+class NoopGate(Gate):
+    code, degree, num_constraints, num_wires = NOOP, 0, 0, 0
+
+    def id(self):
+        return "NoopGate"
+
+
+class ConstantGate(Gate):
+    code, degree = CONSTANT, 1
+
+    def __init__(self, num_consts):
+        self.num_consts = self.num_constants = self.num_constraints = self.num_wires = num_consts
+        self.params = (num_consts, 0, 0, 0)
+
+    def id(self):
+        return "ConstantGate { num_consts: %d }" % self.num_consts
+
+
+class PublicInputGate(Gate):
+    code, degree, num_constraints, num_wires = PUBLIC_INPUT, 1, 4, 4
+
+    def id(self):
+        return "PublicInputGate"
+
+
+class ArithmeticGate(Gate):
+    """num_ops x (m0, m1, addend, out): out = c0*m0*m1 + c1*addend (arithmetic_gate.go:48-84)"""
+    code, degree, num_constants = ARITHMETIC, 3, 2
+
+    def __init__(self, num_ops):
+        self.num_ops = self.num_constraints = num_ops
+        self.num_wires = 4 * num_ops
+        self.params = (num_ops, 0, 0, 0)
+
+    @staticmethod
+    def new_from_config(cfg):
+        return ArithmeticGate(cfg["num_routed_wires"] // 4)
+
+    def id(self):
+        return "ArithmeticGate { num_ops: %d }" % self.num_ops
+
+
+class ArithmeticExtensionGate(Gate):
+    code, degree, num_constants = ARITHMETIC_EXT, 3, 2
+
+    def __init__(self, num_ops):
+        self.num_ops = num_ops
+        self.num_constraints = 2 * num_ops
+        self.num_wires = 8 * num_ops
+        self.params = (num_ops, 0, 0, 0)
+
+    @staticmethod
+    def new_from_config(cfg):
+        return ArithmeticExtensionGate(cfg["num_routed_wires"] // 8)
+
+    def id(self):
+        return "ArithmeticExtensionGate { num_ops: %d }" % self.num_ops
+
+
+class MulExtensionGate(Gate):
+    code, degree, num_constants = MUL_EXT, 3, 1
+
+    def __init__(self, num_ops):
+        self.num_ops = num_ops
+        self.num_constraints = 2 * num_ops
+        self.num_wires = 6 * num_ops
+        self.params = (num_ops, 0, 0, 0)
+
+    @staticmethod
+    def new_from_config(cfg):
+        return MulExtensionGate(cfg["num_routed_wires"] // 6)
+
+    def id(self):
+        return "MulExtensionGate { num_ops: %d }" % self.num_ops
+
+
+class BaseSumGate(Gate):
+    """wire 0 = sum, wires 1..=num_limbs = limbs in base B (base_sum_gate.go:66-96)"""
+    code = BASE_SUM
+
+    def __init__(self, num_limbs, base=2):
+        self.num_limbs, self.base = num_limbs, base
+        self.degree = base
+        self.num_constraints = 1 + num_limbs
+        self.num_wires = 1 + num_limbs
+        self.params = (num_limbs, base, 0, 0)
+
+    def id(self):
+        return "BaseSumGate { num_limbs: %d } + Base: %d" % (self.num_limbs, self.base)
+
+
+class PoseidonGate(Gate):
+    """poseidon_gate.go:27-82: inputs 0..12, outputs 12..24, swap 24, delta 25..29, S-box inputs 29..135"""
+    code, degree, num_constraints, num_wires = POSEIDON, 7, 123, 135
+    WIRE_SWAP, START_DELTA, START_FULL_0, START_PARTIAL, START_FULL_1 = 24, 25, 29, 65, 87
+
+    def id(self):
+        return "PoseidonGate(%s)<WIDTH=12>" % _PH
+
+
+class PoseidonMdsGate(Gate):
+    code, degree, num_constraints, num_wires = POSEIDON_MDS, 1, 24, 48
+
+    def id(self):
+        return "PoseidonMdsGate(%s)<WIDTH=12>" % _PH
+
+
+class RandomAccessGate(Gate):
+    code = RANDOM_ACCESS
+
+    def __init__(self, bits, num_copies, num_extra_constants):
+        self.bits, self.num_copies, self.num_extra_constants = bits, num_copies, num_extra_constants
+        self.num_constants = num_extra_constants
+        self.degree = bits + 1
+        self.num_constraints = num_copies * (bits + 2) + num_extra_constants
+        self.num_routed = (2 + (1 << bits)) * num_copies + num_extra_constants
+        self.num_wires = self.num_routed + bits * num_copies
+        self.params = (bits, num_copies, num_extra_constants, 0)
+
+    @staticmethod
+    def new_from_config(cfg, bits):
+        vec = 1 << bits
+        max_copies = min(cfg["num_routed_wires"] // (2 + vec), cfg["num_wires"] // (2 + vec + bits))
+        extra = min(cfg["num_routed_wires"] - (2 + vec) * max_copies, cfg["num_constants"])
+        return RandomAccessGate(bits, max_copies, extra)
+
+    def id(self):
+        return "RandomAccessGate { bits: %d, num_copies: %d, num_extra_constants: %d, _phantom: %s }<D=2>" % (
+            self.bits, self.num_copies, self.num_extra_constants, _PH)
+
+
+class ReducingGate(Gate):
+    code, degree = REDUCING, 2
+
+    def __init__(self, num_coeffs):
+        self.num_coeffs = num_coeffs
+        self.num_constraints = 2 * num_coeffs
+        self.num_wires = 6 + num_coeffs + 2 * (num_coeffs - 1)
+        self.params = (num_coeffs, 0, 0, 0)
+
+    def id(self):
+        return "ReducingGate { num_coeffs: %d }" % self.num_coeffs
+
+
+class ReducingExtensionGate(Gate):
+    code, degree = REDUCING_EXT, 2
+
+    def __init__(self, num_coeffs):
+        self.num_coeffs = num_coeffs
+        self.num_constraints = 2 * num_coeffs
+        self.num_wires = 6 + 2 * num_coeffs + 2 * (num_coeffs - 1)
+        self.params = (num_coeffs, 0, 0, 0)
+
+    def id(self):
+        return "ReducingExtensionGate { num_coeffs: %d }" % self.num_coeffs
+
+
+class ExponentiationGate(Gate):
+    code, degree = EXPONENTIATION, 4
+
+    def __init__(self, num_power_bits):
+        self.num_power_bits = num_power_bits
+        self.num_constraints = num_power_bits + 1
+        self.num_wires = 2 + 2 * num_power_bits
+        self.params = (num_power_bits, 0, 0, 0)
+
+    def id(self):
+        return "ExponentiationGate { num_power_bits: %d, _phantom: %s }<D=2>" % (self.num_power_bits, _PH)
+
+
+class CosetInterpolationGate(Gate):
+    code = COSET_INTERPOLATION
+
+    def __init__(self, subgroup_bits, degree, barycentric_weights):
+        self.subgroup_bits, self.degree, self.weights = subgroup_bits, degree, list(barycentric_weights)
+        n_pts = 1 << subgroup_bits
+        self.num_intermediates = (n_pts - 2) // (degree - 1)
+        self.num_constraints = 4 + 4 * self.num_intermediates
+        self.num_wires = 1 + 2 * n_pts + 4 + 4 * self.num_intermediates + 2
+        self.params = (subgroup_bits, degree, 0, 0)
+        self.extra = tuple(self.weights)
+
+    def id(self):
+        return "CosetInterpolationGate { subgroup_bits: %d, degree: %d, barycentric_weights: [%s], _phantom: %s }<D=2>" % (
+            self.subgroup_bits, self.degree, ", ".join(str(w) for w in self.weights), _PH)
+
+
+class U32ArithmeticGate(Gate):
+    """crypto/plonky2_u32/src/gates/arithmetic_u32.rs:36-94: per op 6 routed wires (m0, m1, addend, lo, hi, inverse)
+    then 32 two-bit limbs per op after all routed wires"""
+    code, degree = U32_ARITHMETIC, 4
+
+    def __init__(self, num_ops):
+        self.num_ops = num_ops
+        self.num_constraints = num_ops * 36
+        self.num_wires = num_ops * 38
+        self.params = (num_ops, 0, 0, 0)
+
+    @staticmethod
+    def new_from_config(cfg):
+        return U32ArithmeticGate(min(cfg["num_wires"] // 38, cfg["num_routed_wires"] // 6))
+
+    def id(self):
+        return "U32ArithmeticGate { num_ops: %d, _phantom: %s }" % (self.num_ops, _PH)
+
+
+_PATTERNS = [
+    (r"^NoopGate", lambda m: NoopGate()),
+    (r"^ConstantGate \{ num_consts: (\d+) \}", lambda m: ConstantGate(int(m[1]))),
+    (r"^PublicInputGate", lambda m: PublicInputGate()),
+    (r"^ArithmeticGate \{ num_ops: (\d+) \}", lambda m: ArithmeticGate(int(m[1]))),
+    (r"^ArithmeticExtensionGate \{ num_ops: (\d+) \}", lambda m: ArithmeticExtensionGate(int(m[1]))),
+    (r"^MulExtensionGate \{ num_ops: (\d+) \}", lambda m: MulExtensionGate(int(m[1]))),
+    (r"^BaseSumGate \{ num_limbs: (\d+) \} \+ Base: (\d+)", lambda m: BaseSumGate(int(m[1]), int(m[2]))),
+    (r"^PoseidonGate", lambda m: PoseidonGate()),
+    (r"^PoseidonMdsGate", lambda m: PoseidonMdsGate()),
+    (r"^RandomAccessGate \{ bits: (\d+), num_copies: (\d+), num_extra_constants: (\d+)",
+     lambda m: RandomAccessGate(int(m[1]), int(m[2]), int(m[3]))),
+    (r"^ReducingGate \{ num_coeffs: (\d+) \}", lambda m: ReducingGate(int(m[1]))),
+    (r"^ReducingExtensionGate \{ num_coeffs: (\d+) \}", lambda m: ReducingExtensionGate(int(m[1]))),
+    (r"^ExponentiationGate \{ num_power_bits: (\d+)", lambda m: ExponentiationGate(int(m[1]))),
+    (r"^CosetInterpolationGate \{ subgroup_bits: (\d+), degree: (\d+), barycentric_weights: \[([0-9, ]+)\]",
+     lambda m: CosetInterpolationGate(int(m[1]), int(m[2]), [int(x) for x in m[3].split(",")])),
+    (r"^U32ArithmeticGate \{ num_ops: (\d+)", lambda m: U32ArithmeticGate(int(m[1]))),
+]
+
+
+def gate_from_id(gid):
+    """Parse a `Gate::id()` string as written to common_data.json (gates.go:27-54 does the same with regexes)."""
+    for rx, mk in _PATTERNS:
+        m = re.match(rx, gid)
+        if m:
+            return mk(m)
+    raise ValueError("unknown gate id: " + gid)
