@@ -431,6 +431,119 @@ class U32ArithmeticGate(Gate):
         return out
 
 
+def _range_product(K, x, base):
+    acc = K.one
+    for k in range(base):
+        acc = K.mul(acc, K.sub(x, K.const(k)))
+    return acc
+
+
+class U32AddManyGate(Gate):
+    """add_many_u32.rs `eval_unfiltered`"""
+    degree = 4
+
+    def __init__(self, num_addends, num_ops):
+        self.na, self.n = num_addends, num_ops
+        self.num_constraints = num_ops * 21
+
+    def eval(self, K, c, w, pih):
+        per, out = self.na + 3, []
+        for i in range(self.n):
+            comp = w[per * i + self.na]
+            for j in range(self.na):
+                comp = K.add(comp, w[per * i + j])
+            res, carry = w[per * i + self.na + 1], w[per * i + self.na + 2]
+            out.append(K.sub(K.add(K.mul(carry, K.const(1 << 32)), res), comp))
+            cr, cc = K.zero, K.zero
+            for j in reversed(range(18)):
+                l = w[per * self.n + 18 * i + j]
+                out.append(_range_product(K, l, 4))
+                if j < 16:
+                    cr = K.add(K.mul(K.const(4), cr), l)
+                else:
+                    cc = K.add(K.mul(K.const(4), cc), l)
+            out.append(K.sub(cr, res))
+            out.append(K.sub(cc, carry))
+        return out
+
+
+class U32SubtractionGate(Gate):
+    """subtraction_u32.rs `eval_unfiltered`"""
+    degree = 4
+
+    def __init__(self, num_ops):
+        self.n = num_ops
+        self.num_constraints = num_ops * 19
+
+    def eval(self, K, c, w, pih):
+        out = []
+        for i in range(self.n):
+            x, y, bin_, res, bout = w[5 * i:5 * i + 5]
+            initial = K.sub(K.sub(x, y), bin_)
+            out.append(K.sub(res, K.add(initial, K.mul(K.const(1 << 32), bout))))
+            comb = K.zero
+            for j in reversed(range(16)):
+                l = w[5 * self.n + 16 * i + j]
+                out.append(_range_product(K, l, 4))
+                comb = K.add(K.mul(K.const(4), comb), l)
+            out.append(K.sub(comb, res))
+            out.append(K.mul(bout, K.sub(K.one, bout)))
+        return out
+
+
+class U32RangeCheckGate(Gate):
+    """range_check_u32.rs `eval_unfiltered`"""
+    degree = 4
+
+    def __init__(self, num_input_limbs):
+        self.n = num_input_limbs
+        self.num_constraints = num_input_limbs * 17
+
+    def eval(self, K, c, w, pih):
+        out = []
+        for i in range(self.n):
+            aux = [w[self.n + 16 * i + j] for j in range(16)]
+            out.append(K.sub(reduce_with_powers(K, aux, K.const(4)), w[i]))
+            for a in aux:
+                out.append(_range_product(K, a, 4))
+        return out
+
+
+class ComparisonGate(Gate):
+    """comparison.rs:106-190 `eval_unfiltered`"""
+
+    def __init__(self, num_bits, num_chunks):
+        self.nb, self.nc = num_bits, num_chunks
+        self.cb = -(-num_bits // num_chunks)
+        self.degree = 1 << self.cb
+        self.num_constraints = 6 + 5 * num_chunks + self.cb
+
+    def eval(self, K, c, w, pih):
+        nc, cb = self.nc, self.cb
+        size = 1 << cb
+        first = [w[4 + i] for i in range(nc)]
+        second = [w[4 + nc + i] for i in range(nc)]
+        out = [K.sub(reduce_with_powers(K, first, K.const(size)), w[0]), K.sub(reduce_with_powers(K, second, K.const(size)), w[1])]
+        msd = K.zero
+        for i in range(nc):
+            out.append(_range_product(K, first[i], size))
+            out.append(_range_product(K, second[i], size))
+            diff = K.sub(second[i], first[i])
+            dummy, eq = w[4 + 2 * nc + i], w[4 + 3 * nc + i]
+            out.append(K.sub(K.mul(diff, dummy), K.sub(K.one, eq)))
+            out.append(K.mul(eq, diff))
+            inter = w[4 + 4 * nc + i]
+            out.append(K.sub(inter, K.mul(eq, msd)))
+            msd = K.add(inter, K.mul(K.sub(K.one, eq), diff))
+        out.append(K.sub(w[3], msd))
+        bits = [w[4 + 5 * nc + i] for i in range(cb + 1)]
+        for b in bits:
+            out.append(K.mul(b, K.sub(K.one, b)))
+        out.append(K.sub(K.add(K.const(size), w[3]), reduce_with_powers(K, bits, K.const(2))))
+        out.append(K.sub(w[2], bits[cb]))
+        return out
+
+
 GATE_PATTERNS = [
     (re.compile(r"^NoopGate"), lambda m: NoopGate()),
     (re.compile(r"^ConstantGate \{ num_consts: (\d+) \}"), lambda m: ConstantGate(int(m[1]))),
@@ -449,6 +562,10 @@ GATE_PATTERNS = [
     (re.compile(r"^CosetInterpolationGate \{ subgroup_bits: (\d+), degree: (\d+), barycentric_weights: \[([0-9, ]+)\]"),
      lambda m: CosetInterpolationGate(int(m[1]), int(m[2]), [int(x) for x in m[3].split(",")])),
     (re.compile(r"^U32ArithmeticGate \{ num_ops: (\d+)"), lambda m: U32ArithmeticGate(int(m[1]))),
+    (re.compile(r"^U32AddManyGate \{ num_addends: (\d+), num_ops: (\d+)"), lambda m: U32AddManyGate(int(m[1]), int(m[2]))),
+    (re.compile(r"^U32SubtractionGate \{ num_ops: (\d+)"), lambda m: U32SubtractionGate(int(m[1]))),
+    (re.compile(r"^U32RangeCheckGate \{ num_input_limbs: (\d+)"), lambda m: U32RangeCheckGate(int(m[1]))),
+    (re.compile(r"^ComparisonGate \{ num_bits: (\d+), num_chunks: (\d+)"), lambda m: ComparisonGate(int(m[1]), int(m[2]))),
 ]
 
 

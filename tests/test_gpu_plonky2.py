@@ -65,3 +65,42 @@ def test_bad_witness_is_rejected(zctx):
     bad[0, 1] ^= 1    # break a copy-constrained cell
     with pytest.raises(zklc_amd.ZklcError):
         prover.prove_bytes(bad, pis)
+
+
+def _synthetic(shape, degree_bits, seed=3, npi=11):
+    from zklc_amd.plonky2 import synthetic as SY, gates as G, standard_recursion_config, wide_ecc_config
+    if shape == "recursion":
+        cfg = standard_recursion_config()
+        mix = SY.recursion_shape_mix(cfg) + [(G.ExponentiationGate(20), 3)]
+    else:
+        cfg = wide_ecc_config()
+        mix = SY.ed25519_shape_mix(cfg)
+    return SY.synthetic_circuit(degree_bits, cfg, mix, num_public_inputs=npi, seed=seed)
+
+
+@pytest.mark.parametrize("shape,hasher", [("recursion", HASH_GL), ("recursion", HASH_BN128), ("ed25519", HASH_GL)])
+def test_all_gate_types_match_oracle_bit_for_bit(zctx, shape, hasher):
+    """every gate type of the two reference circuit shapes (19 in total), 2^6 rows: GPU proof == oracle proof"""
+    data, wires, pis = _synthetic(shape, 6)
+    common = data.common_data()
+    prover = data.prover(zctx, hasher)
+    proof_bytes = prover.prove_bytes(wires, pis)
+    oproof, ovd = OP.prove(common, data.constants, data.sigmas, wires, pis, HASHERS[hasher])
+    assert prover.verifier_data() == ovd
+    assert proof_bytes == S.proof_to_bytes(oproof, common, hasher)
+    V.verify(json.loads(json.dumps(S.proof_from_bytes(proof_bytes, common, hasher))), ovd, common)
+
+
+@pytest.mark.parametrize("shape,degree_bits,hasher", [("recursion", 12, HASH_GL), ("recursion", 12, HASH_BN128), ("ed25519", 13, HASH_GL)])
+def test_reference_sized_proofs_verify(zctx, shape, degree_bits, hasher):
+    """proofs of the reference's recursion shape (2^12 x 135, both hashers) and a 2^13 x 234 slice of the Ed25519 shape are
+    accepted by the verifier restatement (all 28 query rounds, vanishing identity, PoW)"""
+    data, wires, pis = _synthetic(shape, degree_bits, seed=5, npi=16)
+    common = data.common_data()
+    prover = data.prover(zctx, hasher)
+    proof = prover.prove(wires, pis)
+    V.verify(json.loads(json.dumps(proof)), prover.verifier_data(), common)
+    # tampering with one opened wire value must be caught
+    proof["proof"]["openings"]["wires"][7][0] ^= 1
+    with pytest.raises(AssertionError):
+        V.verify(json.loads(json.dumps(proof)), prover.verifier_data(), common)

@@ -260,15 +260,49 @@ class CircuitData:
     """Prover-side circuit: sorted gates, selector groups, constants, sigmas (numpy u64, poly-major) + witness program."""
 
     def __init__(self, b):
-        cfg = self.config = b.config
+        n = len(b.rows)
+        uniq = sorted({g for g, _ in b.rows}, key=lambda g: (g.degree, g.id()))
+        index = {g: i for i, g in enumerate(uniq)}
+        row_gate = np.array([index[g] for g, _ in b.rows], dtype=np.int64)
+        ngc = max(g.num_constants for g in uniq)
+        row_consts = np.zeros((ngc, n), dtype=np.uint64)
+        for r, (_, cs) in enumerate(b.rows):
+            for k, c in enumerate(cs):
+                row_consts[k, r] = c
+        routed = b.config["num_routed_wires"]
+        # sigma: every routed wire maps to the next wire of its copy class (cyclically)
+        classes = {}
+        for k in list(b.parent):
+            if k[0] == "w":
+                classes.setdefault(b._find(k), []).append((k[2], k[1]))   # (col, row)
+        sig_col = np.tile(np.arange(routed, dtype=np.int64)[:, None], (1, n))
+        sig_row = np.tile(np.arange(n, dtype=np.int64)[None, :], (routed, 1))
+        for members in classes.values():
+            members.sort()
+            assert all(c < routed for c, _ in members), "copy constraint on a non-routed wire"
+            for (c0, r0), (c1, r1) in zip(members, members[1:] + members[:1]):
+                sig_col[c0, r0], sig_row[c0, r0] = c1, r1
         self.builder = b
-        n = self.n = len(b.rows)
+        self._init_arrays(b.config, uniq, row_gate, row_consts, sig_col, sig_row, len(b.public_inputs))
+
+    @classmethod
+    def from_arrays(cls, config, gates, row_gate, row_consts, sig_col, sig_row, num_public_inputs):
+        """gates: list sorted by (degree, id); row_gate[n]: index into gates; row_consts[k, n]: gate-local constants;
+        sigma as (column, row) index arrays of shape [routed, n]"""
+        self = cls.__new__(cls)
+        self.builder = None
+        assert gates == sorted(gates, key=lambda g: (g.degree, g.id()))
+        self._init_arrays(config, gates, row_gate, row_consts, sig_col, sig_row, num_public_inputs)
+        return self
+
+    def _init_arrays(self, cfg, uniq, row_gate, row_consts, sig_col, sig_row, num_public_inputs):
+        self.config = cfg
+        n = self.n = len(row_gate)
+        assert n & (n - 1) == 0
         self.degree_bits = n.bit_length() - 1
         qdf = self.quotient_degree_factor = cfg["max_quotient_degree_factor"]
-        # gates sorted by (degree, id); selector groups (plonky2 plonk/circuit_builder.rs + gates/selectors.rs)
-        uniq = sorted({g for g, _ in b.rows}, key=lambda g: (g.degree, g.id()))
+        # selector groups (plonky2 gates/selectors.rs `selector_polynomials`)
         self.gates = uniq
-        index = {g: i for i, g in enumerate(uniq)}
         max_degree = qdf + 1
         if uniq[-1].degree + len(uniq) - 1 <= max_degree:
             groups = [(0, len(uniq))]
@@ -282,18 +316,17 @@ class CircuitData:
                 groups.append((start, start + size))
                 start += size
         self.groups = groups
-        group_of = [next(j for j, (s, e) in enumerate(groups) if s <= i < e) for i in range(len(uniq))]
-        self.selector_indices = group_of
+        group_of = np.array([next(j for j, (s, e) in enumerate(groups) if s <= i < e) for i in range(len(uniq))])
+        self.selector_indices = [int(x) for x in group_of]
         nsel = len(groups)
         ngc = max(g.num_constants for g in uniq)
+        assert row_consts.shape[0] >= ngc
         self.num_constants = nsel + ngc
         consts = np.zeros((self.num_constants, n), dtype=np.uint64)
-        for r, (g, cs) in enumerate(b.rows):
-            i = index[g]
-            for s in range(nsel):
-                consts[s, r] = i if s == group_of[i] else UNUSED_SELECTOR
-            for k, c in enumerate(cs):
-                consts[nsel + k, r] = c
+        row_group = group_of[row_gate]
+        for s_ in range(nsel):
+            consts[s_] = np.where(row_group == s_, row_gate, UNUSED_SELECTOR).astype(np.uint64)
+        consts[nsel:] = row_consts[:ngc]
         self.constants = consts
         self.num_gate_constraints = max(g.num_constraints for g in uniq)
         routed = cfg["num_routed_wires"]
@@ -304,23 +337,20 @@ class CircuitData:
         for i in range(1, n):
             sub[i] = sub[i - 1] * w % P
         self.subgroup = sub
-        # sigma polynomials: every routed wire maps to the next wire of its copy class (cyclically)
-        classes = {}
-        for k in list(b.parent):
-            if k[0] == "w":
-                classes.setdefault(b._find(k), []).append((k[2], k[1]))   # (col, row)
-        sig_col = np.tile(np.arange(routed, dtype=np.int64)[:, None], (1, n))
-        sig_row = np.tile(np.arange(n, dtype=np.int64)[None, :], (routed, 1))
-        for members in classes.values():
-            members.sort()
-            assert all(c < routed for c, _ in members), "copy constraint on a non-routed wire"
-            for (c0, r0), (c1, r1) in zip(members, members[1:] + members[:1]):
-                sig_col[c0, r0], sig_row[c0, r0] = c1, r1
-        k_arr = np.array(self.k_is, dtype=object)
+        # sigma_j(w^i) = k_is[col'] * w^(row'): one field multiplication per cell, done column by column
         sub_arr = np.array(sub, dtype=object)
-        self.sigmas = np.array((k_arr[sig_col] * sub_arr[sig_row]) % P, dtype=np.uint64)
+        sig = np.zeros((routed, n), dtype=np.uint64)
+        ident = np.arange(n, dtype=np.int64)
+        for j in range(routed):
+            cols, rows = sig_col[j], sig_row[j]
+            if np.all(cols == j) and np.array_equal(rows, ident):
+                sig[j] = np.array([self.k_is[j] * x % P for x in sub], dtype=np.uint64)
+            else:
+                k_of = np.array([self.k_is[c] for c in cols], dtype=object)
+                sig[j] = np.array((k_of * sub_arr[rows]) % P, dtype=np.uint64)
+        self.sigmas = sig
         self.fri_arity_bits = fri_reduction_arity_bits(cfg, self.degree_bits)
-        self.num_public_inputs = len(b.public_inputs)
+        self.num_public_inputs = num_public_inputs
 
     def prover(self, ctx, hasher=0):
         """upload + preprocess the circuit on `ctx`'s GPU (zklc_plonky2_circuit_create)"""

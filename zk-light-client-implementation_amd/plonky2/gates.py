@@ -244,6 +244,74 @@ class U32ArithmeticGate(Gate):
         return "U32ArithmeticGate { num_ops: %d, _phantom: %s }" % (self.num_ops, _PH)
 
 
+class U32AddManyGate(Gate):
+    """crypto/plonky2_u32/src/gates/add_many_u32.rs: per op num_addends addends, carry in, result, carry out (routed),
+    then 16 result + 2 carry two-bit limbs per op after all routed wires"""
+    code, degree = U32_ADD_MANY, 4
+
+    def __init__(self, num_addends, num_ops):
+        self.num_addends, self.num_ops = num_addends, num_ops
+        self.num_constraints = num_ops * (3 + 18)
+        self.num_wires = num_ops * (num_addends + 3 + 18)
+        self.params = (num_addends, num_ops, 0, 0)
+
+    @staticmethod
+    def new_from_config(cfg, num_addends):
+        per, routed = num_addends + 3 + 18, num_addends + 3
+        return U32AddManyGate(num_addends, min(cfg["num_wires"] // per, cfg["num_routed_wires"] // routed))
+
+    def id(self):
+        return "U32AddManyGate { num_addends: %d, num_ops: %d, _phantom: %s }" % (self.num_addends, self.num_ops, _PH)
+
+
+class U32SubtractionGate(Gate):
+    """subtraction_u32.rs: per op (x, y, borrow_in, result, borrow_out) routed, then 16 two-bit limbs of the result"""
+    code, degree = U32_SUBTRACTION, 4
+
+    def __init__(self, num_ops):
+        self.num_ops = num_ops
+        self.num_constraints = num_ops * (3 + 16)
+        self.num_wires = num_ops * (5 + 16)
+        self.params = (num_ops, 0, 0, 0)
+
+    @staticmethod
+    def new_from_config(cfg):
+        return U32SubtractionGate(min(cfg["num_wires"] // 21, cfg["num_routed_wires"] // 5))
+
+    def id(self):
+        return "U32SubtractionGate { num_ops: %d, _phantom: %s }" % (self.num_ops, _PH)
+
+
+class U32RangeCheckGate(Gate):
+    """range_check_u32.rs: num_input_limbs inputs, each followed (after all inputs) by 16 two-bit aux limbs"""
+    code, degree = U32_RANGE_CHECK, 4
+
+    def __init__(self, num_input_limbs):
+        self.num_input_limbs = num_input_limbs
+        self.num_constraints = num_input_limbs * 17
+        self.num_wires = num_input_limbs * 17
+        self.params = (num_input_limbs, 0, 0, 0)
+
+    def id(self):
+        return "U32RangeCheckGate { num_input_limbs: %d, _phantom: %s }" % (self.num_input_limbs, _PH)
+
+
+class ComparisonGate(Gate):
+    """comparison.rs:36-80: first <= second on num_bits-bit values split into num_chunks chunks"""
+    code = COMPARISON
+
+    def __init__(self, num_bits, num_chunks):
+        self.num_bits, self.num_chunks = num_bits, num_chunks
+        self.chunk_bits = -(-num_bits // num_chunks)
+        self.degree = 1 << self.chunk_bits
+        self.num_constraints = 6 + 5 * num_chunks + self.chunk_bits
+        self.num_wires = 4 + 5 * num_chunks + self.chunk_bits + 1
+        self.params = (num_bits, num_chunks, 0, 0)
+
+    def id(self):
+        return "ComparisonGate { num_bits: %d, num_chunks: %d, _phantom: %s }<D=2>" % (self.num_bits, self.num_chunks, _PH)
+
+
 _PATTERNS = [
     (r"^NoopGate", lambda m: NoopGate()),
     (r"^ConstantGate \{ num_consts: (\d+) \}", lambda m: ConstantGate(int(m[1]))),
@@ -262,6 +330,10 @@ _PATTERNS = [
     (r"^CosetInterpolationGate \{ subgroup_bits: (\d+), degree: (\d+), barycentric_weights: \[([0-9, ]+)\]",
      lambda m: CosetInterpolationGate(int(m[1]), int(m[2]), [int(x) for x in m[3].split(",")])),
     (r"^U32ArithmeticGate \{ num_ops: (\d+)", lambda m: U32ArithmeticGate(int(m[1]))),
+    (r"^U32AddManyGate \{ num_addends: (\d+), num_ops: (\d+)", lambda m: U32AddManyGate(int(m[1]), int(m[2]))),
+    (r"^U32SubtractionGate \{ num_ops: (\d+)", lambda m: U32SubtractionGate(int(m[1]))),
+    (r"^U32RangeCheckGate \{ num_input_limbs: (\d+)", lambda m: U32RangeCheckGate(int(m[1]))),
+    (r"^ComparisonGate \{ num_bits: (\d+), num_chunks: (\d+)", lambda m: ComparisonGate(int(m[1]), int(m[2]))),
 ]
 
 
