@@ -25,7 +25,11 @@ on one GPU, a bounded CPU sample of the oracle):
            all-gathered over RCCL and added with a unit-scalar MSM (inside the timing)
   lde      Goldilocks coset LDE 234 x (2^17 -> 2^20), bit-reversed output (C3)
   merkle   Poseidon leaf hashing + Merkle tree, 2^20 leaves x 234 columns, cap height 4 (C3)
-`--no-stages` skips them.
+  prove    full plonky2 proofs (zklc_plonky2_prove_dev, witness resident in HBM) of synthetic circuits with the
+           reference's two shapes: Ed25519 circuit 2^17 rows x 234 wires, recursion circuit 2^12 rows x 135 wires, and the
+           Poseidon-BN128 wrap; plus one Block_i signature sub-DAG (100 validators: 100 Ed25519-shape proofs + 100
+           recursion-shape proofs + 1 wrap, signatures.rs:70-139) run back to back -> Block_i proofs/s
+`--no-stages` skips them; `--no-prove` skips only the last one.
 """
 import argparse
 import json
@@ -239,7 +243,59 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
         assert np.array_equal(tree[:4 << cl].cpu().numpy().view(np.uint64).reshape(-1, 4), lv[0]), "GPU leaf digests differ from the oracle"
         res["merkle"]["cpu_baseline"] = {"value": (1 << cl) / dt / 1e6, "unit": "Mleaf/s", "cores": threads, "kind": "port",
                                          "sample": "the first 2^%d leaves (x 234 columns), oracle/c/goldilocks_oracle.c" % cl}
+    if not args.no_prove:
+        del coeffs, lde, tree
+        torch.cuda.empty_cache()
+        res["prove"] = run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max)
     return res
+
+
+def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
+    """plonky2 proofs of synthetic circuits with the reference's shapes (zklc_amd/plonky2/synthetic.py)."""
+    import torch
+    from zklc_amd.plonky2 import synthetic as SY, standard_recursion_config, wide_ecc_config, HASH_GL, HASH_BN128
+    shapes = [("ed25519_2p17x234", 17, wide_ecc_config(), SY.ed25519_shape_mix, HASH_GL, 584),
+              ("recursion_2p12x135", 12, standard_recursion_config(), SY.recursion_shape_mix, HASH_GL, 16),
+              ("wrap_bn128_2p12x135", 12, standard_recursion_config(), SY.recursion_shape_mix, HASH_BN128, 16)]
+    out, provers = {}, {}
+    for name, bits, cfg, mixf, hasher, npi in shapes:
+        data, wires, pis = SY.synthetic_circuit(bits, cfg, mixf(cfg), num_public_inputs=npi, seed=1 + rank)
+        prover = data.prover(ctx, hasher)
+        d_w = torch.from_numpy(wires.view(np.int64)).to(dev)
+        fn = lambda prover=prover, d_w=d_w, pis=pis: prover.prove_dev(d_w.data_ptr(), pis, stream=stream.cuda_stream)
+        fn()
+        barrier()
+        reps = 3 if bits > 14 else 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        ms = reduce_max((time.perf_counter() - t0) / reps * 1e3)
+        tm = prover.last_timings()
+        # algorithmic bytes of one proof = the four committed LDE matrices written once + read once by the Merkle hashing
+        widths = data.num_constants + cfg["num_routed_wires"] + cfg["num_wires"] + 2 * (1 + data.num_partial_products) + 2 * 8
+        out[name] = {"ms_per_proof": ms, "proofs_per_s": world * 1e3 / ms, "proof_bytes": prover.proof_bytes,
+                     "rows": 1 << bits, "wires": cfg["num_wires"], "committed_polys": widths,
+                     "stages_ms": {k: round(v, 3) for k, v in tm.items()}}
+        provers[name] = (fn, prover)
+    # one Block_i signature sub-DAG at 100 validators, back to back on this GPU
+    t0 = time.perf_counter()
+    for _ in range(VALIDATORS):
+        provers["ed25519_2p17x234"][0]()
+        provers["recursion_2p12x135"][0]()
+    provers["wrap_bn128_2p12x135"][0]()
+    barrier()
+    block_s = reduce_max(time.perf_counter() - t0)
+    out["block_i"] = {"metric": "Block_i signature sub-DAG proofs/s (100 validators: 100 Ed25519-shape + 100 recursion-shape proofs "
+                                "+ 1 BN128 wrap, sequential on one GPU; every rank proves its own block)",
+                      "value": world / block_s, "unit": "proofs/s", "seconds_per_block": block_s,
+                      "cpu_baseline": None,
+                      "note": "synthetic circuits of the reference's shapes and gate types (the Rust circuit builders are not "
+                              "rebuilt); witness generation (SURVEY 8a row a5) is outside the timed region; the reference CPU "
+                              "prover cannot be built here (no Rust toolchain) and publishes no time for this step"}
+    for _, prover in provers.values():
+        prover.close()
+    return out
 
 
 def main():
@@ -251,6 +307,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stages", action="store_true", help="only the headline C2 measurement")
     ap.add_argument("--msm-log", type=int, default=22, help="log2 of the MSM size per GPU")
+    ap.add_argument("--no-prove", action="store_true", help="skip the plonky2 proof stage")
     args = ap.parse_args()
 
     import torch
