@@ -30,7 +30,15 @@ def trim(name, pj, vj, cj):
     print(name, os.path.getsize(path))
 
 
+def copy_bin():
+    """proof.bin of the same golden proof (ProofWithPublicInputs::to_bytes, prove_block.rs:320-458): pins the binary format"""
+    import shutil
+    d = "near_bft_finality/proofs/random/CGZPhFRkL3NvmGaXWBc6N7qJD519EUe6vyNpaEyDe2Ev/"
+    shutil.copy(os.path.join(REF, d, "proof.bin"), os.path.join(OUT, "plonky2_near_random_CGZP_proof.bin"))
+
+
 if __name__ == "__main__":
+    copy_bin()
     d = "near_bft_finality/proofs/random/CGZPhFRkL3NvmGaXWBc6N7qJD519EUe6vyNpaEyDe2Ev/"
     trim("near_random_CGZP", d + "proof.json", d + "verifier_data.json", d + "common_data.json")
     t = "gnark-plonky2-verifier/testdata/test_circuit/"

@@ -61,10 +61,18 @@ def test_proof_matches_oracle_bit_for_bit(zctx, hasher, extra):
 def test_bad_witness_is_rejected(zctx):
     data, wires, pis = small_circuit()
     prover = data.prover(zctx, HASH_GL)
+    from zklc_amd.plonky2 import gates as G
+    row = next(r for r, (g, _) in enumerate(data.builder.rows) if isinstance(g, G.ArithmeticGate))
     bad = wires.copy()
-    bad[0, 1] ^= 1    # break a copy-constrained cell
+    bad[3, row] ^= 1      # a copy-constrained output: the permutation product does not close -> ZKLC_ERR_INVALID_ARG
     with pytest.raises(zklc_amd.ZklcError):
         prover.prove_bytes(bad, pis)
+    bad = wires.copy()
+    bad[79, row] ^= 1     # only a gate constraint breaks: a proof comes out (as with plonky2) and the verifier rejects it
+    proof = prover.prove(bad, pis)
+    with pytest.raises(AssertionError, match="vanishing"):
+        V.verify(json.loads(json.dumps(proof)), prover.verifier_data(), data.common_data())
+    V.verify(json.loads(json.dumps(prover.prove(wires, pis))), prover.verifier_data(), data.common_data())
 
 
 def _synthetic(shape, degree_bits, seed=3, npi=11):

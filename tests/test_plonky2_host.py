@@ -1,0 +1,135 @@
+"""Host side of the plonky2 path without a GPU: proof serialisation pinned by the reference's golden proof.bin / proof.json
+pair, the circuit builder + prover restatement + verifier restatement chain on small circuits (both hash configurations),
+synthetic circuits of both reference shapes (every gate type), and rejection of bad witnesses / tampered proofs."""
+import copy
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, GOLDEN
+import zklc_amd
+from zklc_amd.plonky2 import CircuitBuilder, serialization as S, synthetic as SY, gates as G, standard_recursion_config, wide_ecc_config
+from zklc_amd.plonky2 import poseidon_gate_rows
+from oracle import plonky2_prover as OP, plonky2_verifier as V, poseidon_gl as pgl, plonky2_gates as OG
+
+
+def test_proof_bin_format_is_pinned_by_the_golden_pair():
+    j = load_golden("plonky2_near_random_CGZP.json")
+    raw = open(os.path.join(GOLDEN, "plonky2_near_random_CGZP_proof.bin"), "rb").read()
+    common = j["common_data"]
+    assert len(raw) == 127968 == S.proof_size(common, S.HASH_BN128)
+    pj = S.proof_from_bytes(raw, common, S.HASH_BN128)
+    gold = j["proof"]
+    assert pj["public_inputs"] == gold["public_inputs"]
+    for k in ["wires_cap", "plonk_zs_partial_products_cap", "quotient_polys_cap", "openings"]:
+        assert pj["proof"][k] == gold["proof"][k], k
+    gop, pop = gold["proof"]["opening_proof"], pj["proof"]["opening_proof"]
+    assert pop["commit_phase_merkle_caps"] == gop["commit_phase_merkle_caps"] and pop["final_poly"] == gop["final_poly"]
+    assert pop["pow_witness"] == gop["pow_witness"]
+    kept = j["kept_query_rounds"]
+    assert pop["query_round_proofs"][:kept] == gop["query_round_proofs"]
+    assert S.proof_to_bytes(pj, common, S.HASH_BN128) == raw
+    # and the parsed binary verifies (all 28 rounds)
+    V.verify(pj, j["verifier_data"], common)
+
+
+def test_poseidon_gate_rows_match_the_permutation_and_the_gate_constraints():
+    rng = np.random.default_rng(3)
+    ins = rng.integers(0, pgl.P, (5, 12), dtype=np.uint64)
+    swap = np.array([0, 1, 0, 1, 1], dtype=np.uint64)
+    rows = poseidon_gate_rows(ins, swap)
+    gate = OG.PoseidonGate()
+    for k in range(5):
+        st = [int(x) for x in ins[k]]
+        if swap[k]:
+            st = st[4:8] + st[:4] + st[8:]
+        assert [int(x) for x in rows[k][12:24]] == pgl.permute(st)
+        assert all(c == 0 for c in gate.eval(OG.BaseK, [], [int(x) for x in rows[k]], [0] * 4))
+
+
+def _small():
+    b = CircuitBuilder()
+    x = b.add_virtual_public_input()
+    y = b.add_virtual_target()
+    z = b.mul(x, y)
+    w = b.add(z, b.constant(5))
+    b.split_le(x, 10)
+    lo, hi = b.mul_add_u32(x, y, b.constant(77))
+    b.connect(b.sub(w, z), b.constant(5))
+    b.register_public_input(lo)
+    b.register_public_input(hi)
+    data = b.build()
+    wires, pis = data.generate_witness({x: 1000, y: 4000000000})
+    return data, wires, pis
+
+
+@pytest.mark.parametrize("H,hasher", [(V.HasherGL, S.HASH_GL), (V.HasherBN128, S.HASH_BN128)])
+def test_builder_prover_verifier_chain(H, hasher):
+    data, wires, pis = _small()
+    assert pis == [1000, (1000 * 4000000000 + 77) & 0xFFFFFFFF, (1000 * 4000000000 + 77) >> 32]
+    common = data.common_data()
+    proof, vd = OP.prove(common, data.constants, data.sigmas, wires, pis, H)
+    V.verify(json.loads(json.dumps(proof)), vd, common)
+    raw = S.proof_to_bytes(proof, common, hasher)
+    assert len(raw) == S.proof_size(common, hasher)
+    assert json.loads(json.dumps(S.proof_from_bytes(raw, common, hasher))) == json.loads(json.dumps(proof))
+    bad = copy.deepcopy(proof)
+    bad["public_inputs"][1] ^= 1
+    with pytest.raises(AssertionError):
+        V.verify(json.loads(json.dumps(bad)), vd, common)
+
+
+def test_unsatisfied_witness_is_rejected_by_the_prover_restatement():
+    data, wires, pis = _small()
+    row = next(r for r, (g, _) in enumerate(data.builder.rows) if isinstance(g, G.ArithmeticGate))
+    common = data.common_data()
+    bad = wires.copy()
+    bad[3, row] ^= 1      # a copy-constrained output: the permutation product does not close, the prover refuses
+    with pytest.raises(AssertionError):
+        OP.prove(common, data.constants, data.sigmas, bad, pis, V.HasherGL)
+    bad = wires.copy()
+    bad[79, row] ^= 1     # the free output of an unused op: only a gate constraint breaks -> like plonky2, the prover still
+    proof, vd = OP.prove(common, data.constants, data.sigmas, bad, pis, V.HasherGL)   # emits a proof, the verifier rejects it
+    with pytest.raises(AssertionError, match="vanishing"):
+        V.verify(json.loads(json.dumps(proof)), vd, common)
+
+
+@pytest.mark.parametrize("shape", ["recursion", "ed25519"])
+def test_synthetic_reference_shapes_prove_and_verify(shape):
+    if shape == "recursion":
+        cfg = standard_recursion_config()
+        mix = SY.recursion_shape_mix(cfg) + [(G.ExponentiationGate(20), 3)]
+    else:
+        cfg = wide_ecc_config()
+        mix = SY.ed25519_shape_mix(cfg)
+    data, wires, pis = SY.synthetic_circuit(6, cfg, mix, num_public_inputs=11, seed=7)
+    common = data.common_data()
+    assert len(common["gates"]) == len(mix) + 3 - (1 if shape == "recursion" else 0)   # + Noop, PublicInput (+ Poseidon)
+    # every row satisfies its gate (evaluated with the oracle, on the subgroup)
+    gates = [OG.gate_from_id(g) for g in common["gates"]]
+    nsel = len(common["selectors_info"]["groups"])
+    pih = pgl.hash_no_pad(pis)
+    for r in range(data.n):
+        consts = [int(x) for x in data.constants[:, r]]
+        cs = OG.evaluate_gate_constraints(OG.BaseK, gates, common["selectors_info"], common["num_gate_constraints"], consts,
+                                          [int(x) for x in wires[:, r]], pih)
+        assert not any(cs), "row %d" % r
+    proof, vd = OP.prove(common, data.constants, data.sigmas, wires, pis, V.HasherGL)
+    V.verify(json.loads(json.dumps(proof)), vd, common)
+
+
+def test_selector_groups_reproduce_the_reference_common_data():
+    """the gate order and selector groups computed by the builder equal those of the reference's golden common_data"""
+    j = load_golden("plonky2_near_random_CGZP.json")["common_data"]
+    cfg = standard_recursion_config()
+    data, _, _ = SY.synthetic_circuit(6, cfg, SY.recursion_shape_mix(cfg), num_public_inputs=16, seed=1)
+    c = data.common_data()
+    assert c["gates"] == j["gates"]
+    assert c["selectors_info"] == j["selectors_info"]
+    for k in ["num_constants", "num_partial_products", "quotient_degree_factor", "num_gate_constraints", "k_is", "config"]:
+        assert c[k] == j[k], k
+    from zklc_amd.plonky2.builder import fri_reduction_arity_bits
+    assert fri_reduction_arity_bits(cfg, 12) == j["fri_params"]["reduction_arity_bits"] == [4, 4]
+    assert fri_reduction_arity_bits(cfg, 17) == [4, 4, 4]

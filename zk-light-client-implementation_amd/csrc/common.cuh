@@ -13,9 +13,11 @@
 #include <hip/hip_runtime.h>
 #define ZKLC_HD __device__ __forceinline__
 #define ZKLC_D __device__ __forceinline__
+#define ZKLC_M __device__ __forceinline__   /* member functions */
 #else
 #define ZKLC_HD static inline __attribute__((always_inline))
 #define ZKLC_D static inline
+#define ZKLC_M inline
 #endif
 
 typedef uint32_t u32;

@@ -37,7 +37,7 @@ struct p2_gate {
 struct p2_consumer {
     u64 alpha[P2_MAX_CH], apow[P2_MAX_CH], acc[P2_MAX_CH];
     int nch;
-    ZKLC_D void emit(u64 c) {
+    ZKLC_M void emit(u64 c) {
 #pragma unroll
         for (int k = 0; k < P2_MAX_CH; k++)
             if (k < nch) {
@@ -45,7 +45,7 @@ struct p2_consumer {
                 apow[k] = gl_mul(apow[k], alpha[k]);
             }
     }
-    ZKLC_D void emit2(gl2 c) {
+    ZKLC_M void emit2(gl2 c) {
         emit(c.a);
         emit(c.b);
     }
@@ -57,10 +57,10 @@ struct p2_vars {
     size_t stride, p;
     u32 nsel;
     u64 pih[4];
-    ZKLC_D u64 w(u32 j) const { return wires[(size_t)j * stride + p]; }
-    ZKLC_D u64 c(u32 j) const { return consts[(size_t)(nsel + j) * stride + p]; }
-    ZKLC_D u64 sel(u32 j) const { return consts[(size_t)j * stride + p]; }
-    ZKLC_D gl2 wa(u32 j) const { return gl2_make(w(j), w(j + 1)); }
+    ZKLC_M u64 w(u32 j) const { return wires[(size_t)j * stride + p]; }
+    ZKLC_M u64 c(u32 j) const { return consts[(size_t)(nsel + j) * stride + p]; }
+    ZKLC_M u64 sel(u32 j) const { return consts[(size_t)j * stride + p]; }
+    ZKLC_M gl2 wa(u32 j) const { return gl2_make(w(j), w(j + 1)); }
 };
 
 // prod_{k < base} (x - k)
