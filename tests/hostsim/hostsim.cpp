@@ -83,8 +83,18 @@ u64 hostsim_gl_op(int op, u64 a, u64 b) {
         case 3: return gl_inv(a);
         case 4: return gl_reduce128(a, b);
         case 5: return gl_root_of_unity((u32)a);
+        case 6: return gl_reduce128_loose(a, b);
+        case 7: return gl_add_lc(a, b);
+        case 8: return gl_mul_loose(a, b);
+        case 9: return gl_canonical(a);
         default: return 0;
     }
+}
+// sum_i x[i] * y[i] through the 160-bit accumulator
+u64 hostsim_gl_acc(const u64 *x, const u64 *y, u32 n) {
+    gl_acc160 acc = {0, 0, 0};
+    for (u32 i = 0; i < n; i++) gl_acc_mul(acc, x[i], y[i]);
+    return gl_acc_reduce(acc);
 }
 void hostsim_poseidon_gl_permute(u64 *s) { poseidon_gl_permute(s); }
 void hostsim_poseidon_gl_hash(const u64 *in, u32 len, u64 *out4) { poseidon_gl_hash_or_noop(in, 1, len, out4); }

@@ -57,3 +57,32 @@ def test_poseidon_permutation_and_sponge(hostsim):
     o = (ctypes.c_uint64 * 4)()
     hostsim.hostsim_poseidon_gl_two_to_one((ctypes.c_uint64 * 4)(*l), (ctypes.c_uint64 * 4)(*r), o)
     assert list(o) == pg.two_to_one(l, r)
+
+
+def test_loose_arithmetic_edges(hostsim):
+    """the non-canonical ("loose") helpers of the Poseidon permutation on their worst-case inputs: values in [p, 2^64)"""
+    import numpy as np
+    op = _gl(hostsim)
+    rng = random.Random(11)
+    M = 2**64
+    loose = [M - 1, M - 2, P, P + 1, P - 1, 0, 1, 2**32 - 1, 2**32, M - 2**32, M - 2**32 + 1] + [rng.randrange(P, M) for _ in range(50)]
+    canon = [0, 1, P - 1, P - 2, 2**32, 2**63] + [rng.randrange(P) for _ in range(50)]
+    for a in loose:
+        assert op(9, a, 0) == a % P
+        for b in canon:
+            r = op(7, a, b)
+            assert r % P == (a + b) % P and 0 <= r < M
+        for b in loose[:12] + canon[:12]:
+            r = op(8, a, b)
+            assert r % P == a * b % P
+    for lo, hi in [(M - 1, M - 1), (0, M - 1), (M - 1, 0), (0, 0xFFFFFFFF), (0, 0xFFFFFFFF00000000), (P - 1, P - 1), (0, 0xFFFFFFFF00000001)] + \
+            [(rng.getrandbits(64), rng.getrandbits(64)) for _ in range(2000)]:
+        assert op(6, lo, hi) % P == ((hi << 64) | lo) % P
+    hostsim.hostsim_gl_acc.restype = ctypes.c_uint64
+    hostsim.hostsim_gl_acc.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+    for n in [1, 2, 12, 13, 200]:
+        for vals in ([M - 1] * n, [rng.randrange(P, M) for _ in range(n)], [rng.randrange(M) for _ in range(n)]):
+            x = np.array(vals, dtype=np.uint64)
+            y = np.array([M - 1 if k % 2 else P - 1 for k in range(n)], dtype=np.uint64)
+            want = sum(int(a) * int(b) for a, b in zip(x, y)) % P
+            assert hostsim.hostsim_gl_acc(x.ctypes.data, y.ctypes.data, n) == want

@@ -40,6 +40,24 @@ ZKLC_HD u64 gl_reduce128(u64 lo, u64 hi) {
     return r >= GL_P ? r - GL_P : r;
 }
 
+// "Loose" arithmetic: values are any u64 congruent to the field element (not necessarily < p).  Products and reduce128
+// accept loose inputs; only additions need care.  Used inside the Poseidon permutation, canonicalised on the way out.
+ZKLC_HD u64 gl_reduce128_loose(u64 lo, u64 hi) {
+    u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+    u64 t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= GL_EPS;
+    u64 t1 = hi_lo * GL_EPS;
+    u64 r = t0 + t1;
+    if (r < t1) r += GL_EPS;  // cannot carry again (see gl_reduce128)
+    return r;
+}
+// loose + canonical -> loose (a single wrap is possible: a < 2^64, b < p => a + b - 2^64 + EPS < 2^64)
+ZKLC_HD u64 gl_add_lc(u64 a_loose, u64 b_canonical) {
+    u64 s = a_loose + b_canonical;
+    return s + ((s < a_loose) ? GL_EPS : 0);
+}
+ZKLC_HD u64 gl_canonical(u64 a) { return a >= GL_P ? a - GL_P : a; }
+
 ZKLC_HD void gl_mul_wide(u64 a, u64 b, u64 &lo, u64 &hi) {
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     u64 p00 = (u64)a0 * b0;
@@ -56,6 +74,34 @@ ZKLC_HD u64 gl_mul(u64 a, u64 b) {
     return gl_reduce128(lo, hi);
 }
 ZKLC_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
+ZKLC_HD u64 gl_mul_loose(u64 a, u64 b) {
+    u64 lo, hi;
+    gl_mul_wide(a, b, lo, hi);
+    return gl_reduce128_loose(lo, hi);
+}
+// 160-bit accumulator for sums of 128-bit products (lo, hi, number of 2^128 overflows)
+struct gl_acc160 {
+    u64 lo, hi;
+    u32 over;
+};
+ZKLC_HD void gl_acc_mul(gl_acc160 &a, u64 x, u64 y) {
+    u64 plo, phi;
+    gl_mul_wide(x, y, plo, phi);
+    u64 lo = a.lo + plo;
+    u64 c = lo < plo;
+    u64 hi = a.hi + phi;
+    u32 o = hi < phi;
+    hi += c;
+    o += hi < c;
+    a.lo = lo;
+    a.hi = hi;
+    a.over += o;
+}
+// 2^128 = 2^96 * 2^32 = -2^32 (mod p)
+ZKLC_HD u64 gl_acc_reduce(const gl_acc160 &a) {
+    u64 r = gl_reduce128(a.lo, a.hi);
+    return gl_sub(r, (u64)a.over << 32);
+}
 
 ZKLC_HD u64 gl_pow(u64 a, u64 e) {
     u64 r = 1;

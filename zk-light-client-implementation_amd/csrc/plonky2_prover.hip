@@ -924,7 +924,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
         a.n_in = ch.n_in;
         a.pow_bits = P.proof_of_work_bits;
         a.found = c->d_found;
-        const u64 batch = 1ULL << 20;
+        const u64 batch = 1ULL << (P.proof_of_work_bits + 2 < 24 ? P.proof_of_work_bits + 2 : 24);  // ~98 % hit rate per launch
         unsigned long long found = ~0ULL;
         for (u64 base = 0;; base += batch) {
             ZKLC_HIP(ctx, hipMemsetAsync(c->d_found, 0xFF, 8, st));

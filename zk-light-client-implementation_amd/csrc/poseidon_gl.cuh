@@ -58,49 +58,99 @@ ZKLC_HD void pgl_full_round(u64 *s, int rnd) {
     pgl_mds(s);
 }
 
+// ---- the permutation proper works on LOOSE values (any u64 congruent to the element; goldilocks.cuh) and makes its
+// output canonical at the end: 5 instructions fewer per multiplication, and the sums of products of the partial
+// rounds are accumulated in 160 bits and reduced once (plonky2 does the same on the CPU with u128 sums).
+ZKLC_HD u64 pgl_sbox_l(u64 x) {
+    u64 x2 = gl_mul_loose(x, x);
+    u64 x3 = gl_mul_loose(x2, x);
+    u64 x4 = gl_mul_loose(x2, x2);
+    return gl_mul_loose(x3, x4);
+}
+ZKLC_HD void pgl_mds_l(u64 *s) {
+    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        lo[i] = (u32)s[i];
+        hi[i] = (u32)(s[i] >> 32);
+    }
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        u64 sl = 0, sh = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            sl += (u64)lo[(i + r) % 12] * C[i];
+            sh += (u64)hi[(i + r) % 12] * C[i];
+        }
+        if (r == 0) {
+            sl += (u64)lo[0] * 8;
+            sh += (u64)hi[0] * 8;
+        }
+        u64 l = sl + (sh << 32);
+        u64 h = (sh >> 32) + (l < sl);
+        s[r] = gl_reduce128_loose(l, h);
+    }
+}
+ZKLC_HD void pgl_full_round_l(u64 *s, int rnd) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = pgl_sbox_l(gl_add_lc(s[i], PGL_RC[12 * rnd + i]));
+    pgl_mds_l(s);
+}
+
 ZKLC_HD void poseidon_gl_permute(u64 *s) {
 #if defined(__HIPCC__)
 #pragma unroll 1
 #endif
-    for (int r = 0; r < 4; r++) pgl_full_round(s, r);
+    for (int r = 0; r < 4; r++) pgl_full_round_l(s, r);
     // partial rounds in the "fast" form (goldilocks.go:102-115, :231-331)
 #pragma unroll
-    for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PGL_FP_FIRST[i]);
+    for (int i = 0; i < 12; i++) s[i] = gl_add_lc(s[i], PGL_FP_FIRST[i]);
     {
+        // t[d] = sum_{r=1..11} s[r] * INIT[r-1][d-1]; one output per iteration, rotated into place (static register indices)
         u64 t[12];
-        t[0] = s[0];
 #pragma unroll
         for (int d = 1; d < 12; d++) t[d] = 0;
 #if defined(__HIPCC__)
 #pragma unroll 1
 #endif
-        for (int r = 1; r < 12; r++) {
-            u64 sr = s[1];
+        for (int d = 1; d < 12; d++) {
+            gl_acc160 acc = {0, 0, 0};
 #pragma unroll
-            for (int d = 1; d < 12; d++) t[d] = gl_add(t[d], gl_mul(sr, PGL_FP_INIT[(r - 1) * 11 + d - 1]));
-            // rotate s[1..11] so the loop body always reads s[1] (keeps register indexing static)
+            for (int r = 1; r < 12; r++) gl_acc_mul(acc, s[r], PGL_FP_INIT[(r - 1) * 11 + d - 1]);
 #pragma unroll
-            for (int q = 1; q < 11; q++) s[q] = s[q + 1];
+            for (int q = 1; q < 11; q++) t[q] = t[q + 1];
+            t[11] = gl_acc_reduce(acc);
         }
 #pragma unroll
-        for (int i = 0; i < 12; i++) s[i] = t[i];
+        for (int i = 1; i < 12; i++) s[i] = t[i];
     }
 #if defined(__HIPCC__)
 #pragma unroll 1
 #endif
     for (int i = 0; i < 22; i++) {
-        u64 s0 = gl_add(pgl_sbox(s[0]), PGL_FP_RC[i]);
-        u64 d = gl_mul(s0, 25);  // MDS0TO0
+        u64 s0 = gl_add_lc(pgl_sbox_l(s[0]), PGL_FP_RC[i]);
+        gl_acc160 acc = {0, 0, 0};
+        gl_acc_mul(acc, s0, 25);  // MDS0TO0
 #pragma unroll
-        for (int j = 1; j < 12; j++) d = gl_add(d, gl_mul(s[j], PGL_FP_WHATS[i * 11 + j - 1]));
+        for (int j = 1; j < 12; j++) gl_acc_mul(acc, s[j], PGL_FP_WHATS[i * 11 + j - 1]);
 #pragma unroll
-        for (int j = 1; j < 12; j++) s[j] = gl_add(s[j], gl_mul(s0, PGL_FP_VS[i * 11 + j - 1]));
-        s[0] = d;
+        for (int j = 1; j < 12; j++) {
+            // s[j] + s0 * v < 2^128: one reduction of the sum
+            u64 lo, hi;
+            gl_mul_wide(s0, PGL_FP_VS[i * 11 + j - 1], lo, hi);
+            u64 l2 = lo + s[j];
+            hi += (l2 < lo);
+            s[j] = gl_reduce128_loose(l2, hi);
+        }
+        s[0] = gl_acc_reduce(acc);
     }
 #if defined(__HIPCC__)
 #pragma unroll 1
 #endif
-    for (int r = 0; r < 4; r++) pgl_full_round(s, 26 + r);
+    for (int r = 0; r < 4; r++) pgl_full_round_l(s, 26 + r);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_canonical(s[i]);
 }
 
 // hash_or_noop / hash_no_pad of `len` elements read through a strided accessor:
