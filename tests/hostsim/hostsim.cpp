@@ -158,15 +158,20 @@ void hostsim_p2_eval_gate(u32 type, const u32 *params, const u64 *extra, const u
     v.p = 0;
     v.nsel = 0;
     for (int k = 0; k < 4; k++) v.pih[k] = pih[k];
+    static u64 tab[P2_MAX_CH][1024];
     p2_consumer out;
     out.nch = (int)nch;
     for (int c = 0; c < P2_MAX_CH; c++) {
-        out.alpha[c] = c < (int)nch ? alpha[c] : 0;
-        out.apow[c] = 1;
-        out.acc[c] = 0;
+        u64 a = c < (int)nch ? alpha[c] : 0, pw = 1;
+        for (int i = 0; i < 1024; i++) {
+            tab[c][i] = pw;
+            pw = gl_mul(pw, a);
+        }
+        out.apow[c] = tab[c];
     }
+    out.reset(0);
     p2_eval_gate(g, v, extra, out);
-    for (u32 c = 0; c < nch; c++) acc_out[c] = out.acc[c];
+    for (u32 c = 0; c < nch; c++) acc_out[c] = out.result((int)c);
     (void)n_wires;
     (void)n_consts;
 }

@@ -34,17 +34,28 @@ struct p2_gate {
     u32 extra_off;  // offset (u64 words) into the circuit's gate_extra table
 };
 
+// sum_i alpha_c^(k0 + i) * constraint_i with the powers of alpha read from a table (wave-uniform index -> scalar loads)
+// and the products accumulated unreduced in 160 bits: 2 wide multiplications per constraint instead of 4 modular ones.
 struct p2_consumer {
-    u64 alpha[P2_MAX_CH], apow[P2_MAX_CH], acc[P2_MAX_CH];
+    const u64 *apow[P2_MAX_CH];   // apow[c][k] = alpha_c^k
+    gl_acc160 acc[P2_MAX_CH];
+    u32 k;
     int nch;
-    ZKLC_M void emit(u64 c) {
+    ZKLC_M void reset(u32 k0) {
+        k = k0;
 #pragma unroll
-        for (int k = 0; k < P2_MAX_CH; k++)
-            if (k < nch) {
-                acc[k] = gl_add(acc[k], gl_mul(c, apow[k]));
-                apow[k] = gl_mul(apow[k], alpha[k]);
-            }
+        for (int c = 0; c < P2_MAX_CH; c++) {
+            acc[c].lo = acc[c].hi = 0;
+            acc[c].over = 0;
+        }
     }
+    ZKLC_M void emit(u64 v) {
+#pragma unroll
+        for (int c = 0; c < P2_MAX_CH; c++)
+            if (c < nch) gl_acc_mul(acc[c], v, apow[c][k]);
+        k++;
+    }
+    ZKLC_M u64 result(int c) const { return gl_acc_reduce(acc[c]); }
     ZKLC_M void emit2(gl2 c) {
         emit(c.a);
         emit(c.b);

@@ -158,33 +158,34 @@ struct p2_quotient_args {
     const u64 *extra, *k_is;
     u32 lde_bits, degree_bits, rate_bits, num_constants, nsel, routed, nch, npp, qdf, num_gates;
     u64 w_lde;                      // primitive 2^lde_bits-th root of unity
-    u64 zh_inv[16];                 // 1 / (x^n - 1) for the 2^rate_bits cosets of <w_n> inside g<w_N>
+    u64 zh_inv[16], zh[16];         // 1 / (x^n - 1) and x^n - 1 for the 2^rate_bits cosets of <w_n> inside g<w_N>
     u64 n_field;                    // n as a field element
     u64 pih[4];
     p2_challenges ch;
+    const u64 *apow[P2_MAX_CH];     // powers of the alphas, one table per challenge
     u64 *out;                       // [nch][N]
 };
 
-// vanishing_poly.rs `eval_vanishing_poly_base_batch` at the point stored at position p, divided by Z_H
-__global__ void __launch_bounds__(P2_THREADS) p2_quotient_kernel(p2_quotient_args a) {
+// vanishing_poly.rs `eval_vanishing_poly_base_batch` at the point stored at position p, divided by Z_H.
+// The sum over the vanishing terms is split over launches so that each has a small register footprint (the all-in-one
+// kernel needed 221 VGPRs = 2 waves/SIMD): p2_quotient_base_kernel writes the L_0 and partial-product terms,
+// p2_quotient_gate_kernel<TYPE> adds filter_g * sum_i alpha^(k_gates + i) c_{g,i} for one gate of the list.
+__global__ void __launch_bounds__(P2_THREADS) p2_quotient_base_kernel(p2_quotient_args a) {
     const size_t N = (size_t)1 << a.lde_bits;
     size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     u64 i = __brevll((u64)p) >> (64 - a.lde_bits);  // natural index on the coset
     u64 x = gl_mul(GL_GENERATOR, gl_pow(a.w_lde, i));
-    u64 zh_inv = a.zh_inv[i & ((1u << a.rate_bits) - 1)];
+    const u32 coset = (u32)i & ((1u << a.rate_bits) - 1);
     // L_0(x) = (x^n - 1) / (n (x - 1))
-    u64 l0 = gl_mul(gl_inv(zh_inv), gl_inv(gl_mul(a.n_field, gl_sub(x, 1))));
+    u64 l0 = gl_mul(a.zh[coset], gl_inv(gl_mul(a.n_field, gl_sub(x, 1))));
     u64 i_next = (i + (1ULL << a.rate_bits)) & (N - 1);
     size_t p_next = (size_t)(__brevll(i_next) >> (64 - a.lde_bits));
 
     p2_consumer out;
     out.nch = a.nch;
-    for (int c = 0; c < P2_MAX_CH; c++) {
-        out.alpha[c] = a.ch.alpha[c];
-        out.apow[c] = 1;
-        out.acc[c] = 0;
-    }
+    for (int c = 0; c < P2_MAX_CH; c++) out.apow[c] = a.apow[c];
+    out.reset(0);
     // L_0(x) (Z(x) - 1)
     for (u32 c = 0; c < a.nch; c++) out.emit(gl_mul(l0, gl_sub(a.zs[(size_t)c * N + p], 1)));
     // partial products (plonk.go:84-119)
@@ -205,7 +206,17 @@ __global__ void __launch_bounds__(P2_THREADS) p2_quotient_kernel(p2_quotient_arg
             prev = next;
         }
     }
-    // gate constraints, filtered (evaluate_gates.go:59-105)
+    for (u32 c = 0; c < a.nch; c++) a.out[(size_t)c * N + p] = gl_mul(out.result(c), a.zh_inv[coset]);
+}
+
+// gate constraints, filtered (evaluate_gates.go:59-105); TYPE is a compile-time constant so only that evaluator is inlined
+template <int TYPE>
+__global__ void __launch_bounds__(P2_THREADS) p2_quotient_gate_kernel(p2_quotient_args a, u32 g) {
+    const size_t N = (size_t)1 << a.lde_bits;
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    u64 i = __brevll((u64)p) >> (64 - a.lde_bits);
+    const u32 coset = (u32)i & ((1u << a.rate_bits) - 1);
     p2_vars v;
     v.wires = a.wires;
     v.consts = a.cs;
@@ -213,22 +224,31 @@ __global__ void __launch_bounds__(P2_THREADS) p2_quotient_kernel(p2_quotient_arg
     v.p = p;
     v.nsel = a.nsel;
     for (int k = 0; k < 4; k++) v.pih[k] = a.pih[k];
-    u64 base_pow[P2_MAX_CH], total[P2_MAX_CH];
-    for (int c = 0; c < P2_MAX_CH; c++) {
-        base_pow[c] = out.apow[c];
-        total[c] = out.acc[c];
+    p2_gate gate = a.gates[g];
+    gate.type = TYPE;
+    p2_consumer out;
+    out.nch = a.nch;
+    for (int c = 0; c < P2_MAX_CH; c++) out.apow[c] = a.apow[c];
+    out.reset(a.nch + a.nch * (a.npp + 1));   // the gate constraints follow the Z1 and partial-product terms
+    p2_eval_gate(gate, v, a.extra, out);
+    u64 f = gl_mul(p2_filter(g, gate.group_start, gate.group_end, v.sel(gate.selector_index), a.nsel > 1), a.zh_inv[coset]);
+    for (u32 c = 0; c < a.nch; c++) {
+        u64 *o = a.out + (size_t)c * N + p;
+        *o = gl_add(*o, gl_mul(f, out.result((int)c)));
     }
-    for (u32 g = 0; g < a.num_gates; g++) {
-        p2_gate gate = a.gates[g];
-        for (int c = 0; c < P2_MAX_CH; c++) {
-            out.apow[c] = base_pow[c];
-            out.acc[c] = 0;
-        }
-        p2_eval_gate(gate, v, a.extra, out);
-        u64 f = p2_filter(g, gate.group_start, gate.group_end, v.sel(gate.selector_index), a.nsel > 1);
-        for (int c = 0; c < P2_MAX_CH; c++) total[c] = gl_add(total[c], gl_mul(f, out.acc[c]));
+}
+
+typedef void (*p2_gate_kernel_fn)(p2_quotient_args, u32);
+static p2_gate_kernel_fn p2_gate_kernel_of(u32 type) {
+    switch (type) {
+#define P2_CASE(T) case T: return p2_quotient_gate_kernel<T>;
+        P2_CASE(P2_CONSTANT) P2_CASE(P2_PUBLIC_INPUT) P2_CASE(P2_ARITHMETIC) P2_CASE(P2_ARITHMETIC_EXT) P2_CASE(P2_MUL_EXT)
+        P2_CASE(P2_BASE_SUM) P2_CASE(P2_POSEIDON) P2_CASE(P2_POSEIDON_MDS) P2_CASE(P2_RANDOM_ACCESS) P2_CASE(P2_REDUCING)
+        P2_CASE(P2_REDUCING_EXT) P2_CASE(P2_EXPONENTIATION) P2_CASE(P2_COSET_INTERPOLATION) P2_CASE(P2_U32_ARITHMETIC)
+        P2_CASE(P2_U32_ADD_MANY) P2_CASE(P2_U32_SUBTRACTION) P2_CASE(P2_U32_RANGE_CHECK) P2_CASE(P2_COMPARISON)
+#undef P2_CASE
+        default: return nullptr;   // P2_NOOP: no constraints
     }
-    for (u32 c = 0; c < a.nch; c++) a.out[(size_t)c * N + p] = gl_mul(total[c], zh_inv);
 }
 
 // ---------------------------------------------------------------------------------------------------- openings
@@ -411,6 +431,7 @@ struct zklc_plonky2_circuit {
     u64 *d_wire_vals = nullptr;       // witness values (routed columns are needed after the iNTT)
     u64 *d_rp = nullptr, *d_excl = nullptr, *d_totals = nullptr, *d_grand = nullptr;
     u64 *d_qv = nullptr;              // quotient values [nch][N]
+    u64 *d_apow = nullptr;            // powers of the alphas for the quotient kernel
     gl2 *d_zpow = nullptr, *d_open = nullptr;
     gl2 *d_fri[9] = {};               // FRI oracles (extension values), [0] has N elements
     u64 *d_fri_tree[8] = {};
@@ -539,6 +560,7 @@ static int32_t p2_create(zklc_ctx *ctx, const zklc_plonky2_params *params, const
     if (gate_extra_words) ZKLC_HIP(ctx, hipMemcpyAsync(c->d_extra, gate_extra, (size_t)gate_extra_words * 8, hipMemcpyHostToDevice, st));
     P2_ALLOC(c, c->d_kis, (size_t)P.num_routed_wires * 8);
     ZKLC_HIP(ctx, hipMemcpyAsync(c->d_kis, k_is, (size_t)P.num_routed_wires * 8, hipMemcpyHostToDevice, st));
+    const u32 nch_ = P.num_challenges;
     P2_ALLOC(c, c->d_subgroup, (size_t)n * 8);
     hipLaunchKernelGGL(p2_pow_table_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->d_subgroup, h_root(P.degree_bits), (u64)n);
     ZKLC_HIP(ctx, hipGetLastError());
@@ -567,6 +589,7 @@ static int32_t p2_create(zklc_ctx *ctx, const zklc_plonky2_params *params, const
     P2_ALLOC(c, c->d_excl, (size_t)n * 8);
     P2_ALLOC(c, c->d_totals, (size_t)((n + P2_SCAN_BLOCK - 1) / P2_SCAN_BLOCK) * 8);
     P2_ALLOC(c, c->d_grand, 8);
+    P2_ALLOC(c, c->d_apow, (size_t)nch_ * (nch_ + nch_ * (P.num_partial_products + 1) + P.num_gate_constraints + 1) * 8);
     P2_ALLOC(c, c->d_zpow, (size_t)n * sizeof(gl2));
     u32 total_polys = c->cs.width + c->wires.width + c->zs.width + c->quot.width + nch;
     P2_ALLOC(c, c->d_open, (size_t)total_polys * sizeof(gl2));
@@ -795,12 +818,34 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
         a.num_gates = P.num_gates;
         a.w_lde = h_root(c->lde_bits);
         u64 gn = h_pow(GL_GENERATOR, n), w_r = h_root(P.rate_bits);
-        for (u32 k = 0; k < (1u << P.rate_bits); k++) a.zh_inv[k] = h_inv(h_sub(h_mul(gn, h_pow(w_r, k)), 1));
+        for (u32 k = 0; k < (1u << P.rate_bits); k++) {
+            a.zh[k] = h_sub(h_mul(gn, h_pow(w_r, k)), 1);
+            a.zh_inv[k] = h_inv(a.zh[k]);
+        }
         a.n_field = n;
         for (int k = 0; k < 4; k++) a.pih[k] = pih[k];
         a.ch = chal;
+        {
+            u32 n_pow = nch + nch * (npp + 1) + P.num_gate_constraints + 1;
+            std::vector<u64> tab((size_t)nch * n_pow);
+            for (u32 k = 0; k < nch; k++) {
+                u64 v = 1;
+                for (u32 i = 0; i < n_pow; i++) {
+                    tab[(size_t)k * n_pow + i] = v;
+                    v = h_mul(v, chal.alpha[k]);
+                }
+            }
+            ZKLC_HIP(ctx, hipMemcpyAsync(c->d_apow, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st));
+            ZKLC_HIP(ctx, hipStreamSynchronize(st));   // `tab` is a stack-lifetime source
+            for (u32 k = 0; k < nch; k++) a.apow[k] = c->d_apow + (size_t)k * n_pow;
+            for (u32 k = nch; k < P2_MAX_CH; k++) a.apow[k] = c->d_apow;
+        }
         a.out = c->d_qv;
-        hipLaunchKernelGGL(p2_quotient_kernel, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a);
+        hipLaunchKernelGGL(p2_quotient_base_kernel, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a);
+        for (u32 g = 0; g < P.num_gates; g++) {
+            p2_gate_kernel_fn fn = p2_gate_kernel_of(c->gates[g].type);
+            if (fn) hipLaunchKernelGGL(fn, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a, g);
+        }
         ZKLC_HIP(ctx, hipGetLastError());
         // values on g<w_N> (bit-reversed) -> coefficients: inverse DIT, then undo the coset shift
         P2_RC(zklc_gl_ntt_dev(ctx, st, c->d_qv, c->lde_bits, nch, ZKLC_NTT_INVERSE | ZKLC_NTT_IN_BITREV, 0));
