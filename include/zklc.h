@@ -39,6 +39,9 @@ const char *zklc_strerror(int32_t code);
 /* last HIP error string seen by this context (for ZKLC_ERR_HIP) */
 const char *zklc_last_hip_error(zklc_ctx *ctx);
 int32_t zklc_synchronize(zklc_ctx *ctx);
+/* the context's own non-blocking hipStream_t (what the host-pointer entry points run on); pass it to the *_dev entry
+ * points to keep several contexts' work concurrent on one GPU */
+void *zklc_stream(zklc_ctx *ctx);
 uint32_t zklc_abi_version(void);
 
 /* ---- (a) batched Ed25519 -------------------------------------------------

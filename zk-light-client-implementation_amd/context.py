@@ -53,6 +53,10 @@ class Context:
         if rc != 0:
             raise _lib.ZklcError(rc, self._lib.zklc_last_hip_error(self._h).decode())
 
+    def stream_ptr(self):
+        """the context's own hipStream_t (an int usable as the `stream` argument of the *_dev methods)"""
+        return self._lib.zklc_stream(self._h)
+
     def synchronize(self):
         self._check(self._lib.zklc_synchronize(self._h))
 

@@ -67,6 +67,8 @@ extern "C" void zklc_destroy(zklc_ctx *ctx) {
     delete ctx;
 }
 
+extern "C" void *zklc_stream(zklc_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
 extern "C" int32_t zklc_synchronize(zklc_ctx *ctx) {
     if (!ctx) return ZKLC_ERR_INVALID_ARG;
     ZKLC_HIP(ctx, hipSetDevice(ctx->device));

@@ -252,14 +252,30 @@ static p2_gate_kernel_fn p2_gate_kernel_of(u32 type) {
 }
 
 // ---------------------------------------------------------------------------------------------------- openings
-// out[b] = sum_j coeffs[b][j] * zpow[j] (* scale[j]);  one workgroup per polynomial
+// partial[b][s] = sum over the s-th slice of j of coeffs[b][j] * zpow[j] (* scale[j]);  grid (polynomials, P2_EVAL_SPLIT):
+// enough workgroups to fill the chip for 16-234 polynomials, 4 independent loads in flight per lane
+#define P2_EVAL_SPLIT 8
 __global__ void __launch_bounds__(P2_THREADS)
 p2_eval_at_ext_kernel(const u64 *__restrict__ coeffs, u32 n, const gl2 *__restrict__ zpow, const u64 *__restrict__ scale,
-                      gl2 *__restrict__ out) {
+                      gl2 *__restrict__ partial) {
     __shared__ gl2 sh[P2_THREADS];
     const u64 *c = coeffs + (size_t)blockIdx.x * n;
+    u32 slice = (n + P2_EVAL_SPLIT - 1) / P2_EVAL_SPLIT;
+    u32 j0 = blockIdx.y * slice, j1 = j0 + slice < n ? j0 + slice : n;
     gl2 acc = gl2_make(0, 0);
-    for (u32 j = threadIdx.x; j < n; j += P2_THREADS) {
+    u32 j = j0 + threadIdx.x;
+    for (; j + 3 * P2_THREADS < j1; j += 4 * P2_THREADS) {
+        u64 c0 = c[j], c1 = c[j + P2_THREADS], c2 = c[j + 2 * P2_THREADS], c3 = c[j + 3 * P2_THREADS];
+        gl2 z0 = zpow[j], z1 = zpow[j + P2_THREADS], z2 = zpow[j + 2 * P2_THREADS], z3 = zpow[j + 3 * P2_THREADS];
+        if (scale) {
+            c0 = gl_mul(c0, scale[j]);
+            c1 = gl_mul(c1, scale[j + P2_THREADS]);
+            c2 = gl_mul(c2, scale[j + 2 * P2_THREADS]);
+            c3 = gl_mul(c3, scale[j + 3 * P2_THREADS]);
+        }
+        acc = gl2_add(acc, gl2_add(gl2_add(gl2_scale(z0, c0), gl2_scale(z1, c1)), gl2_add(gl2_scale(z2, c2), gl2_scale(z3, c3))));
+    }
+    for (; j < j1; j += P2_THREADS) {
         u64 cj = c[j];
         if (scale) cj = gl_mul(cj, scale[j]);
         acc = gl2_add(acc, gl2_scale(zpow[j], cj));
@@ -270,7 +286,14 @@ p2_eval_at_ext_kernel(const u64 *__restrict__ coeffs, u32 n, const gl2 *__restri
         if (threadIdx.x < off) sh[threadIdx.x] = gl2_add(sh[threadIdx.x], sh[threadIdx.x + off]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.x * P2_EVAL_SPLIT + blockIdx.y] = sh[0];
+}
+__global__ void p2_eval_finish_kernel(const gl2 *__restrict__ partial, u32 n_polys, gl2 *__restrict__ out) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_polys) return;
+    gl2 acc = partial[(size_t)b * P2_EVAL_SPLIT];
+    for (u32 s = 1; s < P2_EVAL_SPLIT; s++) acc = gl2_add(acc, partial[(size_t)b * P2_EVAL_SPLIT + s]);
+    out[b] = acc;
 }
 
 // -------------------------------------------------------------------------------------------------------- FRI
@@ -292,8 +315,16 @@ __global__ void __launch_bounds__(P2_THREADS) p2_fri_combine_kernel(p2_fri_combi
     u64 x = gl_mul(GL_GENERATOR, gl_pow(a.w_lde, i));
     gl2 acc = gl2_make(0, 0);
     for (int m = 3; m >= 0; m--) {
-        const u64 *mat = a.mats[m];
-        for (u32 j = a.widths[m]; j-- > 0;) acc = gl2_add_base(gl2_mul(acc, a.alpha), mat[(size_t)j * N + p]);
+        const u64 *mat = a.mats[m] + p;
+        u32 j = a.widths[m];
+        for (; j >= 8; j -= 8) {   // Horner over the columns, eight loads in flight
+            u64 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) v[q] = mat[(size_t)(j - 1 - q) * N];
+#pragma unroll
+            for (int q = 0; q < 8; q++) acc = gl2_add_base(gl2_mul(acc, a.alpha), v[q]);
+        }
+        while (j-- > 0) acc = gl2_add_base(gl2_mul(acc, a.alpha), mat[(size_t)j * N]);
     }
     gl2 acc1 = gl2_make(0, 0);
     for (u32 j = a.nch; j-- > 0;) acc1 = gl2_add_base(gl2_mul(acc1, a.alpha), a.mats[2][(size_t)j * N + p]);
@@ -432,7 +463,7 @@ struct zklc_plonky2_circuit {
     u64 *d_rp = nullptr, *d_excl = nullptr, *d_totals = nullptr, *d_grand = nullptr;
     u64 *d_qv = nullptr;              // quotient values [nch][N]
     u64 *d_apow = nullptr;            // powers of the alphas for the quotient kernel
-    gl2 *d_zpow = nullptr, *d_open = nullptr;
+    gl2 *d_zpow = nullptr, *d_open = nullptr, *d_open_partial = nullptr;
     gl2 *d_fri[9] = {};               // FRI oracles (extension values), [0] has N elements
     u64 *d_fri_tree[8] = {};
     gl2 *d_final = nullptr;
@@ -593,6 +624,7 @@ static int32_t p2_create(zklc_ctx *ctx, const zklc_plonky2_params *params, const
     P2_ALLOC(c, c->d_zpow, (size_t)n * sizeof(gl2));
     u32 total_polys = c->cs.width + c->wires.width + c->zs.width + c->quot.width + nch;
     P2_ALLOC(c, c->d_open, (size_t)total_polys * sizeof(gl2));
+    P2_ALLOC(c, c->d_open_partial, (size_t)total_polys * P2_EVAL_SPLIT * sizeof(gl2));
     // FRI oracles
     u32 bits = c->lde_bits;
     P2_ALLOC(c, c->d_fri[0], (size_t)N * sizeof(gl2));
@@ -868,12 +900,15 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
         const p2_batch *bs[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
         u32 off = 0;
         for (int k = 0; k < 4; k++) {
-            hipLaunchKernelGGL(p2_eval_at_ext_kernel, dim3(bs[k]->width), dim3(P2_THREADS), 0, st, (const u64 *)bs[k]->coeffs, n,
-                               (const gl2 *)c->d_zpow, (const u64 *)nullptr, c->d_open + off);
+            hipLaunchKernelGGL(p2_eval_at_ext_kernel, dim3(bs[k]->width, P2_EVAL_SPLIT), dim3(P2_THREADS), 0, st,
+                               (const u64 *)bs[k]->coeffs, n, (const gl2 *)c->d_zpow, (const u64 *)nullptr,
+                               c->d_open_partial + (size_t)off * P2_EVAL_SPLIT);
             off += bs[k]->width;
         }
-        hipLaunchKernelGGL(p2_eval_at_ext_kernel, dim3(nch), dim3(P2_THREADS), 0, st, (const u64 *)c->zs.coeffs, n,
-                           (const gl2 *)c->d_zpow, (const u64 *)c->d_subgroup, c->d_open + off);
+        hipLaunchKernelGGL(p2_eval_at_ext_kernel, dim3(nch, P2_EVAL_SPLIT), dim3(P2_THREADS), 0, st, (const u64 *)c->zs.coeffs, n,
+                           (const gl2 *)c->d_zpow, (const u64 *)c->d_subgroup, c->d_open_partial + (size_t)off * P2_EVAL_SPLIT);
+        hipLaunchKernelGGL(p2_eval_finish_kernel, dim3((n_open + 255) / 256), dim3(256), 0, st, (const gl2 *)c->d_open_partial, n_open,
+                           c->d_open);
         ZKLC_HIP(ctx, hipGetLastError());
         ZKLC_HIP(ctx, hipMemcpyAsync(open.data(), c->d_open, (size_t)n_open * sizeof(gl2), hipMemcpyDeviceToHost, st));
         ZKLC_HIP(ctx, hipStreamSynchronize(st));
