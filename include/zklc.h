@@ -205,6 +205,16 @@ uint64_t zklc_bn254_g1_msm_workspace_bytes(uint64_t n);
 int32_t zklc_bn254_g1_msm_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, const uint64_t *d_scalars, uint64_t n,
                               uint64_t *d_out_affine, uint32_t *d_out_is_infinity, void *d_workspace, uint64_t workspace_bytes);
 
+/* NTT over the BN254 scalar field Fr.  Replaces gnark-crypto `fft.Domain.FFT / FFTInverse` (ecc/bn254/fr/fft, un-vendored)
+ * inside `groth16.Prove` (gnark-plonky2-verifier/cmd/web-api.go:77).  data: 2^log_n elements in gnark-crypto's memory layout
+ * (x * 2^256 mod r, 4 little-endian u64), transformed in place.  values[k] = sum_j coeffs[j] w^(jk), w = rootOfUnity^(2^28/n);
+ * flags as for zklc_gl_ntt (ZKLC_NTT_INVERSE includes 1/n).  coset = 1: evaluate on / interpolate from the coset 5 * <w>
+ * (gnark `fft.OnCoset()`, FrMultiplicativeGen = 5). */
+int32_t zklc_bn254_fr_ntt(zklc_ctx *ctx, uint64_t *data, uint32_t log_n, uint32_t flags, uint32_t coset);
+uint64_t zklc_bn254_fr_ntt_workspace_bytes(uint32_t log_n);
+int32_t zklc_bn254_fr_ntt_dev(zklc_ctx *ctx, void *stream, uint64_t *d_data, uint32_t log_n, uint32_t flags, uint32_t coset,
+                              void *d_workspace, uint64_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

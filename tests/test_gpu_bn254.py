@@ -181,3 +181,59 @@ def test_golden_proof_merkle_paths_with_gpu_hashing(zctx):
             assert cur == pf["commit_caps"][i][w]
             checked += 1
     assert checked == 12
+
+
+# ---------------------------------------------------------------- Fr NTT (zklc_bn254_fr_ntt)
+def _fr_arr(vals):
+    from oracle import bn254_fr as FR
+    return np.array([FR.to_mont_words(v) for v in vals], dtype=np.uint64)
+
+
+def _fr_vals(arr):
+    from oracle import bn254_fr as FR
+    return [FR.from_mont_words(r) for r in arr]
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 6, 10])
+def test_fr_ntt_matches_definition(zctx, log_n):
+    from oracle import bn254_fr as FR
+    import random
+    rng = random.Random(log_n)
+    n = 1 << log_n
+    a = [rng.randrange(FR.R) for _ in range(n)]
+    if n <= 64:
+        assert FR.ntt(a) == FR.naive_dft(a) and FR.ntt(a, coset=True) == FR.naive_dft(a, FR.GENERATOR)
+    got = _fr_vals(zctx.bn254_fr_ntt(_fr_arr(a)))
+    assert got == FR.ntt(a)
+    assert _fr_vals(zctx.bn254_fr_ntt(_fr_arr(a), coset=1)) == FR.ntt(a, coset=True)
+    assert _fr_vals(zctx.bn254_fr_ntt(_fr_arr(a), flags=1)) == FR.ntt(a, inverse=True)
+    assert _fr_vals(zctx.bn254_fr_ntt(_fr_arr(a), flags=1, coset=1)) == FR.ntt(a, inverse=True, coset=True)
+    if log_n:
+        br = [int(format(i, "0%db" % log_n)[::-1], 2) for i in range(n)]
+        out_br = _fr_vals(zctx.bn254_fr_ntt(_fr_arr(a), flags=4))
+        assert [out_br[br[i]] for i in range(n)] == FR.ntt(a)
+        in_br = _fr_vals(zctx.bn254_fr_ntt(_fr_arr([a[br[i]] for i in range(n)]), flags=2))
+        assert in_br == FR.ntt(a)
+
+
+def test_fr_ntt_roundtrip_and_coset_property_2p18(zctx):
+    """size-independent properties at a large size: inverse(forward(x)) == x; coset evaluation of the vanishing polynomial
+    X^n - 1 is the constant 5^n - 1 (what the Groth16 quotient step divides by)"""
+    from oracle import bn254_fr as FR
+    log_n = 18
+    n = 1 << log_n
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)                             # < 2^252 < r: canonical Montgomery images
+    fwd = zctx.bn254_fr_ntt(a, coset=1)
+    back = zctx.bn254_fr_ntt(fwd, flags=1, coset=1)
+    assert np.array_equal(back, a)
+    x = np.zeros((n, 4), dtype=np.uint64)
+    x[0] = FR.to_mont_words(FR.R - 1)          # -1 + X^n wraps onto the constant term in a size-n transform: use 2n
+    big = np.zeros((2 * n, 4), dtype=np.uint64)
+    big[0] = FR.to_mont_words(FR.R - 1)
+    big[n] = FR.to_mont_words(1)
+    ev = _fr_vals(zctx.bn254_fr_ntt(big, coset=1)[:8])
+    g2n = pow(FR.GENERATOR, n, FR.R)
+    w = FR.root(log_n + 1)
+    assert ev == [(g2n * pow(w, k * n, FR.R) - 1) % FR.R for k in range(8)]

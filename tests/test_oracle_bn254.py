@@ -56,3 +56,17 @@ def test_c_msm_bucket_vs_naive_medium():
     s2 = np.array([scalar_words(5), scalar_words(bn.R - 5)], dtype=np.uint64)
     _, inf, _ = cport.bn254_msm(two, s2)
     assert inf
+
+
+def test_fr_ntt_oracle_is_the_dft():
+    import random
+    from oracle import bn254_fr as FR
+    rng = random.Random(3)
+    for log_n in [0, 1, 3, 5]:
+        a = [rng.randrange(FR.R) for _ in range(1 << log_n)]
+        assert FR.ntt(a) == FR.naive_dft(a)
+        assert FR.ntt(a, coset=True) == FR.naive_dft(a, FR.GENERATOR)
+        assert FR.ntt(FR.ntt(a), inverse=True) == a
+        assert FR.ntt(FR.ntt(a, coset=True), inverse=True, coset=True) == a
+    for x in [0, 1, FR.R - 1, rng.randrange(FR.R)]:
+        assert FR.from_mont_words(FR.to_mont_words(x)) == x

@@ -220,6 +220,13 @@ class Context:
     def bn254_g1_msm_dev(self, d_points, d_scalars, n, d_out, d_inf, d_workspace, workspace_bytes, stream=None):
         self._check(self._lib.zklc_bn254_g1_msm_dev(self._h, _stream_ptr(stream), _dev_ptr(d_points), _dev_ptr(d_scalars), n,
                                                     _dev_ptr(d_out), _dev_ptr(d_inf), _dev_ptr(d_workspace), workspace_bytes))
+    def bn254_fr_ntt(self, data, flags=0, coset=0):
+        """data: uint64 [n, 4] Fr elements in gnark Montgomery layout -> transformed copy"""
+        a = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, 4).copy()
+        n = a.shape[0]
+        assert n & (n - 1) == 0 and n
+        self._check(self._lib.zklc_bn254_fr_ntt(self._h, a.ctypes.data, n.bit_length() - 1, flags, coset))
+        return a
 
 
 def _dev_ptr(t):

@@ -1,0 +1,159 @@
+// NTT over the BN254 scalar field Fr (2-adicity 28) for gfx950 + C ABI.
+//
+// Replaces gnark-crypto's `fft.Domain.FFT / FFTInverse` on ecc/bn254/fr (un-vendored, gnark-plonky2-verifier/go.mod:9),
+// used by `groth16.Prove` (gnark-plonky2-verifier/cmd/web-api.go:77) to compute the quotient polynomial h from the
+// A, B, C wire evaluations (three inverse FFTs, three coset FFTs, one coset inverse FFT of size = domain cardinality).
+// Elements cross the ABI in gnark-crypto's memory layout (x * 2^256 mod r, 4 little-endian u64); inside, the ten-limb
+// lazy Montgomery form of bn254_fr.cuh.  Definition: values[k] = sum_j coeffs[j] w^(jk), w = g28^(2^28 / n) with
+// g28 = 0x2a3c09f0a58a7e8500e0a7eb8ef62abc402d111e41112ed49bd61b6e725b19f0 (gnark-crypto's rootOfUnity; order 2^28 is
+// checked in oracle/bn254_fr.py); coset generator 5 (fr.Generator / FrMultiplicativeGen).
+// One launch per radix-2 stage on a limb-form working copy (decimation in time after a bit-reversal gather); the
+// transform is a small part of a Groth16 proof next to the MSMs, so no LDS tiling yet.
+#include "bn254_fr.cuh"
+#include "zklc_internal.h"
+
+#define FR_ROOT28_WORDS {0x725b19f0u, 0x9bd61b6eu, 0x41112ed4u, 0x402d111eu, 0x8ef62abcu, 0x00e0a7ebu, 0xa58a7e85u, 0x2a3c09f0u}
+
+ZKLC_D fr frn_pow(fr a, u64 e) {
+    const fr one = FR_ONE;
+    fr r = one;
+#pragma unroll 1
+    while (e) {
+        if (e & 1) r = fr_mul(r, a);
+        a = fr_sqr(a);
+        e >>= 1;
+    }
+    return r;
+}
+ZKLC_D void frn_store(i32 *dst, const fr &a) {
+#pragma unroll
+    for (int k = 0; k < 10; k++) dst[k] = a.v[k];
+}
+ZKLC_D fr frn_load(const i32 *src) {
+    fr a;
+#pragma unroll
+    for (int k = 0; k < 10; k++) a.v[k] = src[k];
+    return a;
+}
+ZKLC_D fr frn_load_gnark(const u64 *p) {
+    u32 w[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        w[2 * k] = (u32)p[k];
+        w[2 * k + 1] = (u32)(p[k] >> 32);
+    }
+    return fr_reduce(fr_from_gnark(w));
+}
+
+// tw[i] = w^i, i < n/2, w = root28^(2^(28 - logn)) (or its inverse)
+__global__ void frn_twiddle_kernel(i32 *tw, u32 logn, u32 inverse, u32 half) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= half) return;
+    const u32 rw[8] = FR_ROOT28_WORDS;
+    fr g = fr_from_regular(rw);
+    fr w = frn_pow(g, 1ULL << (28 - logn));
+    if (inverse) w = fr_inv(w);
+    frn_store(tw + (size_t)i * 10, frn_pow(w, i));
+}
+
+// consts[0] = 1/n, consts[1] = 5, consts[2] = 1/5 (internal Montgomery form), computed once per call by one lane
+__global__ void frn_consts_kernel(i32 *consts, u32 logn) {
+    if (threadIdx.x || blockIdx.x) return;
+    const fr r2 = FR_R2;
+    fr nn = fr_zero();
+    nn.v[0] = (i32)((1u << logn) & 0x3ffffff);
+    nn.v[1] = (i32)((1u << logn) >> 26);
+    fr five = fr_zero();
+    five.v[0] = 5;
+    five = fr_mul(five, r2);
+    frn_store(consts, fr_inv(fr_mul(nn, r2)));
+    frn_store(consts + 10, five);
+    frn_store(consts + 20, fr_inv(five));
+}
+
+// work[i] = data[src(i)] * shift^src(i)   (src = bit reversal when the input is in natural order)
+__global__ void frn_load_kernel(const u64 *__restrict__ data, i32 *__restrict__ work, const i32 *__restrict__ consts, u32 logn,
+                                u32 bitrev_in, u32 coset) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << logn)) return;
+    u32 s = bitrev_in && logn ? (__brev(i) >> (32 - logn)) : i;
+    fr a = frn_load_gnark(data + (size_t)s * 4);
+    if (coset) a = fr_mul(a, frn_pow(frn_load(consts + 10), s));
+    frn_store(work + (size_t)i * 10, a);
+}
+
+// one decimation-in-time stage: pairs (j, j + half) inside blocks of 2 * half
+__global__ void __launch_bounds__(256) frn_stage_kernel(i32 *__restrict__ work, const i32 *__restrict__ tw, u32 logn, u32 stage) {
+    u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= (1u << (logn - 1))) return;
+    u32 half = 1u << stage;
+    u32 j = b & (half - 1);
+    u32 i0 = ((b >> stage) << (stage + 1)) | j;
+    u32 i1 = i0 + half;
+    fr u = fr_reduce(frn_load(work + (size_t)i0 * 10));     // keeps the lazy magnitudes bounded across the stages
+    fr v = fr_mul(frn_load(work + (size_t)i1 * 10), frn_load(tw + (size_t)(j << (logn - 1 - stage)) * 10));
+    frn_store(work + (size_t)i0 * 10, fr_add(u, v));
+    frn_store(work + (size_t)i1 * 10, fr_sub(u, v));
+}
+
+// data[dst(i)] = work[i] * scale * shift_inv^i
+__global__ void frn_store_kernel(const i32 *__restrict__ work, u64 *__restrict__ data, const i32 *__restrict__ consts, u32 logn,
+                                 u32 bitrev_out, u32 inverse, u32 coset) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1u << logn)) return;
+    fr a = frn_load(work + (size_t)i * 10);
+    if (inverse) {
+        a = fr_mul(a, frn_load(consts));
+        if (coset) a = fr_mul(a, frn_pow(frn_load(consts + 20), i));
+    }
+    u32 d = bitrev_out && logn ? (__brev(i) >> (32 - logn)) : i;
+    u32 w[8];
+    fr_to_gnark(w, a);
+    u64 *o = data + (size_t)d * 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = (u64)w[2 * k] | ((u64)w[2 * k + 1] << 32);
+}
+
+extern "C" uint64_t zklc_bn254_fr_ntt_workspace_bytes(uint32_t log_n) { return ((uint64_t)40 << log_n) + ((uint64_t)20 << log_n) + 512; }
+
+extern "C" int32_t zklc_bn254_fr_ntt_dev(zklc_ctx *ctx, void *stream, uint64_t *d_data, uint32_t log_n, uint32_t flags, uint32_t coset,
+                                         void *d_workspace, uint64_t workspace_bytes) {
+    if (!ctx || !d_data || log_n > 28 || !d_workspace || workspace_bytes < zklc_bn254_fr_ntt_workspace_bytes(log_n))
+        return ZKLC_ERR_INVALID_ARG;
+    bool inverse = flags & ZKLC_NTT_INVERSE, in_br = flags & ZKLC_NTT_IN_BITREV, out_br = flags & ZKLC_NTT_OUT_BITREV;
+    if (in_br && out_br) return ZKLC_ERR_INVALID_ARG;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = zklc_pick_stream(ctx, stream);
+    u32 n = 1u << log_n, half = n >> 1;
+    i32 *work = (i32 *)d_workspace;
+    i32 *tw = work + (size_t)n * 10;
+    i32 *consts = tw + (size_t)(half ? half : 1) * 10;
+    hipLaunchKernelGGL(frn_consts_kernel, dim3(1), dim3(64), 0, st, consts, log_n);
+    if (half) hipLaunchKernelGGL(frn_twiddle_kernel, dim3((half + 255) / 256), dim3(256), 0, st, tw, log_n, (u32)inverse, half);
+    // DIT needs bit-reversed input: gather through the bit reversal unless the caller already supplies that order.
+    // A bit-reversed OUTPUT is produced by running the natural-order transform and scattering through the reversal.
+    hipLaunchKernelGGL(frn_load_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const u64 *)d_data, work, (const i32 *)consts, log_n,
+                       (u32)!in_br, (u32)(coset && !inverse));
+    for (u32 s = 0; s < log_n; s++)
+        hipLaunchKernelGGL(frn_stage_kernel, dim3((half + 255) / 256), dim3(256), 0, st, work, (const i32 *)tw, log_n, s);
+    hipLaunchKernelGGL(frn_store_kernel, dim3((n + 255) / 256), dim3(256), 0, st, (const i32 *)work, d_data, (const i32 *)consts, log_n,
+                       (u32)out_br, (u32)inverse, coset);
+    ZKLC_HIP(ctx, hipGetLastError());
+    return ZKLC_OK;
+}
+
+extern "C" int32_t zklc_bn254_fr_ntt(zklc_ctx *ctx, uint64_t *data, uint32_t log_n, uint32_t flags, uint32_t coset) {
+    if (!ctx || !data || log_n > 28) return ZKLC_ERR_INVALID_ARG;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t bytes = (size_t)32 << log_n;
+    uint64_t wb = zklc_bn254_fr_ntt_workspace_bytes(log_n);
+    void *d, *w;
+    int32_t rc;
+    if ((rc = zklc_stage(ctx, 0, bytes, &d))) return rc;
+    if ((rc = zklc_stage(ctx, 1, wb, &w))) return rc;
+    ZKLC_HIP(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = zklc_bn254_fr_ntt_dev(ctx, ctx->stream, (uint64_t *)d, log_n, flags, coset, w, wb))) return rc;
+    ZKLC_HIP(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return ZKLC_OK;
+}
