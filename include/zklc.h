@@ -205,6 +205,15 @@ uint64_t zklc_bn254_g1_msm_workspace_bytes(uint64_t n);
 int32_t zklc_bn254_g1_msm_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, const uint64_t *d_scalars, uint64_t n,
                               uint64_t *d_out_affine, uint32_t *d_out_is_infinity, void *d_workspace, uint64_t workspace_bytes);
 
+/* G2 multi-scalar multiplication (the B2 term of a Groth16 proof): replaces gnark-crypto `bn254.G2Affine.MultiExp`.
+ * points: n affine G2 points = X.A0, X.A1, Y.A0, Y.A1 (4 x 4 little-endian u64, Montgomery form; all zero = infinity);
+ * scalars as for the G1 MSM; out_affine: 16 u64 in the same layout. */
+int32_t zklc_bn254_g2_msm(zklc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, uint64_t n, uint64_t *out_affine,
+                          uint32_t *out_is_infinity);
+uint64_t zklc_bn254_g2_msm_workspace_bytes(uint64_t n);
+int32_t zklc_bn254_g2_msm_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, const uint64_t *d_scalars, uint64_t n,
+                              uint64_t *d_out_affine, uint32_t *d_out_is_infinity, void *d_workspace, uint64_t workspace_bytes);
+
 /* NTT over the BN254 scalar field Fr.  Replaces gnark-crypto `fft.Domain.FFT / FFTInverse` (ecc/bn254/fr/fft, un-vendored)
  * inside `groth16.Prove` (gnark-plonky2-verifier/cmd/web-api.go:77).  data: 2^log_n elements in gnark-crypto's memory layout
  * (x * 2^256 mod r, 4 little-endian u64), transformed in place.  values[k] = sum_j coeffs[j] w^(jk), w = rootOfUnity^(2^28/n);

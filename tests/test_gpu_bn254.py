@@ -237,3 +237,62 @@ def test_fr_ntt_roundtrip_and_coset_property_2p18(zctx):
     g2n = pow(FR.GENERATOR, n, FR.R)
     w = FR.root(log_n + 1)
     assert ev == [(g2n * pow(w, k * n, FR.R) - 1) % FR.R for k in range(8)]
+
+
+# ---------------------------------------------------------------- G2 MSM (zklc_bn254_g2_msm)
+def _g2_points(n, seed):
+    import random
+    from oracle import bn254 as B
+    rng = random.Random(seed)
+    pts, cur = [], B.g2_mul(rng.randrange(1, B.R), B.G2)
+    step = B.g2_mul(rng.randrange(1, B.R), B.G2)
+    for _ in range(n):
+        pts.append(cur)
+        cur = B.g2_add(cur, step)
+    return pts
+
+
+def test_g2_msm_small_against_python(zctx):
+    import random
+    from oracle import bn254 as B
+    rng = random.Random(21)
+    for n in [0, 1, 2, 3, 17, 70]:
+        pts = _g2_points(n, n)
+        sc = [rng.randrange(B.R) for _ in range(n)]
+        if n >= 3:
+            sc[0], sc[1] = 0, 1
+            pts[2] = None                                  # a point at infinity in the input
+        want = B.g2_msm(sc, pts)
+        pa = np.array([B.g2_to_words(p) for p in pts], dtype=np.uint64).reshape(-1, 16)
+        sa = np.array([[(s >> (64 * i)) & (2**64 - 1) for i in range(4)] for s in sc], dtype=np.uint64).reshape(-1, 4)
+        out, inf = zctx.bn254_g2_msm(pa, sa)
+        assert B.g2_from_words([int(x) for x in out], inf) == want, n
+
+
+def test_g2_msm_adversarial_and_linearity(zctx):
+    """all points equal / P and -P cancelling (exceptional cases of the bucket additions), and at 2^12 points the
+    size-independent identity MSM(s, Q) + MSM(t, Q) == MSM(s + t, Q)"""
+    import random
+    from oracle import bn254 as B
+    rng = random.Random(22)
+    q = B.g2_mul(777, B.G2)
+    n = 300
+    sc = [rng.randrange(B.R) for _ in range(n)]
+    pa = np.array([B.g2_to_words(q)] * n, dtype=np.uint64)
+    sa = np.array([[(s >> (64 * i)) & (2**64 - 1) for i in range(4)] for s in sc], dtype=np.uint64)
+    out, inf = zctx.bn254_g2_msm(pa, sa)
+    assert B.g2_from_words([int(x) for x in out], inf) == B.g2_mul(sum(sc) % B.R, q)
+    pa2 = np.array([B.g2_to_words(q), B.g2_to_words(B.g2_neg(q))] * 8, dtype=np.uint64)
+    sa2 = np.array([[5, 0, 0, 0]] * 16, dtype=np.uint64)
+    out, inf = zctx.bn254_g2_msm(pa2, sa2)
+    assert inf and not out.any()
+    n = 1 << 12
+    pts = _g2_points(n, 99)
+    pa = np.array([B.g2_to_words(p) for p in pts], dtype=np.uint64)
+    s = [rng.randrange(B.R) for _ in range(n)]
+    t = [rng.randrange(B.R) for _ in range(n)]
+    words = lambda v: np.array([[(x >> (64 * i)) & (2**64 - 1) for i in range(4)] for x in v], dtype=np.uint64)
+    a = B.g2_from_words([int(x) for x in zctx.bn254_g2_msm(pa, words(s))[0]])
+    b = B.g2_from_words([int(x) for x in zctx.bn254_g2_msm(pa, words(t))[0]])
+    c = B.g2_from_words([int(x) for x in zctx.bn254_g2_msm(pa, words([(x + y) % B.R for x, y in zip(s, t)]))[0]])
+    assert B.g2_add(a, b) == c and B.g2_is_on_curve(c)

@@ -70,3 +70,11 @@ def test_fr_ntt_oracle_is_the_dft():
         assert FR.ntt(FR.ntt(a, coset=True), inverse=True, coset=True) == a
     for x in [0, 1, FR.R - 1, rng.randrange(FR.R)]:
         assert FR.from_mont_words(FR.to_mont_words(x)) == x
+
+
+def test_g2_group_law_basics():
+    assert B.g2_is_on_curve(B.G2) and B.g2_mul(B.R, B.G2) is None
+    a, b = B.g2_mul(5, B.G2), B.g2_mul(7, B.G2)
+    assert B.g2_add(a, b) == B.g2_mul(12, B.G2) and B.g2_add(a, B.g2_neg(a)) is None
+    assert B.g2_from_words(B.g2_to_words(a)) == a
+    assert B.g2_msm([3, 4], [a, b]) == B.g2_mul(15 + 28, B.G2)

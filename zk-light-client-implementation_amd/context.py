@@ -220,6 +220,19 @@ class Context:
     def bn254_g1_msm_dev(self, d_points, d_scalars, n, d_out, d_inf, d_workspace, workspace_bytes, stream=None):
         self._check(self._lib.zklc_bn254_g1_msm_dev(self._h, _stream_ptr(stream), _dev_ptr(d_points), _dev_ptr(d_scalars), n,
                                                     _dev_ptr(d_out), _dev_ptr(d_inf), _dev_ptr(d_workspace), workspace_bytes))
+    def bn254_g2_msm(self, points, scalars):
+        """points: uint64 [n, 16] (gnark Montgomery affine G2: X.A0, X.A1, Y.A0, Y.A1), scalars: uint64 [n, 4].
+        Returns (uint64[16] affine result, is_infinity)."""
+        pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 16)
+        sc = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        if pts.shape[0] != sc.shape[0]:
+            raise ValueError("points and scalars must have the same length")
+        out = np.zeros(16, dtype=np.uint64)
+        inf = ctypes.c_uint32(0)
+        self._check(self._lib.zklc_bn254_g2_msm(self._h, pts.ctypes.data if pts.size else None, sc.ctypes.data if sc.size else None,
+                                                pts.shape[0], out.ctypes.data, ctypes.addressof(inf)))
+        return out, bool(inf.value)
+
     def bn254_fr_ntt(self, data, flags=0, coset=0):
         """data: uint64 [n, 4] Fr elements in gnark Montgomery layout -> transformed copy"""
         a = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, 4).copy()

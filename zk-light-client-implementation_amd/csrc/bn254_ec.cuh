@@ -1,0 +1,198 @@
+// Short-Weierstrass curves y^2 = x^3 + b (a = 0) in extended Jacobian coordinates (X, Y, ZZ, ZZZ), generic over the
+// coordinate field: BN254 G1 over Fp (bn254_g1.cuh) and G2 over Fp2 (bn254_g2.cuh) share these formulas.
+// x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2 -- the bucket coordinates of gnark-crypto's MSM (g1JacExtended / g2JacExtended,
+// un-vendored: gnark-plonky2-verifier/go.mod:9; call site `groth16.Prove`, cmd/web-api.go:77).  Infinity is ZZ = 0.
+// EFD madd-2008-s / add-2008-s / dbl-2008-s-1; the exceptional cases (P = Q, P = -Q, infinity) are explicit because
+// the adversarial MSM inputs of SURVEY 8(d) ("all points equal") reach them.  b never appears (a = 0 formulas).
+#pragma once
+#include "bn254_fp2.cuh"
+
+struct FpField {
+    typedef fp T;
+    static constexpr int LIMBS = 10;
+    static ZKLC_M T zero() { return fp_zero(); }
+    static ZKLC_M T one() {
+        const fp o = FP_ONE;
+        return o;
+    }
+    static ZKLC_M T add(const T &a, const T &b) { return fp_add(a, b); }
+    static ZKLC_M T sub(const T &a, const T &b) { return fp_sub(a, b); }
+    static ZKLC_M T dbl(const T &a) { return fp_dbl(a); }
+    static ZKLC_M T neg(const T &a) { return fp_neg(a); }
+    static ZKLC_M T mul(const T &a, const T &b) { return fp_mul(a, b); }
+    static ZKLC_M T sqr(const T &a) { return fp_sqr(a); }
+    static ZKLC_M T inv(const T &a) { return fp_inv(a); }
+    static ZKLC_M T reduce(const T &a) { return fp_reduce(a); }
+    static ZKLC_M T select(const T &a, const T &b, u32 c) { return fp_select(a, b, c); }
+    static ZKLC_M u32 is_zero(const T &a) { return fp_is_zero(a); }
+    static ZKLC_M T from_gnark(const u32 *w) { return fp_from_gnark(w); }
+    static ZKLC_M void to_gnark(u32 *w, const T &a) { fp_to_gnark(w, a); }
+    static ZKLC_M void store(i32 *d, const T &a) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) d[k] = a.v[k];
+    }
+    static ZKLC_M T load(const i32 *s) {
+        T a;
+#pragma unroll
+        for (int k = 0; k < 10; k++) a.v[k] = s[k];
+        return a;
+    }
+};
+struct Fp2Field {
+    typedef fp2 T;
+    static constexpr int LIMBS = 20;
+    static ZKLC_M T zero() { return fp2_zero(); }
+    static ZKLC_M T one() { return fp2_one(); }
+    static ZKLC_M T add(const T &a, const T &b) { return fp2_add(a, b); }
+    static ZKLC_M T sub(const T &a, const T &b) { return fp2_sub(a, b); }
+    static ZKLC_M T dbl(const T &a) { return fp2_dbl(a); }
+    static ZKLC_M T neg(const T &a) { return fp2_neg(a); }
+    static ZKLC_M T mul(const T &a, const T &b) { return fp2_mul(a, b); }
+    static ZKLC_M T sqr(const T &a) { return fp2_sqr(a); }
+    static ZKLC_M T inv(const T &a) { return fp2_inv(a); }
+    static ZKLC_M T reduce(const T &a) { return fp2_reduce(a); }
+    static ZKLC_M T select(const T &a, const T &b, u32 c) { return fp2_select(a, b, c); }
+    static ZKLC_M u32 is_zero(const T &a) { return fp2_is_zero(a); }
+    static ZKLC_M T from_gnark(const u32 *w) { return fp2_from_gnark(w); }
+    static ZKLC_M void to_gnark(u32 *w, const T &a) { fp2_to_gnark(w, a); }
+    static ZKLC_M void store(i32 *d, const T &a) {
+        FpField::store(d, a.c0);
+        FpField::store(d + 10, a.c1);
+    }
+    static ZKLC_M T load(const i32 *s) {
+        T a;
+        a.c0 = FpField::load(s);
+        a.c1 = FpField::load(s + 10);
+        return a;
+    }
+};
+
+template <class F>
+struct ec_xyzz {
+    typename F::T X, Y, ZZ, ZZZ;
+};
+
+template <class F>
+ZKLC_HD ec_xyzz<F> ec_infinity() {
+    ec_xyzz<F> r;
+    r.X = F::zero();
+    r.Y = F::zero();
+    r.ZZ = F::zero();
+    r.ZZZ = F::zero();
+    return r;
+}
+template <class F>
+ZKLC_HD u32 ec_is_inf(const ec_xyzz<F> &p) {
+    return F::is_zero(p.ZZ);
+}
+
+// dbl-2008-s-1
+template <class F>
+ZKLC_HD ec_xyzz<F> ec_double(const ec_xyzz<F> &p) {
+    typedef typename F::T T;
+    T U = F::dbl(p.Y);
+    T V = F::sqr(U);
+    T W = F::mul(U, V);
+    T S = F::mul(p.X, V);
+    T XX = F::sqr(p.X);
+    T M = F::add(F::dbl(XX), XX);  // 3 X^2 (a = 0)
+    ec_xyzz<F> r;
+    r.X = F::sub(F::sqr(M), F::dbl(S));
+    r.Y = F::sub(F::mul(M, F::sub(S, r.X)), F::mul(W, p.Y));
+    r.ZZ = F::mul(V, p.ZZ);
+    r.ZZZ = F::mul(W, p.ZZZ);
+    return r;  // doubling infinity (ZZ = 0) gives ZZ = 0 again; these curves have no 2-torsion
+}
+
+// double of an affine point (mdbl-2008-s-1); x, y reduced
+template <class F>
+ZKLC_HD ec_xyzz<F> ec_double_affine(const typename F::T &x, const typename F::T &y) {
+    typedef typename F::T T;
+    T U = F::dbl(y);
+    ec_xyzz<F> r;
+    r.ZZ = F::sqr(U);
+    r.ZZZ = F::mul(U, r.ZZ);
+    T S = F::mul(x, r.ZZ);
+    T XX = F::sqr(x);
+    T M = F::add(F::dbl(XX), XX);
+    r.X = F::sub(F::sqr(M), F::dbl(S));
+    r.Y = F::sub(F::mul(M, F::sub(S, r.X)), F::mul(r.ZZZ, y));
+    return r;
+}
+
+// p + (x2, y2), (x2, y2) affine and finite (lazy from_gnark values allowed); neg = 1 adds (x2, -y2)
+template <class F>
+ZKLC_HD ec_xyzz<F> ec_add_affine(const ec_xyzz<F> &p, const typename F::T &x2, const typename F::T &y2in, u32 neg) {
+    typedef typename F::T T;
+    T y2 = F::select(y2in, F::neg(y2in), neg);
+    if (ec_is_inf(p)) {
+        ec_xyzz<F> r;
+        r.X = F::reduce(x2);
+        r.Y = F::reduce(y2);
+        r.ZZ = F::one();
+        r.ZZZ = F::one();
+        return r;
+    }
+    T U2 = F::mul(x2, p.ZZ);
+    T S2 = F::mul(y2, p.ZZZ);
+    T Pp = F::sub(U2, p.X);
+    T R = F::sub(S2, p.Y);
+    if (F::is_zero(Pp)) {  // same x: P = +-Q
+        if (F::is_zero(R)) return ec_double_affine<F>(F::reduce(x2), F::reduce(y2));
+        return ec_infinity<F>();
+    }
+    T PP = F::sqr(Pp);
+    T PPP = F::mul(Pp, PP);
+    T Q = F::mul(p.X, PP);
+    ec_xyzz<F> r;
+    r.X = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+    r.Y = F::sub(F::mul(R, F::sub(Q, r.X)), F::mul(p.Y, PPP));
+    r.ZZ = F::mul(p.ZZ, PP);
+    r.ZZZ = F::mul(p.ZZZ, PPP);
+    return r;
+}
+
+// add-2008-s, general
+template <class F>
+ZKLC_HD ec_xyzz<F> ec_add(const ec_xyzz<F> &p, const ec_xyzz<F> &q) {
+    typedef typename F::T T;
+    if (ec_is_inf(p)) return q;
+    if (ec_is_inf(q)) return p;
+    T U1 = F::mul(p.X, q.ZZ);
+    T U2 = F::mul(q.X, p.ZZ);
+    T S1 = F::mul(p.Y, q.ZZZ);
+    T S2 = F::mul(q.Y, p.ZZZ);
+    T Pp = F::sub(U2, U1);
+    T R = F::sub(S2, S1);
+    if (F::is_zero(Pp)) {
+        if (F::is_zero(R)) return ec_double(p);
+        return ec_infinity<F>();
+    }
+    T PP = F::sqr(Pp);
+    T PPP = F::mul(Pp, PP);
+    T Q = F::mul(U1, PP);
+    ec_xyzz<F> r;
+    r.X = F::sub(F::sub(F::sqr(R), PPP), F::dbl(Q));
+    r.Y = F::sub(F::mul(R, F::sub(Q, r.X)), F::mul(S1, PPP));
+    r.ZZ = F::mul(F::mul(p.ZZ, q.ZZ), PP);
+    r.ZZZ = F::mul(F::mul(p.ZZZ, q.ZZZ), PPP);
+    return r;
+}
+
+// affine (x, y) = (X / ZZ, Y / ZZZ) in gnark Montgomery words (2 * 8 * LIMBS/10 words); returns 1 for infinity (zeros)
+template <class F>
+ZKLC_HD u32 ec_to_affine_gnark(u32 *out, const ec_xyzz<F> &p) {
+    typedef typename F::T T;
+    const int W = 8 * F::LIMBS / 10;
+    if (ec_is_inf(p)) {
+        for (int i = 0; i < 2 * W; i++) out[i] = 0;
+        return 1;
+    }
+    // one inversion: (ZZ * ZZZ)^-1 -> 1/ZZ = inv * ZZZ, 1/ZZZ = inv * ZZ
+    T inv = F::inv(F::mul(p.ZZ, p.ZZZ));
+    T x = F::mul(p.X, F::mul(inv, p.ZZZ));
+    T y = F::mul(p.Y, F::mul(inv, p.ZZ));
+    F::to_gnark(out, x);
+    F::to_gnark(out + W, y);
+    return 0;
+}

@@ -1,8 +1,9 @@
-// BN254 G1 multi-scalar multiplication (Pippenger bucket method) for gfx950 + C ABI.
+// BN254 G1 and G2 multi-scalar multiplication (Pippenger bucket method) for gfx950 + C ABI.
 //
-// Replaces gnark-crypto's `bn254.G1Affine.MultiExp` (un-vendored,
+// Replaces gnark-crypto's `bn254.G1Affine.MultiExp` / `bn254.G2Affine.MultiExp` (un-vendored,
 // gnark-plonky2-verifier/go.mod:9) under `groth16.Prove`
-// (gnark-plonky2-verifier/cmd/web-api.go:77, tests/prover_test.go:64).
+// (gnark-plonky2-verifier/cmd/web-api.go:77, tests/prover_test.go:64).  Every kernel is a template over the
+// coordinate field (Fp for G1, Fp2 for G2; bn254_ec.cuh) -- the pipeline is identical.
 //
 // Pipeline (all on the device, no host round trips):
 //   1. signed c-bit digits of every scalar; histogram of (window, |digit|) keys
@@ -18,6 +19,7 @@
 // Curve additions are order-independent as group elements, so the (arbitrary) order of the
 // atomics in steps 1 and 3 never changes the affine result.
 #include "bn254_g1.cuh"
+#include "bn254_g2.cuh"
 #include "zklc_internal.h"
 
 #define MSM_MAX_WINDOWS 32
@@ -50,19 +52,25 @@ ZKLC_D int msm_digit(const u32 *sw, u32 w, u32 c, u32 &carry) {
     return (int)raw;
 }
 
+template <int AFF>  // u64 words per affine point: 8 (G1) or 16 (G2)
 ZKLC_D bool msm_point_is_inf(const u64 *points, u32 i) {
-    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(points + (size_t)i * 8);
-    ulonglong2 a = p[0], b = p[1], c = p[2], d = p[3];
-    return (a.x | a.y | b.x | b.y | c.x | c.y | d.x | d.y) == 0;  // gnark encodes infinity as (0, 0)
+    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(points + (size_t)i * AFF);
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < AFF / 2; k++) {
+        ulonglong2 a = p[k];
+        acc |= a.x | a.y;
+    }
+    return acc == 0;  // gnark encodes infinity as all-zero coordinates
 }
 
-template <bool SCATTER>
+template <bool SCATTER, int AFF>
 __global__ void __launch_bounds__(256)
 msm_digits_kernel(const u64 *__restrict__ points, const u64 *__restrict__ scalars, msm_plan pl, u32 *__restrict__ counts,
                   const u32 *__restrict__ offsets, u32 *__restrict__ cursor, u32 *__restrict__ entries) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= pl.n) return;
-    if (msm_point_is_inf(points, i)) return;
+    if (msm_point_is_inf<AFF>(points, i)) return;
     u32 sw[8];
     msm_load_scalar(scalars, i, sw);
     u32 carry = 0;
@@ -136,37 +144,49 @@ __global__ void __launch_bounds__(256) msm_scan_add_kernel(u32 *out, const u32 *
     if (i < n) out[i] += block_sums[i / SCAN_ITEMS];
 }
 
-// ---- bucket accumulation
-ZKLC_D void msm_load_point(const u64 *points, u32 idx, fp &x, fp &y) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(points + (size_t)idx * 8);
-    uint4 a = p[0], b = p[1], c = p[2], d = p[3];
-    u32 wx[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    u32 wy[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-    x = fp_from_gnark(wx);
-    y = fp_from_gnark(wy);
+// ---- bucket accumulation (template over the coordinate field F: FpField = G1, Fp2Field = G2)
+template <class F>
+struct msm_cfg {
+    static constexpr int XYZZ = 4 * F::LIMBS;            // i32 words of a stored XYZZ point
+    static constexpr int AFF = 2 * 4 * F::LIMBS / 10;    // u64 words of an affine point at the ABI
+    static constexpr int BLOCK = F::LIMBS == 10 ? 256 : 128;  // workgroup size of the LDS tree reductions (<= 40 KiB of LDS)
+};
+
+template <class F>
+ZKLC_D void msm_load_point(const u64 *points, u32 idx, typename F::T &x, typename F::T &y) {
+    const int W = msm_cfg<F>::AFF;  // u32 words per coordinate
+    const uint4 *p = reinterpret_cast<const uint4 *>(points + (size_t)idx * W);
+    u32 w[2 * W];
+#pragma unroll
+    for (int k = 0; k < W / 2; k++) {
+        uint4 a = p[k];
+        w[4 * k] = a.x;
+        w[4 * k + 1] = a.y;
+        w[4 * k + 2] = a.z;
+        w[4 * k + 3] = a.w;
+    }
+    x = F::from_gnark(w);
+    y = F::from_gnark(w + W);
 }
 
-ZKLC_D void msm_store_xyzz(i32 *dst, const g1_xyzz &p) {
-#pragma unroll
-    for (int k = 0; k < 10; k++) {
-        dst[k] = p.X.v[k];
-        dst[10 + k] = p.Y.v[k];
-        dst[20 + k] = p.ZZ.v[k];
-        dst[30 + k] = p.ZZZ.v[k];
-    }
+template <class F>
+ZKLC_D void msm_store_xyzz(i32 *dst, const ec_xyzz<F> &p) {
+    F::store(dst, p.X);
+    F::store(dst + F::LIMBS, p.Y);
+    F::store(dst + 2 * F::LIMBS, p.ZZ);
+    F::store(dst + 3 * F::LIMBS, p.ZZZ);
 }
-ZKLC_D g1_xyzz msm_load_xyzz(const i32 *src) {
-    g1_xyzz p;
-#pragma unroll
-    for (int k = 0; k < 10; k++) {
-        p.X.v[k] = src[k];
-        p.Y.v[k] = src[10 + k];
-        p.ZZ.v[k] = src[20 + k];
-        p.ZZZ.v[k] = src[30 + k];
-    }
+template <class F>
+ZKLC_D ec_xyzz<F> msm_load_xyzz(const i32 *src) {
+    ec_xyzz<F> p;
+    p.X = F::load(src);
+    p.Y = F::load(src + F::LIMBS);
+    p.ZZ = F::load(src + 2 * F::LIMBS);
+    p.ZZZ = F::load(src + 3 * F::LIMBS);
     return p;
 }
 
+template <class F>
 __global__ void __launch_bounds__(64)
 msm_bucket_sum_kernel(const u64 *__restrict__ points, const u32 *__restrict__ entries, const u32 *__restrict__ offsets,
                       const u32 *__restrict__ counts, msm_plan pl, i32 *__restrict__ buckets, u32 *__restrict__ heavy_list,
@@ -174,7 +194,7 @@ msm_bucket_sum_kernel(const u64 *__restrict__ points, const u32 *__restrict__ en
     u32 key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= pl.total_buckets) return;
     u32 cnt = counts[key];
-    g1_xyzz acc = g1_infinity();
+    ec_xyzz<F> acc = ec_infinity<F>();
     if (cnt > MSM_HEAVY) {
         u32 slot = atomicAdd(heavy_count, 1u);
         if (slot < MSM_MAX_HEAVY) {
@@ -186,98 +206,110 @@ msm_bucket_sum_kernel(const u64 *__restrict__ points, const u32 *__restrict__ en
     u32 beg = offsets[key];
     for (u32 e = 0; e < cnt; e++) {
         u32 ent = entries[beg + e];
-        fp x, y;
-        msm_load_point(points, ent >> 1, x, y);
-        acc = g1_add_affine(acc, x, y, ent & 1);
+        typename F::T x, y;
+        msm_load_point<F>(points, ent >> 1, x, y);
+        acc = ec_add_affine<F>(acc, x, y, ent & 1);
     }
-    msm_store_xyzz(buckets + (size_t)key * 40, acc);
+    msm_store_xyzz<F>(buckets + (size_t)key * msm_cfg<F>::XYZZ, acc);
 }
 
-// LDS tree reduction of one XYZZ point per thread (256 threads); result in thread 0
-ZKLC_D g1_xyzz msm_block_reduce(g1_xyzz acc, i32 *lds /* 256 * 40 words */) {
-    for (u32 stride = 128; stride >= 1; stride >>= 1) {
-        if (threadIdx.x >= stride && threadIdx.x < 2 * stride) msm_store_xyzz(lds + (threadIdx.x - stride) * 40, acc);
+// LDS tree reduction of one XYZZ point per thread (BLOCK threads); result in thread 0
+template <class F>
+ZKLC_D ec_xyzz<F> msm_block_reduce(ec_xyzz<F> acc, i32 *lds /* BLOCK * XYZZ words */) {
+    const int XY = msm_cfg<F>::XYZZ;
+    for (u32 stride = msm_cfg<F>::BLOCK / 2; stride >= 1; stride >>= 1) {
+        if (threadIdx.x >= stride && threadIdx.x < 2 * stride) msm_store_xyzz<F>(lds + (threadIdx.x - stride) * XY, acc);
         __syncthreads();
-        if (threadIdx.x < stride) acc = g1_add(acc, msm_load_xyzz(lds + threadIdx.x * 40));
+        if (threadIdx.x < stride) acc = ec_add(acc, msm_load_xyzz<F>(lds + threadIdx.x * XY));
         __syncthreads();
     }
     return acc;
 }
 
-__global__ void __launch_bounds__(256)
+template <class F>
+__global__ void __launch_bounds__(msm_cfg<F>::BLOCK)
 msm_heavy_bucket_kernel(const u64 *__restrict__ points, const u32 *__restrict__ entries, const u32 *__restrict__ offsets,
                         const u32 *__restrict__ counts, i32 *__restrict__ buckets, const u32 *__restrict__ heavy_list,
                         const u32 *__restrict__ heavy_count) {
-    __shared__ i32 lds[256 * 40];
+    __shared__ i32 lds[msm_cfg<F>::BLOCK * msm_cfg<F>::XYZZ];
     u32 nheavy = *heavy_count;
     if (nheavy > MSM_MAX_HEAVY) nheavy = MSM_MAX_HEAVY;
     if (blockIdx.x >= nheavy) return;
     u32 key = heavy_list[blockIdx.x];
     u32 beg = offsets[key], cnt = counts[key];
-    g1_xyzz acc = g1_infinity();
-    for (u32 e = threadIdx.x; e < cnt; e += 256) {
+    ec_xyzz<F> acc = ec_infinity<F>();
+    for (u32 e = threadIdx.x; e < cnt; e += msm_cfg<F>::BLOCK) {
         u32 ent = entries[beg + e];
-        fp x, y;
-        msm_load_point(points, ent >> 1, x, y);
-        acc = g1_add_affine(acc, x, y, ent & 1);
+        typename F::T x, y;
+        msm_load_point<F>(points, ent >> 1, x, y);
+        acc = ec_add_affine<F>(acc, x, y, ent & 1);
     }
-    acc = msm_block_reduce(acc, lds);
-    if (threadIdx.x == 0) msm_store_xyzz(buckets + (size_t)key * 40, acc);
+    acc = msm_block_reduce<F>(acc, lds);
+    if (threadIdx.x == 0) msm_store_xyzz<F>(buckets + (size_t)key * msm_cfg<F>::XYZZ, acc);
 }
 
 // k * p for a small k (k < 2^31), double-and-add
-ZKLC_D g1_xyzz msm_small_mul(const g1_xyzz &p, u32 k) {
-    g1_xyzz r = g1_infinity();
+template <class F>
+ZKLC_D ec_xyzz<F> msm_small_mul(const ec_xyzz<F> &p, u32 k) {
+    ec_xyzz<F> r = ec_infinity<F>();
     if (k == 0) return r;
     for (int b = 31 - __clz(k); b >= 0; b--) {
-        r = g1_double(r);
-        if ((k >> b) & 1) r = g1_add(r, p);
+        r = ec_double(r);
+        if ((k >> b) & 1) r = ec_add(r, p);
     }
     return r;
 }
 
 // one lane per segment of MSM_SEG buckets: sum_{b in seg} (b + 1) B_b  (b = bucket index within the window)
+template <class F>
 __global__ void __launch_bounds__(64) msm_segment_kernel(const i32 *__restrict__ buckets, msm_plan pl, i32 *__restrict__ seg_out) {
+    const int XY = msm_cfg<F>::XYZZ;
     u32 seg_per_window = (pl.buckets_per_window + MSM_SEG - 1) / MSM_SEG;
     u32 s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= seg_per_window * pl.windows) return;
     u32 w = s / seg_per_window, si = s % seg_per_window;
     u32 lo = si * MSM_SEG, hi = lo + MSM_SEG < pl.buckets_per_window ? lo + MSM_SEG : pl.buckets_per_window;
-    g1_xyzz S = g1_infinity(), T = g1_infinity();
+    ec_xyzz<F> S = ec_infinity<F>(), T = ec_infinity<F>();
     for (u32 b = hi; b-- > lo;) {
-        S = g1_add(S, msm_load_xyzz(buckets + ((size_t)w * pl.buckets_per_window + b) * 40));
-        T = g1_add(T, S);
+        S = ec_add(S, msm_load_xyzz<F>(buckets + ((size_t)w * pl.buckets_per_window + b) * XY));
+        T = ec_add(T, S);
     }
     // T = sum (b - lo + 1) B_b ; add lo * S
-    if (lo) T = g1_add(T, msm_small_mul(S, lo));
-    msm_store_xyzz(seg_out + (size_t)s * 40, T);
+    if (lo) T = ec_add(T, msm_small_mul<F>(S, lo));
+    msm_store_xyzz<F>(seg_out + (size_t)s * XY, T);
 }
 
 // one workgroup per window: sum of its segment results
-__global__ void __launch_bounds__(256) msm_window_kernel(const i32 *__restrict__ seg_out, msm_plan pl, i32 *__restrict__ win_out) {
-    __shared__ i32 lds[256 * 40];
+template <class F>
+__global__ void __launch_bounds__(msm_cfg<F>::BLOCK) msm_window_kernel(const i32 *__restrict__ seg_out, msm_plan pl, i32 *__restrict__ win_out) {
+    const int XY = msm_cfg<F>::XYZZ;
+    __shared__ i32 lds[msm_cfg<F>::BLOCK * msm_cfg<F>::XYZZ];
     u32 seg_per_window = (pl.buckets_per_window + MSM_SEG - 1) / MSM_SEG;
     u32 w = blockIdx.x;
-    g1_xyzz acc = g1_infinity();
-    for (u32 s = threadIdx.x; s < seg_per_window; s += 256) acc = g1_add(acc, msm_load_xyzz(seg_out + ((size_t)w * seg_per_window + s) * 40));
-    acc = msm_block_reduce(acc, lds);
-    if (threadIdx.x == 0) msm_store_xyzz(win_out + (size_t)w * 40, acc);
+    ec_xyzz<F> acc = ec_infinity<F>();
+    for (u32 s = threadIdx.x; s < seg_per_window; s += msm_cfg<F>::BLOCK)
+        acc = ec_add(acc, msm_load_xyzz<F>(seg_out + ((size_t)w * seg_per_window + s) * XY));
+    acc = msm_block_reduce<F>(acc, lds);
+    if (threadIdx.x == 0) msm_store_xyzz<F>(win_out + (size_t)w * XY, acc);
 }
 
-// result = sum_w 2^(c w) W_w ; affine output in gnark Montgomery words (x: 4 u64, y: 4 u64) + infinity flag
-__global__ void __launch_bounds__(256) msm_final_kernel(const i32 *__restrict__ win_out, msm_plan pl, u64 *__restrict__ out_affine, u32 *__restrict__ out_inf) {
-    __shared__ i32 lds[256 * 40];
-    g1_xyzz acc = g1_infinity();
+// result = sum_w 2^(c w) W_w ; affine output in gnark Montgomery words + infinity flag
+template <class F>
+__global__ void __launch_bounds__(msm_cfg<F>::BLOCK) msm_final_kernel(const i32 *__restrict__ win_out, msm_plan pl, u64 *__restrict__ out_affine, u32 *__restrict__ out_inf) {
+    const int XY = msm_cfg<F>::XYZZ;
+    __shared__ i32 lds[msm_cfg<F>::BLOCK * msm_cfg<F>::XYZZ];
+    ec_xyzz<F> acc = ec_infinity<F>();
     if (threadIdx.x < pl.windows) {
-        acc = msm_load_xyzz(win_out + (size_t)threadIdx.x * 40);
+        acc = msm_load_xyzz<F>(win_out + (size_t)threadIdx.x * XY);
         u32 dbl = pl.c * threadIdx.x;
-        for (u32 k = 0; k < dbl; k++) acc = g1_double(acc);
+        for (u32 k = 0; k < dbl; k++) acc = ec_double(acc);
     }
-    acc = msm_block_reduce(acc, lds);
+    acc = msm_block_reduce<F>(acc, lds);
     if (threadIdx.x == 0) {
-        u32 o[16];
-        u32 inf = g1_to_affine_gnark(o, acc);
-        for (int k = 0; k < 8; k++) out_affine[k] = (u64)o[2 * k] | ((u64)o[2 * k + 1] << 32);
+        const int W = 2 * msm_cfg<F>::AFF;  // u32 words of the affine output
+        u32 o[W];
+        u32 inf = ec_to_affine_gnark(o, acc);
+        for (int k = 0; k < W / 2; k++) out_affine[k] = (u64)o[2 * k] | ((u64)o[2 * k + 1] << 32);
         *out_inf = inf;
     }
 }
@@ -291,23 +323,28 @@ static u32 msm_pick_window(u64 n) {
     return 4;
 }
 
-extern "C" uint64_t zklc_bn254_g1_msm_workspace_bytes(uint64_t n) {
+template <class F>
+static uint64_t msm_workspace_bytes(uint64_t n) {
+    const uint64_t XB = msm_cfg<F>::XYZZ * 4;
     u32 c = msm_pick_window(n), windows = 254 / c + 1, bpw = 1u << (c - 1), total = windows * bpw;
     u32 seg_per_window = (bpw + MSM_SEG - 1) / MSM_SEG;
     uint64_t b = 0;
     b += (uint64_t)total * 4 * 3;                       // counts, offsets, cursor
     b += ((uint64_t)total / SCAN_ITEMS + 2) * 4;        // scan block sums
     b += n * windows * 4;                               // entries
-    b += (uint64_t)total * 160;                         // buckets
-    b += (uint64_t)seg_per_window * windows * 160;      // segment sums
-    b += (uint64_t)windows * 160;                       // window sums
+    b += (uint64_t)total * XB;                          // buckets
+    b += (uint64_t)seg_per_window * windows * XB;       // segment sums
+    b += (uint64_t)windows * XB;                        // window sums
     b += (MSM_MAX_HEAVY + 4) * 4;                       // heavy list + counter
     b += 256 * 16;                                      // alignment slack
     return b;
 }
 
-extern "C" int32_t zklc_bn254_g1_msm_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, const uint64_t *d_scalars, uint64_t n,
-                                         uint64_t *d_out_affine, uint32_t *d_out_inf, void *d_workspace, uint64_t workspace_bytes) {
+template <class F>
+static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, const uint64_t *d_scalars, uint64_t n,
+                           uint64_t *d_out_affine, uint32_t *d_out_inf, void *d_workspace, uint64_t workspace_bytes) {
+    const int AFF = msm_cfg<F>::AFF;
+    const size_t XB = msm_cfg<F>::XYZZ * 4;
     if (!ctx || !d_out_affine || !d_out_inf || (n && (!d_points || !d_scalars)) || n >= (1ULL << 31)) return ZKLC_ERR_INVALID_ARG;
     if (((uintptr_t)d_points | (uintptr_t)d_scalars) & 15) return ZKLC_ERR_INVALID_ARG;
     ZKLC_HIP(ctx, hipSetDevice(ctx->device));
@@ -318,7 +355,7 @@ extern "C" int32_t zklc_bn254_g1_msm_dev(zklc_ctx *ctx, void *stream, const uint
     pl.windows = 254 / pl.c + 1;
     pl.buckets_per_window = 1u << (pl.c - 1);
     pl.total_buckets = pl.windows * pl.buckets_per_window;
-    if (workspace_bytes < zklc_bn254_g1_msm_workspace_bytes(n) || !d_workspace) return ZKLC_ERR_INVALID_ARG;
+    if (workspace_bytes < msm_workspace_bytes<F>(n) || !d_workspace) return ZKLC_ERR_INVALID_ARG;
     u32 seg_per_window = (pl.buckets_per_window + MSM_SEG - 1) / MSM_SEG;
     // carve the workspace (256-byte aligned pieces)
     char *p = (char *)d_workspace;
@@ -336,55 +373,78 @@ extern "C" int32_t zklc_bn254_g1_msm_dev(zklc_ctx *ctx, void *stream, const uint
     u32 *block_sums = (u32 *)take((size_t)(nblocks + 1) * 4);
     u32 *heavy_list = (u32 *)take(MSM_MAX_HEAVY * 4);
     u32 *entries = (u32 *)take((size_t)n * pl.windows * 4 + 4);
-    i32 *buckets = (i32 *)take((size_t)pl.total_buckets * 160);
-    i32 *seg_out = (i32 *)take((size_t)seg_per_window * pl.windows * 160);
-    i32 *win_out = (i32 *)take((size_t)pl.windows * 160);
+    i32 *buckets = (i32 *)take((size_t)pl.total_buckets * XB);
+    i32 *seg_out = (i32 *)take((size_t)seg_per_window * pl.windows * XB);
+    i32 *win_out = (i32 *)take((size_t)pl.windows * XB);
+    const int BLK = msm_cfg<F>::BLOCK;
 
     ZKLC_HIP(ctx, hipMemsetAsync(counts, 0, zero_bytes, st));
     u32 gpts = (pl.n + 255) / 256;
     if (pl.n) {
-        hipLaunchKernelGGL(msm_digits_kernel<false>, dim3(gpts), dim3(256), 0, st, d_points, d_scalars, pl, counts, (const u32 *)nullptr,
-                           cursor, entries);
+        hipLaunchKernelGGL((msm_digits_kernel<false, AFF>), dim3(gpts), dim3(256), 0, st, d_points, d_scalars, pl, counts,
+                           (const u32 *)nullptr, cursor, entries);
     }
     hipLaunchKernelGGL(msm_scan_block_kernel, dim3(nblocks), dim3(256), 0, st, (const u32 *)counts, offsets, block_sums, pl.total_buckets);
     hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(1), dim3(256), 0, st, block_sums, nblocks);
     hipLaunchKernelGGL(msm_scan_add_kernel, dim3((pl.total_buckets + 255) / 256), dim3(256), 0, st, offsets, (const u32 *)block_sums,
                        pl.total_buckets);
     if (pl.n) {
-        hipLaunchKernelGGL(msm_digits_kernel<true>, dim3(gpts), dim3(256), 0, st, d_points, d_scalars, pl, counts, (const u32 *)offsets,
-                           cursor, entries);
+        hipLaunchKernelGGL((msm_digits_kernel<true, AFF>), dim3(gpts), dim3(256), 0, st, d_points, d_scalars, pl, counts,
+                           (const u32 *)offsets, cursor, entries);
     }
-    hipLaunchKernelGGL(msm_bucket_sum_kernel, dim3((pl.total_buckets + 63) / 64), dim3(64), 0, st, d_points, (const u32 *)entries,
+    hipLaunchKernelGGL(msm_bucket_sum_kernel<F>, dim3((pl.total_buckets + 63) / 64), dim3(64), 0, st, d_points, (const u32 *)entries,
                        (const u32 *)offsets, (const u32 *)counts, pl, buckets, heavy_list, heavy_count);
-    hipLaunchKernelGGL(msm_heavy_bucket_kernel, dim3(MSM_MAX_HEAVY), dim3(256), 0, st, d_points, (const u32 *)entries, (const u32 *)offsets,
-                       (const u32 *)counts, buckets, (const u32 *)heavy_list, (const u32 *)heavy_count);
-    hipLaunchKernelGGL(msm_segment_kernel, dim3((seg_per_window * pl.windows + 63) / 64), dim3(64), 0, st, (const i32 *)buckets, pl, seg_out);
-    hipLaunchKernelGGL(msm_window_kernel, dim3(pl.windows), dim3(256), 0, st, (const i32 *)seg_out, pl, win_out);
-    hipLaunchKernelGGL(msm_final_kernel, dim3(1), dim3(256), 0, st, (const i32 *)win_out, pl, d_out_affine, d_out_inf);
+    hipLaunchKernelGGL(msm_heavy_bucket_kernel<F>, dim3(MSM_MAX_HEAVY), dim3(BLK), 0, st, d_points, (const u32 *)entries,
+                       (const u32 *)offsets, (const u32 *)counts, buckets, (const u32 *)heavy_list, (const u32 *)heavy_count);
+    hipLaunchKernelGGL(msm_segment_kernel<F>, dim3((seg_per_window * pl.windows + 63) / 64), dim3(64), 0, st, (const i32 *)buckets, pl,
+                       seg_out);
+    hipLaunchKernelGGL(msm_window_kernel<F>, dim3(pl.windows), dim3(BLK), 0, st, (const i32 *)seg_out, pl, win_out);
+    hipLaunchKernelGGL(msm_final_kernel<F>, dim3(1), dim3(BLK), 0, st, (const i32 *)win_out, pl, d_out_affine, d_out_inf);
     ZKLC_HIP(ctx, hipGetLastError());
     return ZKLC_OK;
 }
 
-extern "C" int32_t zklc_bn254_g1_msm(zklc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, uint64_t n, uint64_t *out_affine,
-                                     uint32_t *out_is_infinity) {
+template <class F>
+static int32_t msm_run_host(zklc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, uint64_t n, uint64_t *out_affine,
+                            uint32_t *out_is_infinity) {
+    const size_t PB = msm_cfg<F>::AFF * 8;
     if (!ctx || !out_affine || !out_is_infinity || (n && (!points || !scalars)) || n >= (1ULL << 31)) return ZKLC_ERR_INVALID_ARG;
     ZKLC_HIP(ctx, hipSetDevice(ctx->device));
     void *dp, *ds, *dw, *dout;
     int32_t rc;
-    uint64_t wb = zklc_bn254_g1_msm_workspace_bytes(n);
-    if ((rc = zklc_stage(ctx, 0, n ? n * 64 : 64, &dp))) return rc;
+    uint64_t wb = msm_workspace_bytes<F>(n);
+    if ((rc = zklc_stage(ctx, 0, n ? n * PB : PB, &dp))) return rc;
     if ((rc = zklc_stage(ctx, 1, n ? n * 32 : 32, &ds))) return rc;
     if ((rc = zklc_stage(ctx, 2, wb, &dw))) return rc;
-    if ((rc = zklc_stage(ctx, 3, 128, &dout))) return rc;
+    if ((rc = zklc_stage(ctx, 3, 256, &dout))) return rc;
     if (n) {
-        ZKLC_HIP(ctx, hipMemcpyAsync(dp, points, n * 64, hipMemcpyHostToDevice, ctx->stream));
+        ZKLC_HIP(ctx, hipMemcpyAsync(dp, points, n * PB, hipMemcpyHostToDevice, ctx->stream));
         ZKLC_HIP(ctx, hipMemcpyAsync(ds, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
     }
-    rc = zklc_bn254_g1_msm_dev(ctx, ctx->stream, (const uint64_t *)dp, (const uint64_t *)ds, n, (uint64_t *)dout,
-                               (uint32_t *)((char *)dout + 64), dw, wb);
+    rc = msm_run_dev<F>(ctx, ctx->stream, (const uint64_t *)dp, (const uint64_t *)ds, n, (uint64_t *)dout, (uint32_t *)((char *)dout + PB),
+                        dw, wb);
     if (rc) return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(out_affine, dout, 64, hipMemcpyDeviceToHost, ctx->stream));
-    ZKLC_HIP(ctx, hipMemcpyAsync(out_is_infinity, (char *)dout + 64, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, hipMemcpyAsync(out_affine, dout, PB, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, hipMemcpyAsync(out_is_infinity, (char *)dout + PB, 4, hipMemcpyDeviceToHost, ctx->stream));
     ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return ZKLC_OK;
+}
+
+extern "C" uint64_t zklc_bn254_g1_msm_workspace_bytes(uint64_t n) { return msm_workspace_bytes<FpField>(n); }
+extern "C" int32_t zklc_bn254_g1_msm_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, const uint64_t *d_scalars, uint64_t n,
+                                         uint64_t *d_out_affine, uint32_t *d_out_inf, void *d_workspace, uint64_t workspace_bytes) {
+    return msm_run_dev<FpField>(ctx, stream, d_points, d_scalars, n, d_out_affine, d_out_inf, d_workspace, workspace_bytes);
+}
+extern "C" int32_t zklc_bn254_g1_msm(zklc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, uint64_t n, uint64_t *out_affine,
+                                     uint32_t *out_is_infinity) {
+    return msm_run_host<FpField>(ctx, points, scalars, n, out_affine, out_is_infinity);
+}
+extern "C" uint64_t zklc_bn254_g2_msm_workspace_bytes(uint64_t n) { return msm_workspace_bytes<Fp2Field>(n); }
+extern "C" int32_t zklc_bn254_g2_msm_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, const uint64_t *d_scalars, uint64_t n,
+                                         uint64_t *d_out_affine, uint32_t *d_out_inf, void *d_workspace, uint64_t workspace_bytes) {
+    return msm_run_dev<Fp2Field>(ctx, stream, d_points, d_scalars, n, d_out_affine, d_out_inf, d_workspace, workspace_bytes);
+}
+extern "C" int32_t zklc_bn254_g2_msm(zklc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, uint64_t n, uint64_t *out_affine,
+                                     uint32_t *out_is_infinity) {
+    return msm_run_host<Fp2Field>(ctx, points, scalars, n, out_affine, out_is_infinity);
 }
