@@ -73,6 +73,7 @@ def test_fr_ntt_oracle_is_the_dft():
 
 
 def test_g2_group_law_basics():
+    B = bn
     assert B.g2_is_on_curve(B.G2) and B.g2_mul(B.R, B.G2) is None
     a, b = B.g2_mul(5, B.G2), B.g2_mul(7, B.G2)
     assert B.g2_add(a, b) == B.g2_mul(12, B.G2) and B.g2_add(a, B.g2_neg(a)) is None
