@@ -214,6 +214,19 @@ uint64_t zklc_bn254_g2_msm_workspace_bytes(uint64_t n);
 int32_t zklc_bn254_g2_msm_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, const uint64_t *d_scalars, uint64_t n,
                               uint64_t *d_out_affine, uint32_t *d_out_is_infinity, void *d_workspace, uint64_t workspace_bytes);
 
+/* Pairing-product checks: is_one[b] = (prod_{i<k} e(P_{b,i}, Q_{b,i}) == 1) for `batch` independent checks.
+ * Replaces gnark-crypto `bn254.PairingCheck` behind `groth16.Verify` (gnark-plonky2-verifier/cmd/web-api.go:84) and the EVM
+ * pairing precompile the reference's Solidity verifier calls (contracts/hardhat/contracts/Verifier.sol:503-548: k = 4,
+ * e(A,B) e(C,-delta) e(alpha,-beta) e(L_pub,-gamma)).  g1: batch x k affine G1 points (8 u64 each), g2: batch x k affine G2
+ * points (16 u64 each), gnark-crypto memory layout (Montgomery); an all-zero point is the point at infinity.
+ * gt_out (optional, may be NULL): the reduced pairing product of every check, 12 Fp coefficients in gnark-crypto's E12 order
+ * (C0.B0.A0, C0.B0.A1, C0.B1.A0, ... C1.B2.A1), 48 u64 per check, exact exponent (p^12 - 1)/r.  Points must be on their
+ * curves and in the r-torsion subgroups (as the precompile requires); this is not checked. */
+int32_t zklc_bn254_pairing_check(zklc_ctx *ctx, const uint64_t *g1, const uint64_t *g2, uint32_t k, uint32_t batch,
+                                 uint32_t *is_one, uint64_t *gt_out);
+int32_t zklc_bn254_pairing_check_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_g1, const uint64_t *d_g2, uint32_t k,
+                                     uint32_t batch, uint32_t *d_is_one, uint64_t *d_gt_out);
+
 /* NTT over the BN254 scalar field Fr.  Replaces gnark-crypto `fft.Domain.FFT / FFTInverse` (ecc/bn254/fr/fft, un-vendored)
  * inside `groth16.Prove` (gnark-plonky2-verifier/cmd/web-api.go:77).  data: 2^log_n elements in gnark-crypto's memory layout
  * (x * 2^256 mod r, 4 little-endian u64), transformed in place.  values[k] = sum_j coeffs[j] w^(jk), w = rootOfUnity^(2^28/n);

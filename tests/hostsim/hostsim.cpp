@@ -6,6 +6,8 @@
 #include "../../zk-light-client-implementation_amd/csrc/bn254_g1.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/poseidon_bn254.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/plonky2_gates.cuh"
+#include "../../zk-light-client-implementation_amd/csrc/bn254_pairing.cuh"
+#include "../../zk-light-client-implementation_amd/csrc/bn254_g2.cuh"
 #include <string.h>
 
 static ge_niels g_btab[ZKLC_ED_BTABLE];
@@ -189,5 +191,65 @@ void hostsim_gl2_op(int op, const u64 *a, const u64 *b, u64 e, u64 *out) {
     }
     out[0] = r.a;
     out[1] = r.b;
+}
+
+// ---- BN254 pairing (csrc/bn254_pairing.cuh).  g1: k x 16 words (x, y gnark Montgomery), g2: k x 32 words (X.A0, X.A1, Y.A0, Y.A1);
+// all-zero point = infinity (pair skipped).  stage 0: Miller loops only, 1: + final exponentiation.  gt_out: 96 words.
+u32 hostsim_pairing(const u32 *g1, const u32 *g2, u32 k, u32 stage, u32 *gt_out) {
+    fp12 f = f12_one();
+    for (u32 i = 0; i < k; i++) {
+        u32 z1 = 0, z2 = 0;
+        for (int j = 0; j < 16; j++) z1 |= g1[16 * i + j];
+        for (int j = 0; j < 32; j++) z2 |= g2[32 * i + j];
+        if (!z1 || !z2) continue;
+        fp xp = fp_reduce(fp_from_gnark(g1 + 16 * i)), yp = fp_reduce(fp_from_gnark(g1 + 16 * i + 8));
+        fp2 xq = fp2_reduce(fp2_from_gnark(g2 + 32 * i)), yq = fp2_reduce(fp2_from_gnark(g2 + 32 * i + 16));
+        bn_miller_loop(f, xp, yp, xq, yq);
+    }
+    if (stage) f = bn_final_exponentiation(f);
+    f12_to_gnark(gt_out, f);
+    return f12_is_one(f);
+}
+// tower primitives: op 0 mul, 1 sqr, 2 inv, 3 frobenius, 4 frobenius^2, 5 conj; operands/results = 96 gnark words
+void hostsim_f12_op(int op, const u32 *a96, const u32 *b96, u32 *out96) {
+    auto load = [](const u32 *w) {
+        fp12 r;
+        fp2 *x[6] = {&r.c0.b0, &r.c0.b1, &r.c0.b2, &r.c1.b0, &r.c1.b1, &r.c1.b2};
+        for (int i = 0; i < 6; i++) *x[i] = fp2_reduce(fp2_from_gnark(w + 16 * i));
+        return r;
+    };
+    fp12 a = load(a96), b = load(b96), r;
+    switch (op) {
+        case 0: r = f12_mul(a, b); break;
+        case 1: r = f12_sqr(a); break;
+        case 2: r = f12_inv(a); break;
+        case 3: r = f12_frobenius(a, 1); break;
+        case 4: r = f12_frobenius(a, 2); break;
+        default: r = f12_conj(a);
+    }
+    f12_to_gnark(out96, r);
+}
+// weak reduction on a raw limb vector (|value| <= 64p): returns the canonical value of the result as gnark-domain words
+void hostsim_fp_wred(const i32 *limbs, i32 *out_limbs, u32 *out_words) {
+    fp a;
+    for (int i = 0; i < 10; i++) a.v[i] = limbs[i];
+    fp r = fp_wred(a);
+    for (int i = 0; i < 10; i++) out_limbs[i] = r.v[i];
+    fp_freeze_words(out_words, r);
+}
+u32 hostsim_g2_op(int op, const u32 *p32, const u32 *q32, u32 *out32) {
+    g2_xyzz a;
+    a.X = fp2_reduce(fp2_from_gnark(p32));
+    a.Y = fp2_reduce(fp2_from_gnark(p32 + 16));
+    a.ZZ = a.ZZZ = fp2_one();
+    fp2 qx = fp2_from_gnark(q32), qy = fp2_from_gnark(q32 + 16);
+    g2_xyzz r;
+    switch (op) {
+        case 0: r = g2_add_affine(a, qx, qy, 0); break;
+        case 1: r = g2_add_affine(a, qx, qy, 1); break;
+        case 2: r = g2_double(a); break;
+        default: { g2_xyzz s = g2_add_affine(a, qx, qy, 0); r = g2_add(s, a); }
+    }
+    return g2_to_affine_gnark(out32, r);
 }
 }

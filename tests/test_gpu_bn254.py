@@ -296,3 +296,60 @@ def test_g2_msm_adversarial_and_linearity(zctx):
     b = B.g2_from_words([int(x) for x in zctx.bn254_g2_msm(pa, words(t))[0]])
     c = B.g2_from_words([int(x) for x in zctx.bn254_g2_msm(pa, words([(x + y) % B.R for x, y in zip(s, t)]))[0]])
     assert B.g2_add(a, b) == c and B.g2_is_on_curve(c)
+
+
+# ---------------------------------------------------------------- pairing (zklc_bn254_pairing_check)
+def _g1_words(p):
+    from oracle import bn254 as B
+    return [0] * 8 if p is None else B.to_mont_words(p[0]) + B.to_mont_words(p[1])
+
+
+def _gt_from_words(w):
+    from oracle import bn254 as B
+    v = [B.from_mont_words([int(x) for x in w[4 * i:4 * i + 4]]) for i in range(12)]
+    c = [(v[2 * i], v[2 * i + 1]) for i in range(6)]
+    return ((c[0], c[1], c[2]), (c[3], c[4], c[5]))
+
+
+def test_pairing_value_bilinearity_and_infinity(zctx):
+    from oracle import bn254 as B
+    from oracle import bn254_pairing as PR
+    p, q = B.mul(0xABCDEF, B.G1), B.g2_mul(0x13579B, B.G2)
+    checks = [[(p, q)], [(p, q), (B.neg(p), q)], [(None, q), (p, None)],
+              [(B.mul(5, B.G1), B.G2), (B.neg(B.G1), B.g2_mul(5, B.G2))], [(B.G1, B.G2), (B.G1, B.G2)]]
+    k = 2
+    g1 = np.array([[_g1_words(c[i][0]) if i < len(c) else [0] * 8 for i in range(k)] for c in checks], dtype=np.uint64)
+    g2 = np.array([[B.g2_to_words(c[i][1]) if i < len(c) else [0] * 16 for i in range(k)] for c in checks], dtype=np.uint64)
+    ok, gt = zctx.bn254_pairing_check(g1, g2, k, want_gt=True)
+    assert ok.tolist() == [0, 1, 1, 1, 0]
+    assert _gt_from_words(gt[0]) == PR.pairing(p, q)
+    assert _gt_from_words(gt[1]) == PR.F12_ONE
+    e = PR.pairing(B.G1, B.G2)
+    assert _gt_from_words(gt[4]) == PR.f12_mul(e, e)
+
+
+def test_reference_groth16_kat_on_the_gpu(zctx):
+    """the reference's Groth16 proof (contracts/hardhat/test/proof_with_witness.json) verifies against the verifying key of
+    Verifier.sol:57-83 through the GPU pairing; the tampered vectors of test/verify.ts do not; batch of 256 checks"""
+    from conftest import load_golden
+    from oracle import bn254 as B
+    from test_oracle_pairing import kat_vk
+    j = load_golden("groth16_kat.json")
+    vk = kat_vk(j)
+
+    def pairs(proof, inputs):
+        a = (proof[0], proof[1])
+        b = ((proof[3], proof[2]), (proof[5], proof[4]))
+        c = (proof[6], proof[7])
+        l = vk["ic"][0]
+        for s, pt in zip(inputs, vk["ic"][1:]):
+            l = B.add(l, B.mul(s, pt))
+        return [(a, b), (c, vk["delta_neg"]), (vk["alpha"], vk["beta_neg"]), (l, vk["gamma_neg"])]
+    proof, inputs = [int(x) for x in j["proof"]], [int(x) for x in j["inputs"]]
+    good = pairs(proof, inputs)
+    bad_in = pairs(proof, [int(x) for x in j["incorrect_inputs"]])
+    checks = [good, bad_in] * 128
+    g1 = np.array([[_g1_words(p) for p, _ in c] for c in checks], dtype=np.uint64)
+    g2 = np.array([[B.g2_to_words(q) for _, q in c] for c in checks], dtype=np.uint64)
+    ok, _ = zctx.bn254_pairing_check(g1, g2, 4)
+    assert ok.tolist() == [1, 0] * 128

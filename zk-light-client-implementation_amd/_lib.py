@@ -53,6 +53,9 @@ _SIGS = {
     "zklc_bn254_g2_msm_workspace_bytes": (ctypes.c_uint64, [ctypes.c_uint64]),
     "zklc_bn254_g2_msm_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _u8p, _u8p,
                                                ctypes.c_uint64]),
+    "zklc_bn254_pairing_check": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint32, ctypes.c_uint32, _u8p, _u8p]),
+    "zklc_bn254_pairing_check_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint32, ctypes.c_uint32,
+                                                      _u8p, _u8p]),
     "zklc_bn254_fr_ntt": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]),
     "zklc_bn254_fr_ntt_workspace_bytes": (ctypes.c_uint64, [ctypes.c_uint32]),
     "zklc_bn254_fr_ntt_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,

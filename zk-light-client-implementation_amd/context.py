@@ -233,6 +233,18 @@ class Context:
                                                 pts.shape[0], out.ctypes.data, ctypes.addressof(inf)))
         return out, bool(inf.value)
 
+    def bn254_pairing_check(self, g1, g2, k, want_gt=False):
+        """g1: uint64 [batch, k, 8], g2: uint64 [batch, k, 16] (gnark Montgomery affine) -> (is_one uint32[batch], gt uint64[batch, 48])"""
+        a = np.ascontiguousarray(g1, dtype=np.uint64).reshape(-1, k, 8)
+        b = np.ascontiguousarray(g2, dtype=np.uint64).reshape(-1, k, 16)
+        batch = a.shape[0]
+        assert b.shape[0] == batch
+        ok = np.zeros(batch, dtype=np.uint32)
+        gt = np.zeros((batch, 48), dtype=np.uint64) if want_gt else None
+        self._check(self._lib.zklc_bn254_pairing_check(self._h, a.ctypes.data, b.ctypes.data, k, batch, ok.ctypes.data,
+                                                       gt.ctypes.data if want_gt else None))
+        return ok, gt
+
     def bn254_fr_ntt(self, data, flags=0, coset=0):
         """data: uint64 [n, 4] Fr elements in gnark Montgomery layout -> transformed copy"""
         a = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, 4).copy()
