@@ -247,7 +247,80 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
         del coeffs, lde, tree
         torch.cuda.empty_cache()
         res["prove"] = run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max)
+        if with_cpu and "cpu_baseline" in res["lde"] and "cpu_baseline" in res["merkle"]:
+            # CPU lower bound of ONE Ed25519-shape proof with the oracle's C port: only its wires commitment
+            # (LDE of 234 columns + Merkle tree over 2^20 leaves), extrapolated from the two bounded samples above
+            lde_s = alg / 1e9 / res["lde"]["cpu_baseline"]["value"]
+            mk_s = N / 1e6 / res["merkle"]["cpu_baseline"]["value"]
+            gpu_ms = res["prove"]["ed25519_2p17x234"]["ms_per_proof"]
+            res["prove"]["ed25519_2p17x234"]["cpu_baseline"] = {
+                "value": 1.0 / (lde_s + mk_s), "unit": "proofs/s (upper bound)", "cores": threads, "kind": "port",
+                "sample": "wires commitment only (coset LDE %.1f s + Poseidon Merkle tree %.1f s, extrapolated from the lde / merkle "
+                          "samples above, oracle/c/goldilocks_oracle.c): a LOWER bound of the time of one CPU proof with this port; "
+                          "the reference's Rust prover cannot be built here" % (lde_s, mk_s),
+                "gpu_full_proof_vs_cpu_commit_only": (lde_s + mk_s) * 1e3 / gpu_ms}
+    if not args.no_bn254_extras:
+        res["bn254_extras"] = run_bn254_extras(ctx, dev, reduce_max, barrier, world)
     return res
+
+
+def run_bn254_extras(ctx, dev, reduce_max, barrier, world):
+    """G2 MSM, Fr coset NTT and Groth16-shaped pairing checks (the rest of the Groth16 wrap)"""
+    import torch
+    import zklc_amd
+    from oracle import bn254 as B
+    lib = zklc_amd.load()
+    sp = ctx.stream_ptr()
+    out = {}
+
+    def timed(fn, reps=3):
+        fn()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        barrier()
+        return reduce_max((time.perf_counter() - t0) / reps * 1e3)
+    rng = np.random.default_rng(3)
+    # G2 MSM 2^18 (256 distinct points tiled: generating G2 points on the host is slow)
+    cur, step, pts = B.g2_mul(12345, B.G2), B.g2_mul(777, B.G2), []
+    for _ in range(256):
+        pts.append(B.g2_to_words(cur))
+        cur = B.g2_add(cur, step)
+    n = 1 << 18
+    d_p = torch.from_numpy(np.tile(np.array(pts, dtype=np.uint64), (n // 256, 1)).view(np.int64)).to(dev)
+    sc = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64((1 << 60) - 1)
+    d_s = torch.from_numpy(sc.view(np.int64)).to(dev)
+    wb = int(lib.zklc_bn254_g2_msm_workspace_bytes(n))
+    d_w = torch.empty(wb, dtype=torch.uint8, device=dev)
+    d_o = torch.zeros(17, dtype=torch.int64, device=dev)
+    ms = timed(lambda: ctx._check(lib.zklc_bn254_g2_msm_dev(ctx._h, sp, d_p.data_ptr(), d_s.data_ptr(), n, d_o.data_ptr(),
+                                                            d_o.data_ptr() + 128, d_w.data_ptr(), wb)))
+    out["g2_msm_2p18"] = {"ms": ms, "value": world * n / ms / 1e3, "unit": "Melem/s"}
+    del d_p, d_s, d_w
+    # Fr coset NTT 2^22
+    n = 1 << 22
+    a = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64)
+    a[:, 3] &= np.uint64((1 << 60) - 1)
+    d_a = torch.from_numpy(a.view(np.int64)).to(dev)
+    wb = int(lib.zklc_bn254_fr_ntt_workspace_bytes(22))
+    d_w = torch.empty(wb, dtype=torch.uint8, device=dev)
+    ms = timed(lambda: ctx._check(lib.zklc_bn254_fr_ntt_dev(ctx._h, sp, d_a.data_ptr(), 22, 0, 1, d_w.data_ptr(), wb)))
+    out["fr_coset_ntt_2p22"] = {"ms": ms, "value": world * 64.0 * n / ms / 1e6, "unit": "GB/s (64 B/element algorithmic)"}
+    del d_a, d_w
+    # pairing checks, k = 4 (Groth16 verification shape)
+    p, q = B.mul(0xABCDEF, B.G1), B.g2_mul(0x13579B, B.G2)
+    one = [(p, q), (B.neg(p), q), (B.mul(5, B.G1), B.G2), (B.neg(B.G1), B.g2_mul(5, B.G2))]
+    checks = 4096
+    g1 = np.array([[B.to_mont_words(x[0]) + B.to_mont_words(x[1]) for x, _ in one]] * checks, dtype=np.uint64)
+    g2 = np.array([[B.g2_to_words(y) for _, y in one]] * checks, dtype=np.uint64)
+    d1, d2 = torch.from_numpy(g1.view(np.int64)).to(dev), torch.from_numpy(g2.view(np.int64)).to(dev)
+    d_r = torch.zeros(checks, dtype=torch.int32, device=dev)
+    ms = timed(lambda: ctx._check(lib.zklc_bn254_pairing_check_dev(ctx._h, sp, d1.data_ptr(), d2.data_ptr(), 4, checks, d_r.data_ptr(), None)), reps=2)
+    assert int(d_r.sum()) == checks
+    out["pairing_checks_k4_x4096"] = {"ms": ms, "value": world * checks / ms * 1e3, "unit": "checks/s"}
+    return out
 
 
 def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
@@ -373,6 +446,7 @@ def main():
     ap.add_argument("--no-stages", action="store_true", help="only the headline C2 measurement")
     ap.add_argument("--msm-log", type=int, default=22, help="log2 of the MSM size per GPU")
     ap.add_argument("--no-prove", action="store_true", help="skip the plonky2 proof stage")
+    ap.add_argument("--no-bn254-extras", action="store_true", help="skip the G2 MSM / Fr NTT / pairing stage")
     ap.add_argument("--prove-streams", type=int, default=4, help="proofs in flight per GPU in the Block_i stage")
     args = ap.parse_args()
 
