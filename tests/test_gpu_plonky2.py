@@ -112,3 +112,23 @@ def test_reference_sized_proofs_verify(zctx, shape, degree_bits, hasher):
     proof["proof"]["openings"]["wires"][7][0] ^= 1
     with pytest.raises(AssertionError):
         V.verify(json.loads(json.dumps(proof)), prover.verifier_data(), common)
+
+
+def test_reference_sha512_circuit_proof(zctx):
+    """the reference's SHA-512 circuit (crypto/plonky2_sha512/src/circuit.rs, restated in zklc_amd/plonky2/sha512.py) with a
+    real witness -- SHA-512 of a 105-byte NEAR Ed25519 preimage -- proven on the GPU; the verifier restatement accepts the
+    proof and its 512 public inputs are the hashlib digest bits"""
+    import hashlib
+    from zklc_amd.plonky2 import sha512
+    msg = bytes((11 * i + 5) & 0xFF for i in range(105))
+    b = CircuitBuilder()
+    message, digest = sha512.sha512_circuit(b, 8 * len(msg))
+    for t in digest:
+        b.register_public_input(t)
+    data = b.build()
+    wires, pis = data.generate_witness(dict(zip(message, sha512.array_to_bits(msg))))
+    prover = data.prover(zctx, HASH_GL)
+    proof = prover.prove(wires, pis)
+    assert proof["public_inputs"] == sha512.array_to_bits(hashlib.sha512(msg).digest())
+    V.verify(json.loads(json.dumps(proof)), prover.verifier_data(), data.common_data())
+    print("sha512 circuit: 2^14 rows, proof stages", prover.last_timings())

@@ -133,3 +133,29 @@ def test_selector_groups_reproduce_the_reference_common_data():
     from zklc_amd.plonky2.builder import fri_reduction_arity_bits
     assert fri_reduction_arity_bits(cfg, 12) == j["fri_params"]["reduction_arity_bits"] == [4, 4]
     assert fri_reduction_arity_bits(cfg, 17) == [4, 4, 4]
+
+
+def test_sha512_circuit_witness_matches_hashlib():
+    """crypto/plonky2_sha512/src/circuit.rs restated on the host builder: the generated witness carries SHA-512 of NEAR's
+    105-byte Ed25519 preimage (R || A || M, one block) in its public inputs, and sampled rows satisfy their gates"""
+    import hashlib
+    import random
+    from zklc_amd.plonky2 import sha512
+    msg = bytes((7 * i + 3) & 0xFF for i in range(105))
+    b = CircuitBuilder()
+    message, digest = sha512.sha512_circuit(b, 8 * len(msg))
+    assert len(message) == 840 and len(digest) == 512
+    for t in digest:
+        b.register_public_input(t)
+    data = b.build()
+    assert data.n == 1 << 14
+    wires, pis = data.generate_witness(dict(zip(message, sha512.array_to_bits(msg))))
+    assert pis == sha512.array_to_bits(hashlib.sha512(msg).digest())
+    common = data.common_data()
+    gates = [OG.gate_from_id(g) for g in common["gates"]]
+    pih = pgl.hash_no_pad(pis)
+    rng = random.Random(1)
+    for r in rng.sample(range(data.n), 60) + [data.n - 1]:
+        cs = OG.evaluate_gate_constraints(OG.BaseK, gates, common["selectors_info"], common["num_gate_constraints"],
+                                          [int(x) for x in data.constants[:, r]], [int(x) for x in wires[:, r]], pih)
+        assert not any(cs), "row %d" % r

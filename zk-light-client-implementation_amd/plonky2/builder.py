@@ -69,6 +69,7 @@ class CircuitBuilder:
         self._u32_slot = None
         self._const_slot = None
         self._ra_slot = {}
+        self._addmany_slot = {}
 
     # ---- targets / copy constraints
     def add_virtual_target(self):
@@ -178,6 +179,57 @@ class CircuitBuilder:
             return [(bits[i], (v[0] >> i) & 1) for i in range(num_bits)]
         self.add_generator([s], gen)
         return bits
+
+    def le_sum(self, bits):
+        """BaseSumGate row whose limbs are connected to `bits` (little-endian); returns the sum wire
+        (plonky2 `CircuitBuilder::le_sum`, used by crypto/plonky2_sha512/src/circuit.rs:74-80)"""
+        bits = list(bits)
+        if not bits:
+            return self.zero()
+        row = self.add_gate(G.BaseSumGate(len(bits), 2))
+        limbs = [Target(row, 1 + i) for i in range(len(bits))]
+        for b, l in zip(bits, limbs):
+            self.connect(b, l)
+        s = Target(row, 0)
+        self.add_generator(limbs, lambda v, s=s: [(s, sum(x << i for i, x in enumerate(v)) % P)])
+        return s
+
+    # ---- U32AddManyGate (crypto/plonky2_u32/src/gadgets/arithmetic_u32.rs:157-183 `add_many_u32`)
+    def add_many_u32(self, to_add):
+        to_add = list(to_add)
+        if len(to_add) == 0:
+            return self.zero(), self.zero()
+        if len(to_add) == 1:
+            return to_add[0], self.zero()
+        if len(to_add) == 2:
+            return self.mul_add_u32(to_add[0], self.one(), to_add[1])
+        na = len(to_add)
+        gate = G.U32AddManyGate.new_from_config(self.config, na)
+        slot = self._addmany_slot.get(na)
+        if slot is None or slot[1] == gate.num_ops:
+            slot = [self.add_gate(gate), 0]
+            self._addmany_slot[na] = slot
+        row, i = slot
+        slot[1] += 1
+        per = na + 3
+        ins = [Target(row, per * i + j) for j in range(na)]
+        for a, w in zip(to_add, ins):
+            self.connect(a, w)
+        carry_in = Target(row, per * i + na)
+        self.connect(carry_in, self.zero())
+        res, carry = Target(row, per * i + na + 1), Target(row, per * i + na + 2)
+        limbs = [Target(row, per * gate.num_ops + 18 * i + j) for j in range(18)]
+
+        def gen(v, res=res, carry=carry, limbs=limbs):
+            s = sum(v)
+            lo, hi = s & 0xFFFFFFFF, s >> 32
+            assert hi < 16, "add_many_u32: carry does not fit"
+            out = [(res, lo), (carry, hi)]
+            out += [(limbs[j], (lo >> (2 * j)) & 3) for j in range(16)]
+            out += [(limbs[16 + j], (hi >> (2 * j)) & 3) for j in range(2)]
+            return out
+        self.add_generator(ins, gen)
+        return res, carry
 
     # ---- U32ArithmeticGate: (lo, hi) = m0*m1 + addend on 32-bit values
     def mul_add_u32(self, m0, m1, addend):
