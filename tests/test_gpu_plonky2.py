@@ -132,3 +132,33 @@ def test_reference_sha512_circuit_proof(zctx):
     assert proof["public_inputs"] == sha512.array_to_bits(hashlib.sha512(msg).digest())
     V.verify(json.loads(json.dumps(proof)), prover.verifier_data(), data.common_data())
     print("sha512 circuit: 2^14 rows, proof stages", prover.last_timings())
+
+
+def test_reference_ed25519_circuit_proof_of_a_near_mainnet_signature(zctx):
+    """the reference's per-signature circuit (crypto/plonky2_ed25519/src/gadgets/eddsa.rs:34-85, restated in
+    zklc_amd/plonky2/ed25519_circuit.py: SHA-512 + two point decompressions + windowed [h]A + fixed-base [s]B over
+    non-native 2^255-19 arithmetic) on a real approval signature of the NEAR fixture data/*_small.json: host witness
+    generation, GPU proof, verifier restatement accepts; public inputs = message bits then public-key bits.
+    Building the 181k-row circuit and its witness in Python takes a few minutes of host time."""
+    from conftest import load_golden
+    from zklc_amd.plonky2 import wide_ecc_config, ed25519_circuit as E, sha512
+    j = load_golden("ed25519_near_c1_small.json")
+    msg = bytes.fromhex(j["msg"])
+    e = j["entries"][0]
+    pk, sig = bytes.fromhex(e["validator_tail"])[1:33], bytes.fromhex(e["approval"])[2:]
+    b = CircuitBuilder(wide_ecc_config())
+    targets = E.ed25519_circuit(b, 8 * len(msg))
+    data = b.build()
+    assert data.n == 1 << 18 and data.num_public_inputs == 8 * len(msg) + 256
+    wires, pis = data.generate_witness(E.fill_ecdsa_targets(targets, msg, sig, pk))
+    assert pis == sha512.array_to_bits(msg) + sha512.array_to_bits(pk)
+    # a corrupted signature has no witness (the reference's generators / prover fail the same way)
+    bad = bytearray(sig)
+    bad[40] ^= 1
+    with pytest.raises((AssertionError, ValueError)):
+        data.generate_witness(E.fill_ecdsa_targets(targets, msg, bytes(bad), pk))
+    prover = data.prover(zctx, HASH_GL)
+    proof = prover.prove(wires, pis)
+    print("ed25519 circuit: 2^18 rows x 234 wires, 20 gate types; proof stages", prover.last_timings())
+    V.verify(json.loads(json.dumps(proof)), prover.verifier_data(), data.common_data())
+    assert proof["public_inputs"] == pis

@@ -70,6 +70,8 @@ class CircuitBuilder:
         self._const_slot = None
         self._ra_slot = {}
         self._addmany_slot = {}
+        self._target_const = {}
+        self._sub_slot = None
 
     # ---- targets / copy constraints
     def add_virtual_target(self):
@@ -124,7 +126,12 @@ class CircuitBuilder:
         t = Target(row, k)
         self.add_generator([], lambda v, t=t, c=c: [(t, c)])
         self._const_targets[c] = t
+        self._target_const[t.key()] = c
         return t
+
+    def target_as_constant(self, t):
+        """the value if `t` is a constant target created by `constant()` (plonky2 `target_as_constant`)"""
+        return self._target_const.get(t.key())
 
     def zero(self):
         return self.constant(0)
@@ -203,6 +210,16 @@ class CircuitBuilder:
             return to_add[0], self.zero()
         if len(to_add) == 2:
             return self.mul_add_u32(to_add[0], self.one(), to_add[1])
+        return self._add_many_gate(to_add, self.zero())
+
+    def add_u32s_with_carry(self, to_add, carry):
+        """arithmetic_u32.rs:185-214: U32AddManyGate with an explicit carry-in target"""
+        to_add = list(to_add)
+        if len(to_add) == 1:
+            return self.mul_add_u32(to_add[0], self.one(), carry)
+        return self._add_many_gate(to_add, carry)
+
+    def _add_many_gate(self, to_add, carry_t):
         na = len(to_add)
         gate = G.U32AddManyGate.new_from_config(self.config, na)
         slot = self._addmany_slot.get(na)
@@ -212,18 +229,16 @@ class CircuitBuilder:
         row, i = slot
         slot[1] += 1
         per = na + 3
-        ins = [Target(row, per * i + j) for j in range(na)]
-        for a, w in zip(to_add, ins):
+        ins = [Target(row, per * i + j) for j in range(na + 1)]
+        for a, w in zip(list(to_add) + [carry_t], ins):
             self.connect(a, w)
-        carry_in = Target(row, per * i + na)
-        self.connect(carry_in, self.zero())
         res, carry = Target(row, per * i + na + 1), Target(row, per * i + na + 2)
         limbs = [Target(row, per * gate.num_ops + 18 * i + j) for j in range(18)]
 
         def gen(v, res=res, carry=carry, limbs=limbs):
             s = sum(v)
             lo, hi = s & 0xFFFFFFFF, s >> 32
-            assert hi < 16, "add_many_u32: carry does not fit"
+            assert hi < 16, "U32AddManyGate: carry does not fit in 4 bits"
             out = [(res, lo), (carry, hi)]
             out += [(limbs[j], (lo >> (2 * j)) & 3) for j in range(16)]
             out += [(limbs[16 + j], (hi >> (2 * j)) & 3) for j in range(2)]
@@ -231,8 +246,169 @@ class CircuitBuilder:
         self.add_generator(ins, gen)
         return res, carry
 
+    def sub_u32(self, x, y, borrow):
+        """arithmetic_u32.rs:221-238 (U32SubtractionGate): (x - y - borrow mod 2^32, borrow out)"""
+        gate = G.U32SubtractionGate.new_from_config(self.config)
+        if self._sub_slot is None or self._sub_slot[1] == gate.num_ops:
+            self._sub_slot = [self.add_gate(gate), 0]
+        row, i = self._sub_slot
+        self._sub_slot[1] += 1
+        w = [Target(row, 5 * i + k) for k in range(5)]
+        for a, t in zip((x, y, borrow), w):
+            self.connect(a, t)
+        limbs = [Target(row, 5 * gate.num_ops + 16 * i + j) for j in range(16)]
+
+        def gen(v, w=w, limbs=limbs):
+            d = v[0] - v[1] - v[2]
+            bout = 1 if d < 0 else 0
+            res = d + (bout << 32)
+            assert 0 <= res < (1 << 32)
+            return [(w[3], res), (w[4], bout)] + [(limbs[j], (res >> (2 * j)) & 3) for j in range(16)]
+        self.add_generator(w[:3], gen)
+        return w[3], w[4]
+
+    def range_check_u32(self, vals):
+        """crypto/plonky2_u32/src/gadgets/range_check.rs: one U32RangeCheckGate row for the list"""
+        vals = list(vals)
+        gate = G.U32RangeCheckGate(len(vals))
+        row = self.add_gate(gate)
+        n = len(vals)
+        ins = [Target(row, i) for i in range(n)]
+        for a, t in zip(vals, ins):
+            self.connect(a, t)
+
+        def gen(v, row=row, n=n):
+            out = []
+            for i, x in enumerate(v):
+                assert x < (1 << 32), "range_check_u32: value exceeds 32 bits"
+                out += [(Target(row, n + 16 * i + j), (x >> (2 * j)) & 3) for j in range(16)]
+            return out
+        self.add_generator(ins, gen)
+
+    def _comparison(self, a, b, num_bits=32):
+        """one ComparisonGate row: result = (a <= b)  (crypto/plonky2_u32/src/gates/comparison.rs generator)"""
+        num_chunks = -(-num_bits // 2)
+        gate = G.ComparisonGate(num_bits, num_chunks)
+        row = self.add_gate(gate)
+        wa, wb = Target(row, 0), Target(row, 1)
+        self.connect(a, wa)
+        self.connect(b, wb)
+        nc, cb = num_chunks, gate.chunk_bits
+
+        def gen(v, row=row, nc=nc, cb=cb):
+            x, y = v
+            out = []
+            msd = 0
+            size = 1 << cb
+            for i in range(nc):
+                ca, cy = (x >> (cb * i)) & (size - 1), (y >> (cb * i)) & (size - 1)
+                diff = (cy - ca) % P
+                eq = 1 if ca == cy else 0
+                out += [(Target(row, 4 + i), ca), (Target(row, 4 + nc + i), cy),
+                        (Target(row, 4 + 2 * nc + i), 1 if eq else pow(diff, P - 2, P)), (Target(row, 4 + 3 * nc + i), eq)]
+                inter = eq * msd % P
+                out.append((Target(row, 4 + 4 * nc + i), inter))
+                msd = (inter + (1 - eq) * diff) % P
+            out.append((Target(row, 3), msd))
+            top = (size + msd) % P
+            assert top < 2 * size
+            for i in range(cb + 1):
+                out.append((Target(row, 4 + 5 * nc + i), (top >> i) & 1))
+            out.append((Target(row, 2), (top >> cb) & 1))
+            return out
+        self.add_generator([wa, wb], gen)
+        return Target(row, 2)
+
+    def list_le(self, a, b, num_bits=32):
+        """multiple_comparison.rs:17-64 `list_le_circuit`: a <= b as little-endian lists of num_bits-bit limbs"""
+        assert len(a) == len(b)
+        one = self.one()
+        result = one
+        for x, y in zip(a, b):
+            a_le_b = self._comparison(x, y, num_bits)
+            b_le_a = self._comparison(y, x, num_bits)
+            equal = self.mul(a_le_b, b_le_a)
+            less = self.sub(one, b_le_a)
+            result = self.mul_add(equal, result, less)
+        return result
+
+    def not_(self, b):
+        return self.sub(self.one(), b)
+
+    def assert_zero(self, x):
+        self.connect(x, self.zero())
+
+    def assert_one(self, x):
+        self.connect(x, self.one())
+
+    def assert_bool(self, b):
+        """b * b - b == 0"""
+        self.assert_zero(self.arithmetic(1, b, b, P - 1, b))
+
+    def is_equal(self, x, y):
+        """plonky2 `is_equal`: equal bit + inverse-of-difference witness"""
+        equal, inv = self.add_virtual_target(), self.add_virtual_target()
+        self.add_generator([x, y], lambda v, equal=equal, inv=inv: [(equal, 1 if v[0] == v[1] else 0),
+                                                                    (inv, 0 if v[0] == v[1] else pow((v[0] - v[1]) % P, P - 2, P))])
+        not_equal = self.not_(equal)
+        diff = self.sub(x, y)
+        self.connect(self.mul(diff, equal), self.zero())
+        self.connect(not_equal, self.mul(diff, inv))
+        return equal
+
+    def split_le_base(self, x, num_limbs, base):
+        """plonky2 `split_le_base::<B>`: BaseSumGate row, little-endian base-B limbs"""
+        if base == 2:
+            return self.split_le(x, num_limbs)
+        gate = G.BaseSumGate(num_limbs, base)
+        row = self.add_gate(gate)
+        s = Target(row, 0)
+        self.connect(x, s)
+        limbs = [Target(row, 1 + i) for i in range(num_limbs)]
+
+        def gen(v, limbs=limbs, base=base, num_limbs=num_limbs):
+            assert v[0] < base ** num_limbs, "split_le_base: value does not fit"
+            return [(limbs[i], (v[0] // base ** i) % base) for i in range(num_limbs)]
+        self.add_generator([s], gen)
+        return limbs
+
+    def random_access(self, index, items):
+        """plonky2 `random_access` (RandomAccessGate): items[index], len(items) a power of two"""
+        items = list(items)
+        bits = len(items).bit_length() - 1
+        assert 1 << bits == len(items)
+        if bits == 0:
+            return items[0]
+        gate = G.RandomAccessGate.new_from_config(self.config, bits)
+        slot = self._ra_slot.get(bits)
+        if slot is None or slot[1] == gate.num_copies:
+            consts = [0] * gate.num_extra_constants
+            slot = [self.add_gate(gate, consts), 0]
+            self._ra_slot[bits] = slot
+        row, cp = slot
+        slot[1] += 1
+        vs = 1 << bits
+        base = (2 + vs) * cp
+        w_idx, w_claim = Target(row, base), Target(row, base + 1)
+        w_items = [Target(row, base + 2 + i) for i in range(vs)]
+        self.connect(index, w_idx)
+        for a, t in zip(items, w_items):
+            self.connect(a, t)
+        w_bits = [Target(row, gate.num_routed + cp * bits + i) for i in range(bits)]
+
+        def gen(v, w_claim=w_claim, w_bits=w_bits, bits=bits):
+            idx = v[0]
+            assert idx < (1 << bits), "random_access: index out of range"
+            return [(w_claim, v[1 + idx])] + [(w_bits[i], (idx >> i) & 1) for i in range(bits)]
+        self.add_generator([w_idx] + w_items, gen)
+        return w_claim
+
     # ---- U32ArithmeticGate: (lo, hi) = m0*m1 + addend on 32-bit values
     def mul_add_u32(self, m0, m1, addend):
+        c0, c1, c2 = self.target_as_constant(m0), self.target_as_constant(m1), self.target_as_constant(addend)
+        if c0 is not None and c1 is not None and c2 is not None:   # arithmetic_u32.rs:107-130 special case
+            s_ = (c0 * c1 + c2) % P
+            return self.constant(s_ & 0xFFFFFFFF), self.constant(s_ >> 32)
         gate = G.U32ArithmeticGate.new_from_config(self.config)
         if self._u32_slot is None or self._u32_slot[1] == gate.num_ops:
             self._u32_slot = [self.add_gate(gate), 0]
