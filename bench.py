@@ -25,10 +25,11 @@ on one GPU, a bounded CPU sample of the oracle):
            all-gathered over RCCL and added with a unit-scalar MSM (inside the timing)
   lde      Goldilocks coset LDE 234 x (2^17 -> 2^20), bit-reversed output (C3)
   merkle   Poseidon leaf hashing + Merkle tree, 2^20 leaves x 234 columns, cap height 4 (C3)
-  prove    full plonky2 proofs (zklc_plonky2_prove_dev, witness resident in HBM) of synthetic circuits with the
-           reference's two shapes: Ed25519 circuit 2^17 rows x 234 wires, recursion circuit 2^12 rows x 135 wires, and the
-           Poseidon-BN128 wrap; plus one Block_i signature sub-DAG (100 validators: 100 Ed25519-shape proofs + 100
-           recursion-shape proofs + 1 wrap, signatures.rs:70-139) run back to back -> Block_i proofs/s
+  prove    full plonky2 proofs (zklc_plonky2_prove_dev, witness resident in HBM): the reference's per-signature Ed25519
+           circuit itself (2^18 rows x 234 wires, witness of a real NEAR approval signature), synthetic circuits of the
+           recursion shape (2^12 rows x 135 wires, the 13 gate types of the golden common_data) with the Poseidon and the
+           Poseidon-BN128 (wrap) hashers; plus one Block_i signature sub-DAG (100 validators: 100 Ed25519 proofs, the serial
+           fold of 100 recursion-shape proofs, 1 wrap; signatures.rs:70-139) with several proofs in flight -> Block_i proofs/s
 `--no-stages` skips them; `--no-prove` skips only the last one.
 """
 import argparse
@@ -248,12 +249,12 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
         torch.cuda.empty_cache()
         res["prove"] = run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max)
         if with_cpu and "cpu_baseline" in res["lde"] and "cpu_baseline" in res["merkle"]:
-            # CPU lower bound of ONE Ed25519-shape proof with the oracle's C port: only its wires commitment
-            # (LDE of 234 columns + Merkle tree over 2^20 leaves), extrapolated from the two bounded samples above
-            lde_s = alg / 1e9 / res["lde"]["cpu_baseline"]["value"]
-            mk_s = N / 1e6 / res["merkle"]["cpu_baseline"]["value"]
-            gpu_ms = res["prove"]["ed25519_2p17x234"]["ms_per_proof"]
-            res["prove"]["ed25519_2p17x234"]["cpu_baseline"] = {
+            # CPU lower bound of ONE Ed25519 proof (2^18 rows) with the oracle's C port: only its wires commitment
+            # (LDE of 234 columns 2^18 -> 2^21 + Merkle tree over 2^21 leaves), extrapolated from the two bounded samples above
+            lde_s = 2 * alg / 1e9 / res["lde"]["cpu_baseline"]["value"]
+            mk_s = 2 * N / 1e6 / res["merkle"]["cpu_baseline"]["value"]
+            gpu_ms = res["prove"]["ed25519_circuit_2p18x234"]["ms_per_proof"]
+            res["prove"]["ed25519_circuit_2p18x234"]["cpu_baseline"] = {
                 "value": 1.0 / (lde_s + mk_s), "unit": "proofs/s (upper bound)", "cores": threads, "kind": "port",
                 "sample": "wires commitment only (coset LDE %.1f s + Poseidon Merkle tree %.1f s, extrapolated from the lde / merkle "
                           "samples above, oracle/c/goldilocks_oracle.c): a LOWER bound of the time of one CPU proof with this port; "
@@ -327,12 +328,29 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     """plonky2 proofs of synthetic circuits with the reference's shapes (zklc_amd/plonky2/synthetic.py)."""
     import torch
     from zklc_amd.plonky2 import synthetic as SY, standard_recursion_config, wide_ecc_config, HASH_GL, HASH_BN128
-    shapes = [("ed25519_2p17x234", 17, wide_ecc_config(), SY.ed25519_shape_mix, HASH_GL, 584),
+    shapes = [("ed25519_circuit_2p18x234", 18, wide_ecc_config(), None, HASH_GL, 584),
               ("recursion_2p12x135", 12, standard_recursion_config(), SY.recursion_shape_mix, HASH_GL, 16),
               ("wrap_bn128_2p12x135", 12, standard_recursion_config(), SY.recursion_shape_mix, HASH_BN128, 16)]
     out, provers, circuits = {}, {}, {}
     for name, bits, cfg, mixf, hasher, npi in shapes:
-        data, wires, pis = SY.synthetic_circuit(bits, cfg, mixf(cfg), num_public_inputs=npi, seed=1 + rank)
+        host_s = None
+        if mixf is None:
+            # the reference's per-signature circuit itself (crypto/plonky2_ed25519/src/gadgets/eddsa.rs:34-85 restated in
+            # zklc_amd/plonky2/ed25519_circuit.py) with the witness of a real NEAR approval signature (fixture C1, entry 0)
+            from zklc_amd.plonky2 import CircuitBuilder, ed25519_circuit as E
+            t0 = time.perf_counter()
+            j = json.load(open(os.path.join(ROOT, "tests", "golden", "ed25519_near_c1_small.json")))
+            msg, e0 = bytes.fromhex(j["msg"]), j["entries"][0]
+            bld = CircuitBuilder(cfg)
+            targets = E.ed25519_circuit(bld, 8 * len(msg))
+            data = bld.build()
+            t1 = time.perf_counter()
+            wires, pis = data.generate_witness(E.fill_ecdsa_targets(targets, msg, bytes.fromhex(e0["approval"])[2:],
+                                                                    bytes.fromhex(e0["validator_tail"])[1:33]))
+            host_s = {"circuit_build_s": t1 - t0, "witness_generation_s": time.perf_counter() - t1}
+            assert data.degree_bits == bits
+        else:
+            data, wires, pis = SY.synthetic_circuit(bits, cfg, mixf(cfg), num_public_inputs=npi, seed=1 + rank)
         prover = data.prover(ctx, hasher)
         d_w = torch.from_numpy(wires.view(np.int64)).to(dev)
         fn = lambda prover=prover, d_w=d_w, pis=pis: prover.prove_dev(d_w.data_ptr(), pis, stream=stream.cuda_stream)
@@ -348,8 +366,12 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         # algorithmic bytes of one proof = the four committed LDE matrices written once + read once by the Merkle hashing
         widths = data.num_constants + cfg["num_routed_wires"] + cfg["num_wires"] + 2 * (1 + data.num_partial_products) + 2 * 8
         out[name] = {"ms_per_proof": ms, "proofs_per_s": world * 1e3 / ms, "proof_bytes": prover.proof_bytes,
-                     "rows": 1 << bits, "wires": cfg["num_wires"], "committed_polys": widths,
+                     "rows": 1 << bits, "wires": cfg["num_wires"], "committed_polys": widths, "gate_types": len(data.gates),
+                     "circuit": ("reference Ed25519 circuit, real NEAR signature witness" if mixf is None
+                                 else "synthetic circuit of the reference's shape and gate types"),
                      "stages_ms": {k: round(v, 3) for k, v in tm.items()}}
+        if host_s:
+            out[name]["host_python_untimed"] = host_s
         provers[name] = (fn, prover)
         circuits[name] = (data, d_w, pis, hasher)
         prover.close()
@@ -364,7 +386,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     for t in range(nthreads):
         wctx = ctx if t == 0 else zklc_amd.Context(torch.cuda.current_device())
         fns = {}
-        need = ["ed25519_2p17x234"] if (t < nthreads - 1 or nthreads == 1) else []
+        need = ["ed25519_circuit_2p18x234"] if (t < nthreads - 1 or nthreads == 1) else []
         if t == nthreads - 1:
             need += ["recursion_2p12x135", "wrap_bn128_2p12x135"]
         for name in need:
@@ -388,7 +410,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                     next_ed[0] += 1
                 if i >= VALIDATORS:
                     return
-                fns["ed25519_2p17x234"][0]()
+                fns["ed25519_circuit_2p18x234"][0]()
                 ed_done[i].set()
         except Exception as e:  # pragma: no cover
             errors.append(e)
@@ -399,7 +421,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         try:
             for i in range(VALIDATORS):
                 if also_ed:
-                    fns["ed25519_2p17x234"][0]()
+                    fns["ed25519_circuit_2p18x234"][0]()
                 else:
                     ed_done[i].wait()
                 fns["recursion_2p12x135"][0]()
@@ -418,14 +440,16 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     block_s = reduce_max(time.perf_counter() - t0)
     if errors:
         raise errors[0]
-    out["block_i"] = {"metric": "Block_i signature sub-DAG proofs/s (100 validators: 100 Ed25519-shape proofs, the serial fold of 100 "
+    out["block_i"] = {"metric": "Block_i signature sub-DAG proofs/s (100 validators: 100 proofs of the reference Ed25519 circuit, the serial fold of 100 "
                                 "recursion-shape proofs, 1 BN128 wrap; %d proofs in flight per GPU; every rank proves its own block)"
                                 % nthreads,
                       "value": world / block_s, "unit": "proofs/s", "seconds_per_block": block_s, "streams": nthreads,
                       "cpu_baseline": None,
-                      "note": "synthetic circuits of the reference's shapes and gate types (the Rust circuit builders are not "
-                              "rebuilt); witness generation (SURVEY 8a row a5) is outside the timed region; the reference CPU "
-                              "prover cannot be built here (no Rust toolchain) and publishes no time for this step"}
+                      "note": "Ed25519 proofs: the reference circuit (restated) with one real signature witness repeated; recursion and "
+                              "wrap proofs: synthetic circuits of the reference's shape and gate types (the recursive verifier "
+                              "circuit is not restated yet); witness generation (SURVEY 8a row a5, host Python today) is outside "
+                              "the timed region; the reference CPU prover cannot be built here (no Rust toolchain) and publishes "
+                              "no time for this step"}
     for wctx, fns in workers:
         for _, pr in fns.values():
             pr.close()

@@ -511,6 +511,7 @@ class CircuitData:
             for (c0, r0), (c1, r1) in zip(members, members[1:] + members[:1]):
                 sig_col[c0, r0], sig_row[c0, r0] = c1, r1
         self.builder = b
+        self._plan = None
         self._init_arrays(b.config, uniq, row_gate, row_consts, sig_col, sig_row, len(b.public_inputs))
 
     @classmethod
@@ -519,6 +520,7 @@ class CircuitData:
         sigma as (column, row) index arrays of shape [routed, n]"""
         self = cls.__new__(cls)
         self.builder = None
+        self._plan = None
         assert gates == sorted(gates, key=lambda g: (g.degree, g.id()))
         self._init_arrays(config, gates, row_gate, row_consts, sig_col, sig_row, num_public_inputs)
         return self
@@ -608,27 +610,42 @@ class CircuitData:
     def generate_witness(self, inputs):
         """inputs: {Target: value}.  Returns (wires u64[num_wires, n], public input values)."""
         b = self.builder
+        if self._plan is None:
+            # the copy classes are final once the circuit is built: resolve every target to its class once
+            rep = {}
+
+            def find(t):
+                k = t.key()
+                r = rep.get(k)
+                if r is None:
+                    r = rep[k] = b._find(k)
+                return r
+            self._plan = ([([find(t) for t in ins], fn) for ins, fn in b.generators], find)
+        plan, find = self._plan
         vals = {}
 
         def setv(t, v):
-            k = b._find(t.key())
+            k = find(t)
             v %= P
-            if k in vals:
-                assert vals[k] == v, "copy constraint violated at %r: %d != %d" % (t, vals[k], v)
-            vals[k] = v
+            old = vals.get(k)
+            if old is None:
+                vals[k] = v
+            elif old != v:
+                raise AssertionError("copy constraint violated at %r: %d != %d" % (t, old, v))
 
         for t, v in inputs.items():
             setv(t, v)
-        pending = list(b.generators)
+        pending = plan
         while pending:
             rest = []
-            for ins, fn in pending:
-                ks = [b._find(t.key()) for t in ins]
-                if all(k in vals for k in ks):
-                    for t, v in fn([vals[k] for k in ks]):
-                        setv(t, v)
-                else:
-                    rest.append((ins, fn))
+            for ks, fn in pending:
+                try:
+                    args = [vals[k] for k in ks]
+                except KeyError:
+                    rest.append((ks, fn))
+                    continue
+                for t, v in fn(args):
+                    setv(t, v)
             assert len(rest) < len(pending), "witness generation stuck: %d generators without inputs" % len(rest)
             pending = rest
         wires = np.zeros((self.config["num_wires"], self.n), dtype=np.uint64)
@@ -640,5 +657,5 @@ class CircuitData:
                 r = b._find(k)
                 if r in vals:
                     wires[k[2], k[1]] = vals[r]
-        pis = [vals[b._find(t.key())] for t in b.public_inputs]
+        pis = [vals[find(t)] for t in b.public_inputs]
         return wires, pis
