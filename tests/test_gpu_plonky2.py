@@ -150,14 +150,23 @@ def test_reference_ed25519_circuit_proof_of_a_near_mainnet_signature(zctx):
     targets = E.ed25519_circuit(b, 8 * len(msg))
     data = b.build()
     assert data.n == 1 << 18 and data.num_public_inputs == 8 * len(msg) + 256
+    import time
     wires, pis = data.generate_witness(E.fill_ecdsa_targets(targets, msg, sig, pk))
     assert pis == sha512.array_to_bits(msg) + sha512.array_to_bits(pk)
+    # native witness generation (csrc/plonky2_witness.cpp): all three signatures of the fixture, identical to the Python one
+    data.witness_program(E.fill_ecdsa_targets(targets, msg, sig, pk))
+    sigs = [(bytes.fromhex(x["approval"])[2:], bytes.fromhex(x["validator_tail"])[1:33]) for x in j["entries"]]
+    t0 = time.time()
+    wn, pn = data.generate_witness_native([E.fill_ecdsa_targets(targets, msg, s_, p_) for s_, p_ in sigs])
+    print("native witness generation: %.2f s for %d signatures" % (time.time() - t0, len(sigs)))
+    assert np.array_equal(wn[0], wires) and [int(x) for x in pn[0]] == pis
     # a corrupted signature has no witness (the reference's generators / prover fail the same way)
     bad = bytearray(sig)
     bad[40] ^= 1
-    with pytest.raises((AssertionError, ValueError)):
-        data.generate_witness(E.fill_ecdsa_targets(targets, msg, bytes(bad), pk))
+    with pytest.raises(AssertionError):
+        data.generate_witness_native([E.fill_ecdsa_targets(targets, msg, bytes(bad), pk)])
     prover = data.prover(zctx, HASH_GL)
+    V.verify(json.loads(json.dumps(prover.prove(wn[2], [int(x) for x in pn[2]]))), prover.verifier_data(), data.common_data())
     proof = prover.prove(wires, pis)
     print("ed25519 circuit: 2^18 rows x 234 wires, 20 gate types; proof stages", prover.last_timings())
     V.verify(json.loads(json.dumps(proof)), prover.verifier_data(), data.common_data())

@@ -159,3 +159,49 @@ def test_sha512_circuit_witness_matches_hashlib():
         cs = OG.evaluate_gate_constraints(OG.BaseK, gates, common["selectors_info"], common["num_gate_constraints"],
                                           [int(x) for x in data.constants[:, r]], [int(x) for x in wires[:, r]], pih)
         assert not any(cs), "row %d" % r
+
+
+def test_native_witness_interpreter_matches_the_python_generators():
+    """csrc/plonky2_witness.cpp (zklc_plonky2_witness_run) against the builder's Python generators on a circuit that uses the
+    non-native field, point decompression, curve doubling / conditional addition, random access, comparison, division and
+    u32 gadgets of the Ed25519 circuit; an undecodable public key has no witness"""
+    import random
+    from zklc_amd.plonky2 import ed25519_circuit as E, sha512
+    rng = random.Random(1)
+    b = CircuitBuilder(wide_ecc_config())
+    g = E.Gadgets(b)
+    xa, ya = g.virtual_biguint(8), g.virtual_biguint(8)
+    for f in (g.add_nonnative, g.sub_nonnative, g.mul_nonnative):
+        f(xa, ya)
+    g.inv_nonnative(xa)
+    g.neg_nonnative(ya)
+    pk_bits = b.add_virtual_targets(256)
+    pt = g.point_decompress(pk_bits)
+    dbl = g.curve_double(pt)
+    w4 = g.split_nonnative_to_4_bit_limbs(xa)
+    sel = g.random_access_curve_points(w4[0], [g.constant_affine_point(E.pt_mul(i + 1, E.BASE)) for i in range(16)])
+    g.curve_conditional_add(dbl, sel, b.not_(b.is_equal(w4[1], b.zero())))
+    for t in g.reduce(xa + ya, E.L25519):
+        b.register_public_input(t)
+    data = b.build()
+    j = load_golden("ed25519_near_c2_100.json")
+    pks = [bytes.fromhex(e["validator_tail"])[1:33] for e in j["entries"][:4]]
+
+    def inputs(x, y, pk):
+        d = dict(zip(xa, E.limbs_of(x, 8)))
+        d.update(zip(ya, E.limbs_of(y, 8)))
+        d.update(zip(pk_bits, E.bits_in_le(sha512.array_to_bits(pk))))
+        return d
+    ins = [inputs(rng.randrange(E.P25519), rng.randrange(E.P25519), pk) for pk in pks]
+    ins.append(inputs(E.P25519 - 1, 1, pks[0]))
+    data.witness_program(ins[0])
+    wn, pn = data.generate_witness_native(ins, threads=2)
+    for i, inp in enumerate(ins):
+        wp, pp = data.generate_witness(inp)
+        assert np.array_equal(wp, wn[i]) and pp == [int(x) for x in pn[i]], i
+    x, y = E.value_of(ins[1][t] for t in xa), E.value_of(ins[1][t] for t in ya)
+    assert E.value_of(pn[1]) == (x + (y << 256)) % E.L25519
+    bad = dict(ins[0])
+    bad[pk_bits[5]] ^= 1
+    with pytest.raises(AssertionError, match="decompression|copy constraint"):
+        data.generate_witness_native([bad])

@@ -26,7 +26,7 @@ def _newest(paths):
 
 
 HOST_CXX = os.environ.get("CXX", "g++")
-HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
 
 
 def _compile(src, obj, log):
@@ -57,7 +57,7 @@ def build(verbose=True, force=False):
         with cf.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(lambda so: _compile(so[0], so[1], verbose), jobs))
     if jobs or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

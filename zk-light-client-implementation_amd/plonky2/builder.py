@@ -19,6 +19,9 @@ import numpy as np
 from . import gates as G
 
 P = 2**64 - 2**32 + 1
+# instruction set of the native witness interpreter (csrc/plonky2_witness.cpp)
+OP_CONST, OP_ARITH, OP_SPLIT, OP_LE_SUM, OP_U32_MULADD, OP_ADD_MANY, OP_SUB_U32, OP_RANGE_CHECK, OP_COMPARISON, OP_IS_EQUAL, \
+    OP_RANDOM_ACCESS, OP_NN_ADD, OP_NN_SUB, OP_NN_MUL, OP_NN_INV, OP_DIV_REM, OP_DECOMPRESS, OP_POSEIDON = range(18)
 UNUSED_SELECTOR = (1 << 32) - 1
 GENERATOR = 7
 POWER_OF_TWO_GENERATOR = 1753635133440165772
@@ -109,8 +112,10 @@ class CircuitBuilder:
         self.rows.append((gate, [c % P for c in constants]))
         return len(self.rows) - 1
 
-    def add_generator(self, inputs, fn):
-        self.generators.append((list(inputs), fn))
+    def add_generator(self, inputs, fn, op=None, params=()):
+        """fn(values of inputs) -> [(target, value)]; (op, params) name the same computation for the native interpreter
+        (csrc/plonky2_witness.cpp), which must emit its outputs in the order fn returns them"""
+        self.generators.append((list(inputs), fn, op, tuple(int(x) for x in params)))
 
     # ---- constants
     def constant(self, c):
@@ -124,7 +129,7 @@ class CircuitBuilder:
         self.rows[row][1][k] = c
         self._const_slot[1] += 1
         t = Target(row, k)
-        self.add_generator([], lambda v, t=t, c=c: [(t, c)])
+        self.add_generator([], lambda v, t=t, c=c: [(t, c)], OP_CONST, (c,))
         self._const_targets[c] = t
         self._target_const[t.key()] = c
         return t
@@ -155,7 +160,7 @@ class CircuitBuilder:
         self.connect(m1, w[1])
         self.connect(addend, w[2])
         self.add_generator([w[0], w[1], w[2]],
-                           lambda v, w=w, c0=c0, c1=c1: [(w[3], (c0 * v[0] * v[1] + c1 * v[2]) % P)])
+                           lambda v, w=w, c0=c0, c1=c1: [(w[3], (c0 * v[0] * v[1] + c1 * v[2]) % P)], OP_ARITH, (c0, c1))
         return w[3]
 
     def mul(self, a, b):
@@ -184,7 +189,7 @@ class CircuitBuilder:
         def gen(v, bits=bits, num_bits=num_bits):
             assert v[0] < (1 << num_bits), "split_le: value does not fit"
             return [(bits[i], (v[0] >> i) & 1) for i in range(num_bits)]
-        self.add_generator([s], gen)
+        self.add_generator([s], gen, OP_SPLIT, (2, num_bits))
         return bits
 
     def le_sum(self, bits):
@@ -198,7 +203,7 @@ class CircuitBuilder:
         for b, l in zip(bits, limbs):
             self.connect(b, l)
         s = Target(row, 0)
-        self.add_generator(limbs, lambda v, s=s: [(s, sum(x << i for i, x in enumerate(v)) % P)])
+        self.add_generator(limbs, lambda v, s=s: [(s, sum(x << i for i, x in enumerate(v)) % P)], OP_LE_SUM)
         return s
 
     # ---- U32AddManyGate (crypto/plonky2_u32/src/gadgets/arithmetic_u32.rs:157-183 `add_many_u32`)
@@ -243,7 +248,7 @@ class CircuitBuilder:
             out += [(limbs[j], (lo >> (2 * j)) & 3) for j in range(16)]
             out += [(limbs[16 + j], (hi >> (2 * j)) & 3) for j in range(2)]
             return out
-        self.add_generator(ins, gen)
+        self.add_generator(ins, gen, OP_ADD_MANY)
         return res, carry
 
     def sub_u32(self, x, y, borrow):
@@ -264,7 +269,7 @@ class CircuitBuilder:
             res = d + (bout << 32)
             assert 0 <= res < (1 << 32)
             return [(w[3], res), (w[4], bout)] + [(limbs[j], (res >> (2 * j)) & 3) for j in range(16)]
-        self.add_generator(w[:3], gen)
+        self.add_generator(w[:3], gen, OP_SUB_U32)
         return w[3], w[4]
 
     def range_check_u32(self, vals):
@@ -283,7 +288,7 @@ class CircuitBuilder:
                 assert x < (1 << 32), "range_check_u32: value exceeds 32 bits"
                 out += [(Target(row, n + 16 * i + j), (x >> (2 * j)) & 3) for j in range(16)]
             return out
-        self.add_generator(ins, gen)
+        self.add_generator(ins, gen, OP_RANGE_CHECK)
 
     def _comparison(self, a, b, num_bits=32):
         """one ComparisonGate row: result = (a <= b)  (crypto/plonky2_u32/src/gates/comparison.rs generator)"""
@@ -316,7 +321,7 @@ class CircuitBuilder:
                 out.append((Target(row, 4 + 5 * nc + i), (top >> i) & 1))
             out.append((Target(row, 2), (top >> cb) & 1))
             return out
-        self.add_generator([wa, wb], gen)
+        self.add_generator([wa, wb], gen, OP_COMPARISON, (nc, cb))
         return Target(row, 2)
 
     def list_le(self, a, b, num_bits=32):
@@ -349,7 +354,8 @@ class CircuitBuilder:
         """plonky2 `is_equal`: equal bit + inverse-of-difference witness"""
         equal, inv = self.add_virtual_target(), self.add_virtual_target()
         self.add_generator([x, y], lambda v, equal=equal, inv=inv: [(equal, 1 if v[0] == v[1] else 0),
-                                                                    (inv, 0 if v[0] == v[1] else pow((v[0] - v[1]) % P, P - 2, P))])
+                                                                    (inv, 0 if v[0] == v[1] else pow((v[0] - v[1]) % P, P - 2, P))],
+                           OP_IS_EQUAL)
         not_equal = self.not_(equal)
         diff = self.sub(x, y)
         self.connect(self.mul(diff, equal), self.zero())
@@ -369,7 +375,7 @@ class CircuitBuilder:
         def gen(v, limbs=limbs, base=base, num_limbs=num_limbs):
             assert v[0] < base ** num_limbs, "split_le_base: value does not fit"
             return [(limbs[i], (v[0] // base ** i) % base) for i in range(num_limbs)]
-        self.add_generator([s], gen)
+        self.add_generator([s], gen, OP_SPLIT, (base, num_limbs))
         return limbs
 
     def random_access(self, index, items):
@@ -400,7 +406,7 @@ class CircuitBuilder:
             idx = v[0]
             assert idx < (1 << bits), "random_access: index out of range"
             return [(w_claim, v[1 + idx])] + [(w_bits[i], (idx >> i) & 1) for i in range(bits)]
-        self.add_generator([w_idx] + w_items, gen)
+        self.add_generator([w_idx] + w_items, gen, OP_RANDOM_ACCESS, (bits,))
         return w_claim
 
     # ---- U32ArithmeticGate: (lo, hi) = m0*m1 + addend on 32-bit values
@@ -429,7 +435,7 @@ class CircuitBuilder:
             res = [(w[3], lo), (w[4], hi), (w[5], inv)]
             res += [(limbs[j], (out >> (2 * j)) & 3) for j in range(32)]
             return res
-        self.add_generator(w[:3], gen)
+        self.add_generator(w[:3], gen, OP_U32_MULADD)
         return w[3], w[4]
 
     # ---- Poseidon (PoseidonGate rows); witness rows come from the library (zklc_poseidon_gl_gate_rows)
@@ -445,7 +451,7 @@ class CircuitBuilder:
             from .prover import poseidon_gate_rows
             r = poseidon_gate_rows(np.array([v], dtype=np.uint64), np.zeros(1, dtype=np.uint64))[0]
             return [(Target(row, c), int(r[c])) for c in range(12, 135) if c != 24]
-        self.add_generator(ins, gen)
+        self.add_generator(ins, gen, OP_POSEIDON)
         return [Target(row, 12 + i) for i in range(12)]
 
     def hash_n_to_hash_no_pad(self, inputs):
@@ -512,6 +518,8 @@ class CircuitData:
                 sig_col[c0, r0], sig_row[c0, r0] = c1, r1
         self.builder = b
         self._plan = None
+        self._trace = None
+        self._program = None
         self._init_arrays(b.config, uniq, row_gate, row_consts, sig_col, sig_row, len(b.public_inputs))
 
     @classmethod
@@ -521,6 +529,8 @@ class CircuitData:
         self = cls.__new__(cls)
         self.builder = None
         self._plan = None
+        self._trace = None
+        self._program = None
         assert gates == sorted(gates, key=lambda g: (g.degree, g.id()))
         self._init_arrays(config, gates, row_gate, row_consts, sig_col, sig_row, num_public_inputs)
         return self
@@ -582,6 +592,81 @@ class CircuitData:
         self.fri_arity_bits = fri_reduction_arity_bits(cfg, self.degree_bits)
         self.num_public_inputs = num_public_inputs
 
+    # ---- native witness generation (csrc/plonky2_witness.cpp)
+    def witness_program(self, example_inputs):
+        """Compile the circuit's generators into the interpreter's program.  `example_inputs` is any satisfiable partial
+        witness {Target: value}: one run of the Python generators fixes the execution order and the output slots."""
+        if self._program is not None:
+            return self._program
+        b = self.builder
+        self._trace = []
+        try:
+            self.generate_witness(example_inputs)
+            trace = self._trace
+        finally:
+            self._trace = None
+        _, find = self._plan
+        slot_of = {}
+
+        def slot(k):
+            s_ = slot_of.get(k)
+            if s_ is None:
+                s_ = slot_of[k] = len(slot_of)
+            return s_
+        code = []
+        for gi, out_keys in trace:
+            ins, _, op, params = b.generators[gi]
+            assert op is not None, "generator without a native opcode"
+            code += [op, len(params), len(ins), len(out_keys)] + [x - (1 << 64) if x >= (1 << 63) else x for x in params]
+            code += [slot(find(t)) for t in ins] + [slot(k) for k in out_keys]
+        in_targets = list(example_inputs.keys())
+        ws, wc, wr = [], [], []
+        for k in list(b.parent) + [k for k in slot_of if k[0] == "w" and k not in b.parent]:
+            if k[0] == "w":
+                r = b._find(k)
+                if r in slot_of:
+                    ws.append(slot_of[r])
+                    wc.append(k[2])
+                    wr.append(k[1])
+        self._program = {
+            "code": np.array(code, dtype=np.int64), "n_slots": len(slot_of) + len(in_targets) + 1,
+            "input_targets": in_targets, "input_slots": np.array([slot(find(t)) for t in in_targets], dtype=np.uint32),
+            "wire_slot": np.array(ws, dtype=np.uint32), "wire_col": np.array(wc, dtype=np.uint32), "wire_row": np.array(wr, dtype=np.uint32),
+            "pi_slots": np.array([slot(find(t)) for t in b.public_inputs], dtype=np.uint32),
+        }
+        self._program["n_slots"] = len(slot_of) + 1
+        return self._program
+
+    def generate_witness_native(self, inputs_list, out=None, threads=None):
+        """inputs_list: partial witnesses ({Target: value} with the same keys as the example given to witness_program).
+        Returns (wires uint64 [k, num_wires, n], public inputs uint64 [k, n_pi]); raises if a witness does not exist.
+        `out` may be a zero-initialised buffer of that shape reused across calls (only the circuit's wire cells are written)."""
+        import ctypes
+        import os
+        from .. import _lib
+        pr = self._program
+        assert pr is not None, "call witness_program(example_inputs) first"
+        k = len(inputs_list)
+        vals = np.array([[int(w[t]) for t in pr["input_targets"]] for w in inputs_list], dtype=np.uint64).reshape(k, -1)
+        nw = self.config["num_wires"]
+        wires = out if out is not None else np.zeros((k, nw, self.n), dtype=np.uint64)
+        assert wires.shape == (k, nw, self.n) and wires.dtype == np.uint64 and wires.flags["C_CONTIGUOUS"]
+        npi = len(pr["pi_slots"])
+        pis = np.zeros((k, max(npi, 1)), dtype=np.uint64)
+        status = np.zeros(k, dtype=np.int32)
+        err = ctypes.create_string_buffer(200 * k)
+        threads = threads or min(k, len(os.sched_getaffinity(0)))
+        rc = _lib.load().zklc_plonky2_witness_run(
+            pr["code"].ctypes.data, len(pr["code"]), pr["n_slots"], pr["input_slots"].ctypes.data, vals.shape[1], vals.ctypes.data, k,
+            pr["wire_slot"].ctypes.data, pr["wire_col"].ctypes.data, pr["wire_row"].ctypes.data, len(pr["wire_slot"]), nw, self.n,
+            wires.ctypes.data, pr["pi_slots"].ctypes.data, npi, pis.ctypes.data, status.ctypes.data, err, threads)
+        if rc != 0:
+            raise ValueError("zklc_plonky2_witness_run: invalid argument")
+        for i in range(k):
+            if status[i]:
+                raise AssertionError("witness %d: %s" % (i, err.raw[200 * i:200 * i + 200].split(b"\0")[0].decode()))
+        return wires, pis[:, :npi]
+
     def prover(self, ctx, hasher=0):
         """upload + preprocess the circuit on `ctx`'s GPU (zklc_plonky2_circuit_create)"""
         from .prover import Prover
@@ -620,7 +705,7 @@ class CircuitData:
                 if r is None:
                     r = rep[k] = b._find(k)
                 return r
-            self._plan = ([([find(t) for t in ins], fn) for ins, fn in b.generators], find)
+            self._plan = ([([find(t) for t in ins], fn, gi) for gi, (ins, fn, _, _) in enumerate(b.generators)], find)
         plan, find = self._plan
         vals = {}
 
@@ -636,15 +721,19 @@ class CircuitData:
         for t, v in inputs.items():
             setv(t, v)
         pending = plan
+        trace = self._trace
         while pending:
             rest = []
-            for ks, fn in pending:
+            for ks, fn, gi in pending:
                 try:
                     args = [vals[k] for k in ks]
                 except KeyError:
-                    rest.append((ks, fn))
+                    rest.append((ks, fn, gi))
                     continue
-                for t, v in fn(args):
+                outs = fn(args)
+                if trace is not None:
+                    trace.append((gi, [find(t) for t, _ in outs]))
+                for t, v in outs:
                     setv(t, v)
             assert len(rest) < len(pending), "witness generation stuck: %d generators without inputs" % len(rest)
             pending = rest
