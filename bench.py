@@ -332,6 +332,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
               ("recursion_2p12x135", 12, standard_recursion_config(), SY.recursion_shape_mix, HASH_GL, 16),
               ("wrap_bn128_2p12x135", 12, standard_recursion_config(), SY.recursion_shape_mix, HASH_BN128, 16)]
     out, provers, circuits = {}, {}, {}
+    ed_targets = None
     for name, bits, cfg, mixf, hasher, npi in shapes:
         host_s = None
         if mixf is None:
@@ -343,6 +344,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
             msg, e0 = bytes.fromhex(j["msg"]), j["entries"][0]
             bld = CircuitBuilder(cfg)
             targets = E.ed25519_circuit(bld, 8 * len(msg))
+            ed_targets = targets
             data = bld.build()
             t1 = time.perf_counter()
             ents = j["entries"]
@@ -382,63 +384,119 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         provers[name] = (fn, prover)
         circuits[name] = (data, d_w, pis, hasher)
         prover.close()
-    # one Block_i signature sub-DAG at 100 validators (signatures.rs:70-139): the Ed25519-shape proofs are independent,
-    # the recursion-shape proofs form the serial fold (proof i folds signature proof i into the running aggregate), then the
-    # BN128 wrap.  `--prove-streams` host threads, each with its own zklc context (= its own HIP stream, twiddle tables and
-    # scratch) and its own resident circuits, keep that many proofs in flight on the GPU; the last thread runs the fold chain.
+    # ---- one Block_i signature sub-DAG, end to end, on the reference's own fixture (BASELINE configs[1]/[2]):
+    # data/validators_ordered.json (100 validators) + data/next_block_header.json: 66 present approvals of one 41-byte message.
+    #   a3  batched Ed25519 pre-verification of the present approvals on the GPU (signatures.rs:79)
+    #   a5  native witness generation on the host cores (csrc/plonky2_witness.cpp), chunks of `wchunk` signatures, double-buffered
+    #       in pinned memory, overlapped with proving
+    #   a6  one proof of the reference Ed25519 circuit per approval; `--prove-streams` - 1 host threads, each with its own zklc
+    #       context (= HIP stream) and resident circuit, keep that many proofs in flight
+    #   a7  the serial fold: one recursion-shape proof per approval as soon as its signature proof exists, then the BN128 wrap
+    #       (synthetic circuits of the golden common_data shape: the recursive verifier circuit is not restated yet)
+    import queue
     import threading
     import zklc_amd
-    nthreads = max(1, args.prove_streams)
+    from zklc_amd.plonky2 import ed25519_circuit as E
+    ed_name = "ed25519_circuit_2p18x234"
+    ed_data = circuits[ed_name][0]
+    c2 = json.load(open(os.path.join(ROOT, "tests", "golden", "ed25519_near_c2_100.json")))
+    c2_msg = bytes.fromhex(c2["msg"])
+    present = [(bytes.fromhex(x["approval"])[2:], bytes.fromhex(x["validator_tail"])[1:33]) for x in c2["entries"]
+               if len(bytes.fromhex(x["approval"])) == 66]
+    n_sig = len(present)
+    fills = [E.fill_ecdsa_targets(ed_targets, c2_msg, sg, pk_) for sg, pk_ in present]
+    nthreads = max(2, args.prove_streams)
     workers = []
     for t in range(nthreads):
         wctx = ctx if t == 0 else zklc_amd.Context(torch.cuda.current_device())
         fns = {}
-        need = ["ed25519_circuit_2p18x234"] if (t < nthreads - 1 or nthreads == 1) else []
-        if t == nthreads - 1:
-            need += ["recursion_2p12x135", "wrap_bn128_2p12x135"]
-        for name in need:
-            data, d_w, pis, hasher = circuits[name]
-            pr = data.prover(wctx, hasher)
-            fn = (lambda pr=pr, d_w=d_w, pis=pis, sp=wctx.stream_ptr(): pr.prove_dev(d_w.data_ptr(), pis, stream=sp))
-            fn()
-            fns[name] = (fn, pr)
+        if t < nthreads - 1:
+            fns[ed_name] = ed_data.prover(wctx, HASH_GL)
+        else:
+            for name in ("recursion_2p12x135", "wrap_bn128_2p12x135"):
+                data, d_w, pis, hasher = circuits[name]
+                pr = data.prover(wctx, hasher)
+                fns[name] = (lambda pr=pr, d_w=d_w, pis=pis, sp=wctx.stream_ptr(): pr.prove_dev(d_w.data_ptr(), pis, stream=sp), pr)
+                fns[name][0]()
         workers.append((wctx, fns))
+    wchunk = max(1, min(12, host_cores() - nthreads))
+    nbuf = 2
+    nw_, n_rows = ed_data.config["num_wires"], ed_data.n
+    pinned = [torch.zeros((wchunk, nw_, n_rows), dtype=torch.int64).pin_memory() for _ in range(nbuf)]
+    views = [p_.numpy().view(np.uint64) for p_ in pinned]
+    for w in workers[:-1]:       # warm every Ed25519 prover once (also pages the pinned buffers in)
+        data_w, pis_w = ed_data.generate_witness_native(fills[:1], out=views[0][:1])
+        w[1][ed_name].prove_host_ptr(views[0][0].ctypes.data, [int(x) for x in pis_w[0]])
     barrier()
-    ed_done = [threading.Event() for _ in range(VALIDATORS)]
-    next_ed = [0]
+    ed_done = [threading.Event() for _ in range(n_sig)]
+    free_slots, ready = queue.Queue(), queue.Queue()
+    for sl in range(nbuf):
+        free_slots.put(sl)
+    slot_left = [0] * nbuf
     lock = threading.Lock()
     errors = []
+    tw = [0.0]
+
+    def fail(e):
+        errors.append(e)
+        for ev in ed_done:
+            ev.set()
+        for _ in range(nthreads):
+            ready.put(None)
+
+    def witness_producer():
+        try:
+            for c0 in range(0, n_sig, wchunk):
+                idx = list(range(c0, min(c0 + wchunk, n_sig)))
+                sl = free_slots.get()
+                t_ = time.perf_counter()
+                _, pis_ = ed_data.generate_witness_native([fills[i] for i in idx], out=views[sl][:len(idx)], threads=len(idx))
+                tw[0] += time.perf_counter() - t_
+                with lock:
+                    slot_left[sl] = len(idx)
+                for k, i in enumerate(idx):
+                    ready.put((i, sl, k, [int(x) for x in pis_[k]]))
+            for _ in range(nthreads):
+                ready.put(None)
+        except Exception as e:  # pragma: no cover
+            fail(e)
 
     def ed_worker(fns):
         try:
             while True:
-                with lock:
-                    i = next_ed[0]
-                    next_ed[0] += 1
-                if i >= VALIDATORS:
+                item = ready.get()
+                if item is None:
                     return
-                fns["ed25519_circuit_2p18x234"][0]()
+                i, sl, k, pis_ = item
+                fns[ed_name].prove_host_ptr(views[sl][k].ctypes.data, pis_)
                 ed_done[i].set()
+                with lock:
+                    slot_left[sl] -= 1
+                    if slot_left[sl] == 0:
+                        free_slots.put(sl)
         except Exception as e:  # pragma: no cover
-            errors.append(e)
-            for ev in ed_done:
-                ev.set()
+            fail(e)
 
-    def fold_worker(fns, also_ed):
+    def fold_worker(fns):
         try:
-            for i in range(VALIDATORS):
-                if also_ed:
-                    fns["ed25519_circuit_2p18x234"][0]()
-                else:
-                    ed_done[i].wait()
+            for i in range(n_sig):
+                ed_done[i].wait()
+                if errors:
+                    return
                 fns["recursion_2p12x135"][0]()
             fns["wrap_bn128_2p12x135"][0]()
         except Exception as e:  # pragma: no cover
-            errors.append(e)
+            fail(e)
 
+    pk_arr = np.frombuffer(b"".join(p_ for _, p_ in present), np.uint8)
+    sg_arr = np.frombuffer(b"".join(s_ for s_, _ in present), np.uint8)
     t0 = time.perf_counter()
-    threads = [threading.Thread(target=ed_worker, args=(w[1],)) for w in workers[:-1]]
-    threads.append(threading.Thread(target=fold_worker, args=(workers[-1][1], nthreads == 1)))
+    ok = ctx.ed25519_verify_batch(pk_arr, sg_arr, c2_msg)                       # a3: the native pre-check of signatures.rs:79
+    assert int(ok.sum()) == n_sig, "fixture approvals must verify"
+    t_verify = time.perf_counter() - t0
+    threads = [threading.Thread(target=witness_producer)]
+    threads += [threading.Thread(target=ed_worker, args=(w[1],)) for w in workers[:-1]]
+    threads.append(threading.Thread(target=fold_worker, args=(workers[-1][1],)))
     for th in threads:
         th.start()
     for th in threads:
@@ -447,19 +505,20 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     block_s = reduce_max(time.perf_counter() - t0)
     if errors:
         raise errors[0]
-    out["block_i"] = {"metric": "Block_i signature sub-DAG proofs/s (100 validators: 100 proofs of the reference Ed25519 circuit, the serial fold of 100 "
-                                "recursion-shape proofs, 1 BN128 wrap; %d proofs in flight per GPU; every rank proves its own block)"
-                                % nthreads,
+    out["block_i"] = {"metric": "Block_i signature sub-DAG proofs/s, end to end from the approval bytes (reference fixture: 100 validators, "
+                                "%d present approvals): GPU pre-verification, native witness generation, %d proofs of the reference "
+                                "Ed25519 circuit, serial fold of %d recursion-shape proofs, 1 BN128 wrap; every rank proves its own block"
+                                % (n_sig, n_sig, n_sig),
                       "value": world / block_s, "unit": "proofs/s", "seconds_per_block": block_s, "streams": nthreads,
+                      "approvals": n_sig, "witness_chunk": wchunk, "witness_cpu_seconds_total": tw[0], "preverify_ms": t_verify * 1e3,
                       "cpu_baseline": None,
-                      "note": "Ed25519 proofs: the reference circuit (restated) with one real signature witness repeated; recursion and "
-                              "wrap proofs: synthetic circuits of the reference's shape and gate types (the recursive verifier "
-                              "circuit is not restated yet); witness generation (SURVEY 8a row a5, host Python today) is outside "
-                              "the timed region; the reference CPU prover cannot be built here (no Rust toolchain) and publishes "
-                              "no time for this step"}
+                      "note": "signature proofs: the reference circuit (restated) on the fixture's real signatures, witness generation "
+                              "inside the timed region (host threads, overlapped); recursion and wrap proofs: synthetic circuits of "
+                              "the reference's shape and gate types (the recursive verifier circuit is not restated yet); the "
+                              "reference CPU prover cannot be built here (no Rust toolchain) and publishes no time for this step"}
     for wctx, fns in workers:
-        for _, pr in fns.values():
-            pr.close()
+        for v in fns.values():
+            (v[1] if isinstance(v, tuple) else v).close()
         if wctx is not ctx:
             wctx.close()
     for _, prover in provers.values():

@@ -192,13 +192,15 @@ int32_t zklc_poseidon_gl_gate_rows(const uint64_t *inputs, const uint64_t *swap,
 /* Native witness generation (host, multi-threaded; no GPU): executes the generator program of a circuit built by the host
  * builder -- the witness generators of crypto/plonky2_ed25519/src/gadgets/nonnative.rs:447-705, gadgets/curve.rs:327-370,
  * crypto/plonky2_ecdsa/src/gadgets/biguint.rs:417-470 and the gate generators of crypto/plonky2_u32/src/gates -- for
- * n_witnesses partial witnesses.  code = [opcode, n_params, n_in, n_out, params.., input slots.., output slots..]*,
- * a slot = one copy class of the circuit (zklc_amd/plonky2/builder.py `witness_program`).  wires_out: n_witnesses x
- * num_wires x n_rows u64, only the circuit's wire cells are written (zero-fill once, reuse); status[i] != 0 when
- * witness i does not exist (e.g. an invalid signature: "copy constraint violated"), message in err_out[200 i ..]. */
-int32_t zklc_plonky2_witness_run(const int64_t *code, uint64_t code_len, uint32_t n_slots, const uint32_t *input_slots,
-                                 uint32_t n_inputs, const uint64_t *input_values, uint32_t n_witnesses, const uint32_t *wire_slot,
-                                 const uint32_t *wire_col, const uint32_t *wire_row, uint64_t n_wire_entries, uint32_t num_wires,
+ * n_witnesses partial witnesses.  code (u32 words) = [opcode, n_params, n_in, n_out, input slots.., output slots..]*, the
+ * parameters of all instructions consecutive in `params`; a slot = one copy class of the circuit
+ * (zklc_amd/plonky2/builder.py `witness_program`).  wire_slot / wire_index (= col * n_rows + row): the wire cells.
+ * wires_out: n_witnesses x num_wires x n_rows u64, only the circuit's wire cells are written (zero-fill once, reuse);
+ * status[i] != 0 when witness i does not exist (e.g. an invalid signature: "copy constraint violated"), message in
+ * err_out[200 i ..]. */
+int32_t zklc_plonky2_witness_run(const uint32_t *code, uint64_t code_len, const int64_t *params, uint32_t n_slots,
+                                 const uint32_t *input_slots, uint32_t n_inputs, const uint64_t *input_values, uint32_t n_witnesses,
+                                 const uint32_t *wire_slot, const uint32_t *wire_index, uint64_t n_wire_entries, uint32_t num_wires,
                                  uint32_t n_rows, uint64_t *wires_out, const uint32_t *pi_slots, uint32_t n_pi, uint64_t *pi_out,
                                  int32_t *status, char *err_out, uint32_t threads);
 

@@ -275,24 +275,27 @@ struct Runner {
         return false;
     }
 
-    // code: [opcode, n_params, n_in, n_out, params..., ins..., outs...] repeated
-    bool run(const int64_t *code, u64 code_len, const u32 *in_slots, const u64 *in_vals, u32 n_inputs) {
+    // code (u32 words): [opcode, n_params, n_in, n_out, ins..., outs...] repeated; the parameters of all instructions are
+    // consecutive in `params` (64-bit: constants are field elements)
+    bool run(const u32 *code, u64 code_len, const int64_t *params, const u32 *in_slots, const u64 *in_vals, u32 n_inputs) {
         cur++;
         failed = false;
         for (u32 i = 0; i < n_inputs; i++)
             if (!set(in_slots[i], in_vals[i] % GLP, 0)) return false;
         std::vector<u64> in, out;
-        u64 pc = 0, ip = 0;
+        u64 pc = 0, ip = 0, pp = 0;
         while (ip < code_len) {
             int op = (int)code[ip];
-            u32 np = (u32)code[ip + 1], ni = (u32)code[ip + 2], no = (u32)code[ip + 3];
-            const int64_t *pr = code + ip + 4, *is = pr + np, *os = is + ni;
-            ip += 4 + np + ni + no;
+            u32 np = code[ip + 1], ni = code[ip + 2], no = code[ip + 3];
+            const int64_t *pr = params + pp;
+            const u32 *is = code + ip + 4, *os = is + ni;
+            ip += 4 + ni + no;
+            pp += np;
             pc++;
             in.resize(ni);
             for (u32 i = 0; i < ni; i++) {
-                if (epoch[(u32)is[i]] != cur) return fail("input not available", pc);
-                in[i] = val[(u32)is[i]];
+                if (epoch[is[i]] != cur) return fail("input not available", pc);
+                in[i] = val[is[i]];
             }
             out.clear();
             switch (op) {
@@ -504,20 +507,47 @@ struct Runner {
             }
             if (out.size() != no) return fail("output count mismatch", pc);
             for (u32 i = 0; i < no; i++)
-                if (!set((u32)os[i], out[i] % GLP, pc)) return false;
+                if (!set(os[i], out[i] % GLP, pc)) return false;
         }
         return true;
     }
 };
 
+// pool of interpreter states (value + epoch arrays are hundreds of MB for the Ed25519 circuit: keep them across calls)
+#include <mutex>
+static std::mutex g_pool_mutex;
+static std::vector<Runner *> g_pool;
+static Runner *runner_acquire(u32 n_slots) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mutex);
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (g_pool[i]->val.size() == n_slots) {
+                Runner *r = g_pool[i];
+                g_pool.erase(g_pool.begin() + i);
+                return r;
+            }
+    }
+    Runner *r = new Runner();
+    r->val.assign(n_slots, 0);
+    r->epoch.assign(n_slots, 0);
+    return r;
+}
+static void runner_release(Runner *r) {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    if (g_pool.size() < 32)
+        g_pool.push_back(r);
+    else
+        delete r;
+}
+
 // Runs the program for `n_witnesses` partial witnesses (input_values: n_witnesses x n_inputs) on up to `threads` host
-// threads.  wire_{slot,col,row}: the wires of every copy class (n_wire_entries); wires_out: n_witnesses matrices of
-// num_wires x n_rows u64 -- only the listed wire cells are written (the caller zero-fills the buffer once; the set of
-// written cells is the same for every witness of a circuit).  pi_out: n_witnesses x n_pi.  status[i] = 0 ok / 1 failed;
-// err_out (optional): n_witnesses x 200 bytes of messages.
-extern "C" int32_t zklc_plonky2_witness_run(const int64_t *code, uint64_t code_len, uint32_t n_slots, const uint32_t *input_slots,
-                                            uint32_t n_inputs, const uint64_t *input_values, uint32_t n_witnesses,
-                                            const uint32_t *wire_slot, const uint32_t *wire_col, const uint32_t *wire_row,
+// threads.  wire_slot / wire_index: the wire cells of every copy class (n_wire_entries), index = col * n_rows + row;
+// wires_out: n_witnesses matrices of num_wires x n_rows u64 -- only the listed cells are written (the caller zero-fills the
+// buffer once; the set of written cells is the same for every witness of a circuit).  pi_out: n_witnesses x n_pi.
+// status[i] = 0 ok / 1 failed; err_out (optional): n_witnesses x 200 bytes of messages.
+extern "C" int32_t zklc_plonky2_witness_run(const uint32_t *code, uint64_t code_len, const int64_t *params, uint32_t n_slots,
+                                            const uint32_t *input_slots, uint32_t n_inputs, const uint64_t *input_values,
+                                            uint32_t n_witnesses, const uint32_t *wire_slot, const uint32_t *wire_index,
                                             uint64_t n_wire_entries, uint32_t num_wires, uint32_t n_rows, uint64_t *wires_out,
                                             const uint32_t *pi_slots, uint32_t n_pi, uint64_t *pi_out, int32_t *status, char *err_out,
                                             uint32_t threads) {
@@ -526,19 +556,18 @@ extern "C" int32_t zklc_plonky2_witness_run(const int64_t *code, uint64_t code_l
     if (threads > n_witnesses) threads = n_witnesses ? n_witnesses : 1;
     std::atomic<u32> next(0);
     auto worker = [&]() {
-        Runner r;
-        r.val.assign(n_slots, 0);
-        r.epoch.assign(n_slots, 0);
+        Runner *rp = runner_acquire(n_slots);
+        Runner &r = *rp;
         for (;;) {
             u32 w = next.fetch_add(1);
-            if (w >= n_witnesses) return;
-            bool ok = r.run(code, code_len, input_slots, input_values + (size_t)w * n_inputs, n_inputs);
+            if (w >= n_witnesses) break;
+            bool ok = r.run(code, code_len, params, input_slots, input_values + (size_t)w * n_inputs, n_inputs);
             u64 *wires = wires_out + (size_t)w * num_wires * n_rows;
             if (ok) {
                 for (u64 k = 0; k < n_wire_entries; k++) {
                     u32 s = wire_slot[k];
                     if (r.epoch[s] != r.cur) continue;  // unconstrained cell of a class nobody assigned: stays as it is (zero)
-                    wires[(size_t)wire_col[k] * n_rows + wire_row[k]] = r.val[s];
+                    wires[wire_index[k]] = r.val[s];
                 }
                 for (u32 k = 0; k < n_pi; k++) {
                     if (r.epoch[pi_slots[k]] != r.cur) {
@@ -557,6 +586,7 @@ extern "C" int32_t zklc_plonky2_witness_run(const int64_t *code, uint64_t code_l
                     memcpy(err_out + (size_t)w * 200, r.err, 200);
             }
         }
+        runner_release(rp);
     };
     std::vector<std::thread> pool;
     for (u32 t = 1; t < threads; t++) pool.emplace_back(worker);

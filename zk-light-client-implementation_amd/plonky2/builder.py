@@ -613,25 +613,28 @@ class CircuitData:
             if s_ is None:
                 s_ = slot_of[k] = len(slot_of)
             return s_
-        code = []
+        code, pvals = [], []
         for gi, out_keys in trace:
             ins, _, op, params = b.generators[gi]
             assert op is not None, "generator without a native opcode"
-            code += [op, len(params), len(ins), len(out_keys)] + [x - (1 << 64) if x >= (1 << 63) else x for x in params]
+            code += [op, len(params), len(ins), len(out_keys)]
+            pvals += [x - (1 << 64) if x >= (1 << 63) else x for x in params]
             code += [slot(find(t)) for t in ins] + [slot(k) for k in out_keys]
         in_targets = list(example_inputs.keys())
-        ws, wc, wr = [], [], []
+        ws, wi = [], []
+        n_rows = self.n
         for k in list(b.parent) + [k for k in slot_of if k[0] == "w" and k not in b.parent]:
             if k[0] == "w":
                 r = b._find(k)
                 if r in slot_of:
                     ws.append(slot_of[r])
-                    wc.append(k[2])
-                    wr.append(k[1])
+                    wi.append(k[2] * n_rows + k[1])
+        assert self.config["num_wires"] * n_rows < (1 << 32)
+        order = np.argsort(np.array(wi, dtype=np.int64), kind="stable")      # scatter in address order
         self._program = {
-            "code": np.array(code, dtype=np.int64), "n_slots": len(slot_of) + len(in_targets) + 1,
+            "code": np.array(code, dtype=np.uint32), "params": np.array(pvals + [0], dtype=np.int64),
             "input_targets": in_targets, "input_slots": np.array([slot(find(t)) for t in in_targets], dtype=np.uint32),
-            "wire_slot": np.array(ws, dtype=np.uint32), "wire_col": np.array(wc, dtype=np.uint32), "wire_row": np.array(wr, dtype=np.uint32),
+            "wire_slot": np.array(ws, dtype=np.uint32)[order], "wire_index": np.array(wi, dtype=np.uint32)[order],
             "pi_slots": np.array([slot(find(t)) for t in b.public_inputs], dtype=np.uint32),
         }
         self._program["n_slots"] = len(slot_of) + 1
@@ -657,9 +660,9 @@ class CircuitData:
         err = ctypes.create_string_buffer(200 * k)
         threads = threads or min(k, len(os.sched_getaffinity(0)))
         rc = _lib.load().zklc_plonky2_witness_run(
-            pr["code"].ctypes.data, len(pr["code"]), pr["n_slots"], pr["input_slots"].ctypes.data, vals.shape[1], vals.ctypes.data, k,
-            pr["wire_slot"].ctypes.data, pr["wire_col"].ctypes.data, pr["wire_row"].ctypes.data, len(pr["wire_slot"]), nw, self.n,
-            wires.ctypes.data, pr["pi_slots"].ctypes.data, npi, pis.ctypes.data, status.ctypes.data, err, threads)
+            pr["code"].ctypes.data, len(pr["code"]), pr["params"].ctypes.data, pr["n_slots"], pr["input_slots"].ctypes.data,
+            vals.shape[1], vals.ctypes.data, k, pr["wire_slot"].ctypes.data, pr["wire_index"].ctypes.data, len(pr["wire_slot"]), nw,
+            self.n, wires.ctypes.data, pr["pi_slots"].ctypes.data, npi, pis.ctypes.data, status.ctypes.data, err, threads)
         if rc != 0:
             raise ValueError("zklc_plonky2_witness_run: invalid argument")
         for i in range(k):

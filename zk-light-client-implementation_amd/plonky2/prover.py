@@ -115,6 +115,16 @@ class Prover:
         self.ctx._check(rc)
         return bytes(out[:ln.value])
 
+    def prove_host_ptr(self, wires_ptr, public_inputs):
+        """wires_ptr: address of a host (ideally pinned) uint64 [num_wires, n] matrix -> proof bytes"""
+        pis = np.array([int(x) for x in public_inputs], dtype=np.uint64)
+        out = np.zeros(self.proof_bytes, dtype=np.uint8)
+        ln = ctypes.c_uint64()
+        rc = self._lib.zklc_plonky2_prove(self.ctx._h, self._h, wires_ptr, pis.ctypes.data if len(pis) else None,
+                                          out.ctypes.data, out.size, ctypes.byref(ln))
+        self.ctx._check(rc)
+        return bytes(out[:ln.value])
+
     def prove(self, wires, public_inputs):
         """-> proof in the reference's proof.json schema"""
         return S.proof_from_bytes(self.prove_bytes(wires, public_inputs), self.common, self.hasher)
