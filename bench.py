@@ -419,7 +419,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                 fns[name] = (lambda pr=pr, d_w=d_w, pis=pis, sp=wctx.stream_ptr(): pr.prove_dev(d_w.data_ptr(), pis, stream=sp), pr)
                 fns[name][0]()
         workers.append((wctx, fns))
-    wchunk = max(1, min(12, host_cores() - nthreads))
+    wchunk = max(1, min(12, host_cores() // max(1, world) - nthreads))   # host threads of this rank's witness producer
     nbuf = 2
     nw_, n_rows = ed_data.config["num_wires"], ed_data.n
     pinned = [torch.zeros((wchunk, nw_, n_rows), dtype=torch.int64).pin_memory() for _ in range(nbuf)]
