@@ -9,6 +9,7 @@
 // contiguous) AND for leaf hashing with one lane per leaf (for every column p the
 // 64 lanes of a wave read 64 consecutive u64 = 512 contiguous bytes), so the
 // "transpose to row-major leaves" pass of the CPU prover disappears.
+#include <stdlib.h>
 #include "poseidon_gl.cuh"
 #include "zklc_internal.h"
 
@@ -20,6 +21,23 @@
 __global__ void gl_pow_table_kernel(u64 *out, u64 base, u64 n, u64 exp_stride) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = gl_pow(base, i * exp_stride);
+}
+
+// staged twiddles: for every stage s the values w^(j << s), j < n / 2^(s+1), contiguous at offset n - (n >> s)
+// (n entries in total).  Lanes with consecutive j read consecutive words, whereas tw[j << s] of the flat table puts every
+// lane of a wave on its own cache line from stage 1 on -- the texture-address unit, not the VALU, was the limit.
+__global__ void gl_staged_twiddle_kernel(u64 *out, u64 w, u32 logn) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 n = 1ULL << logn;
+    if (i >= n - 1) {
+        if (i == n - 1) out[i] = 1;
+        return;
+    }
+    // i = n - (n >> s) + j  with j < n >> (s + 1):  s = number of leading ones of i in logn bits
+    u32 s = 0;
+    while (i >= n - (n >> (s + 1))) s++;
+    u64 j = i - (n - (n >> s));
+    out[i] = gl_pow(w, j << s);
 }
 
 // ---------------------------------------------------------------- NTT passes
@@ -104,6 +122,112 @@ gl_ntt_pass_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t in_
     }
 }
 
+// ---- radix-8 variant of the pass: the k stages of a pass are done in groups of 3 (then 2 or 1): a lane loads the 8
+// elements of a radix-8 butterfly group from the LDS tile, does its 12 butterflies in registers and writes them back --
+// a third of the LDS traffic and of the barriers of the radix-2 loop above, and 7 instead of 12 twiddle loads.
+// For the group of stages s'..s'+g-1 (s' = s0 + t0) on elements base | m << pb_low the twiddle of the butterfly of stage
+// s'+u whose lower element has group bits m is  w^(((m mod 2^(g-1-u)) << (logn - g + u)) + (J << (s' + u)))  with
+// J = the index bits below the group; all of them are entries of the one table tw[i] = w^i, i < n/2.
+// LDS tile padded by one element per 8 (index e + e/8) so that both the unit-stride and the stride-8 groups spread
+// over the banks.
+#define NTT_TI(e) ((e) + ((e) >> 3))
+template <int G, bool DIT>
+ZKLC_D void gl_ntt_group(u64 *tile, const u64 *__restrict__ tws, u64 n_full, u32 base, int pb_low, u64 J, int sh, int hi_shift) {
+    constexpr int M = 1 << G;
+    u64 x[M];
+#pragma unroll
+    for (int m = 0; m < M; m++) x[m] = tile[NTT_TI(base | ((u32)m << pb_low))];
+#pragma unroll
+    for (int uu = 0; uu < G; uu++) {
+        const int u = DIT ? (G - 1 - uu) : uu;   // stage within the group; DIT runs the stages backwards
+        const int bit = G - 1 - u;
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            if (m & (1 << bit)) continue;
+            const u64 lp = (u64)(m & ((1 << bit) - 1));
+            u64 w = tws[(n_full - (n_full >> (sh + u))) + ((lp << hi_shift) + J)];
+            u64 a = x[m], b = x[m | (1 << bit)];
+            if (DIT) {
+                b = gl_mul(b, w);
+                x[m] = gl_add(a, b);
+                x[m | (1 << bit)] = gl_sub(a, b);
+            } else {
+                x[m] = gl_add(a, b);
+                x[m | (1 << bit)] = gl_mul(gl_sub(a, b), w);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; m++) tile[NTT_TI(base | ((u32)m << pb_low))] = x[m];
+}
+
+template <bool DIT>
+__global__ void __launch_bounds__(NTT_THREADS)
+gl_ntt_pass_r8_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t in_stride, size_t out_stride, ntt_pass p,
+                      const u64 *__restrict__ tw, const u64 *__restrict__ scale_hi, const u64 *__restrict__ scale_lo) {
+    __shared__ u64 tile[NTT_TILE_MAX + NTT_TILE_MAX / 8];
+    const int tile_log = p.k + p.c + p.d;
+    const int tile_n = 1 << tile_log;
+    const int lowbits = p.logn - p.s0 - p.k;
+    const u32 tid = threadIdx.x;
+    const u64 t_id = blockIdx.x;
+    const u64 tileL = t_id & ((1ULL << (lowbits - p.c)) - 1);
+    const u64 tileH = t_id >> (lowbits - p.c);
+    const u64 *src = in + (size_t)blockIdx.y * in_stride;
+    u64 *dst = out + (size_t)blockIdx.y * out_stride;
+
+    auto global_index = [&](u32 e) -> u64 {
+        u64 lowc = e & ((1u << p.c) - 1);
+        u64 mid = (e >> p.c) & ((1u << p.k) - 1);
+        u64 hid = e >> (p.c + p.k);
+        u64 L = (tileL << p.c) | lowc;
+        u64 H = (tileH << p.d) | hid;
+        return (H << (lowbits + p.k)) | (mid << lowbits) | L;
+    };
+
+    for (u32 e = tid; e < (u32)tile_n; e += NTT_THREADS) {
+        u64 g = global_index(e);
+        u64 v = 0;
+        if (g < (1ULL << p.log_in)) {
+            v = src[g];
+            if (p.scale_shift) v = gl_mul(v, gl_mul(scale_hi[g >> p.scale_shift], scale_lo[g & ((1u << p.scale_shift) - 1)]));
+        }
+        tile[NTT_TI(e)] = v;
+    }
+    __syncthreads();
+
+    int done = 0;
+    while (done < p.k) {
+        const int g = p.k - done >= 3 ? 3 : p.k - done;
+        const int t0 = DIT ? (p.k - done - g) : done;      // first (lowest-numbered) stage of the group
+        const int mg = p.k - g - t0;                        // number of `mid` bits below the group
+        const int pb_low = p.c + mg;
+        const int sh = p.s0 + t0;
+        const int hi_shift = mg + lowbits;
+        const u32 n_groups = (u32)tile_n >> g;
+        for (u32 gi = tid; gi < n_groups; gi += NTT_THREADS) {
+            u32 base = ((gi >> pb_low) << (pb_low + g)) | (gi & ((1u << pb_low) - 1));
+            u64 lowc = base & ((1u << p.c) - 1);
+            u64 mid_low = (base >> p.c) & ((1u << mg) - 1);
+            u64 J = (mid_low << lowbits) | ((tileL << p.c) | lowc);
+            if (g == 3)
+                gl_ntt_group<3, DIT>(tile, tw, 1ULL << p.logn, base, pb_low, J, sh, hi_shift);
+            else if (g == 2)
+                gl_ntt_group<2, DIT>(tile, tw, 1ULL << p.logn, base, pb_low, J, sh, hi_shift);
+            else
+                gl_ntt_group<1, DIT>(tile, tw, 1ULL << p.logn, base, pb_low, J, sh, hi_shift);
+        }
+        __syncthreads();
+        done += g;
+    }
+
+    for (u32 e = tid; e < (u32)tile_n; e += NTT_THREADS) {
+        u64 v = tile[NTT_TI(e)];
+        if (p.out_scale != 1) v = gl_mul(v, p.out_scale);
+        dst[global_index(e)] = v;
+    }
+}
+
 // out[i] = in[bitrev(i)] (per polynomial)
 __global__ void __launch_bounds__(256) gl_bitrev_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t stride, int logn) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -171,7 +295,9 @@ void zklc_gl_fini(zklc_ctx *ctx) {
     for (int i = 0; i <= ZKLC_GL_MAX_LOG; i++) {
         if (ctx->gl_tw_fwd[i]) (void)hipFree(ctx->gl_tw_fwd[i]);
         if (ctx->gl_tw_inv[i]) (void)hipFree(ctx->gl_tw_inv[i]);
-        ctx->gl_tw_fwd[i] = ctx->gl_tw_inv[i] = nullptr;
+        if (ctx->gl_tws_fwd[i]) (void)hipFree(ctx->gl_tws_fwd[i]);
+        if (ctx->gl_tws_inv[i]) (void)hipFree(ctx->gl_tws_inv[i]);
+        ctx->gl_tw_fwd[i] = ctx->gl_tw_inv[i] = ctx->gl_tws_fwd[i] = ctx->gl_tws_inv[i] = nullptr;
     }
     if (ctx->gl_scale_hi) (void)hipFree(ctx->gl_scale_hi);
     if (ctx->gl_scale_lo) (void)hipFree(ctx->gl_scale_lo);
@@ -188,6 +314,20 @@ static int32_t gl_get_twiddles(zklc_ctx *ctx, hipStream_t st, int logn, bool inv
         if (inverse) w = host_gl_pow(w, GL_P - 2);
         hipLaunchKernelGGL(gl_pow_table_kernel, dim3((unsigned)((n_half + 255) / 256)), dim3(256), 0, st, (u64 *)*slot, w, n_half,
                            (u64)1);
+        ZKLC_HIP(ctx, hipGetLastError());
+    }
+    *out = (const u64 *)*slot;
+    return ZKLC_OK;
+}
+
+static int32_t gl_get_staged_twiddles(zklc_ctx *ctx, hipStream_t st, int logn, bool inverse, const u64 **out) {
+    void **slot = inverse ? &ctx->gl_tws_inv[logn] : &ctx->gl_tws_fwd[logn];
+    if (!*slot) {
+        u64 n = 1ULL << logn;
+        ZKLC_HIP(ctx, hipMalloc(slot, n * 8));
+        u64 w = host_gl_pow(GL_POWER_OF_TWO_GENERATOR, 1ULL << (32 - logn));
+        if (inverse) w = host_gl_pow(w, GL_P - 2);
+        hipLaunchKernelGGL(gl_staged_twiddle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (u64 *)*slot, w, (u32)logn);
         ZKLC_HIP(ctx, hipGetLastError());
     }
     *out = (const u64 *)*slot;
@@ -223,8 +363,9 @@ static int32_t gl_ntt_run(zklc_ctx *ctx, hipStream_t st, const u64 *in, size_t i
                 ZKLC_HIP(ctx, hipMemcpyAsync(out + b * out_stride, in + b * in_stride, 8, hipMemcpyDeviceToDevice, st));
         return ZKLC_OK;
     }
+    static const bool radix2 = getenv("ZKLC_NTT_RADIX2") != nullptr;   // A/B switch: the original one-stage-per-barrier loop
     const u64 *tw;
-    int32_t rc = gl_get_twiddles(ctx, st, logn, inverse, &tw);
+    int32_t rc = radix2 ? gl_get_twiddles(ctx, st, logn, inverse, &tw) : gl_get_staged_twiddles(ctx, st, logn, inverse, &tw);
     if (rc) return rc;
     if (load_shift) {
         if ((rc = gl_get_scale(ctx, st, load_shift, log_in))) return rc;
@@ -262,12 +403,20 @@ static int32_t gl_ntt_run(zklc_ctx *ctx, hipStream_t st, const u64 *in, size_t i
         const u64 *src = first ? in : out;
         size_t sstride = first ? in_stride : out_stride;
         dim3 grid((unsigned)(1ULL << (logn - (p.k + p.c + p.d))), batch);
-        if (dit)
-            hipLaunchKernelGGL(gl_ntt_pass_kernel<true>, grid, dim3(NTT_THREADS), 0, st, src, out, sstride, out_stride, p, tw,
+        if (radix2) {
+            if (dit)
+                hipLaunchKernelGGL(gl_ntt_pass_kernel<true>, grid, dim3(NTT_THREADS), 0, st, src, out, sstride, out_stride, p, tw,
+                                   (const u64 *)ctx->gl_scale_hi, (const u64 *)ctx->gl_scale_lo);
+            else
+                hipLaunchKernelGGL(gl_ntt_pass_kernel<false>, grid, dim3(NTT_THREADS), 0, st, src, out, sstride, out_stride, p, tw,
+                                   (const u64 *)ctx->gl_scale_hi, (const u64 *)ctx->gl_scale_lo);
+        } else if (dit) {
+            hipLaunchKernelGGL(gl_ntt_pass_r8_kernel<true>, grid, dim3(NTT_THREADS), 0, st, src, out, sstride, out_stride, p, tw,
                                (const u64 *)ctx->gl_scale_hi, (const u64 *)ctx->gl_scale_lo);
-        else
-            hipLaunchKernelGGL(gl_ntt_pass_kernel<false>, grid, dim3(NTT_THREADS), 0, st, src, out, sstride, out_stride, p, tw,
+        } else {
+            hipLaunchKernelGGL(gl_ntt_pass_r8_kernel<false>, grid, dim3(NTT_THREADS), 0, st, src, out, sstride, out_stride, p, tw,
                                (const u64 *)ctx->gl_scale_hi, (const u64 *)ctx->gl_scale_lo);
+        }
         ZKLC_HIP(ctx, hipGetLastError());
     }
     return ZKLC_OK;

@@ -23,6 +23,9 @@ struct zklc_ctx {
     // Goldilocks: twiddle tables w^i (i < 2^(logn-1)) per transform size, forward and inverse
     void *gl_tw_fwd[ZKLC_GL_MAX_LOG + 1] = {};
     void *gl_tw_inv[ZKLC_GL_MAX_LOG + 1] = {};
+    // staged tables (per stage s: w^(j << s) contiguous), used by the radix-8 passes
+    void *gl_tws_fwd[ZKLC_GL_MAX_LOG + 1] = {};
+    void *gl_tws_inv[ZKLC_GL_MAX_LOG + 1] = {};
     // two-level table of coset-shift powers (shift^j = hi[j >> 10] * lo[j & 1023])
     void *gl_scale_hi = nullptr, *gl_scale_lo = nullptr;
     uint64_t gl_scale_shift = 0;
