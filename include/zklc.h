@@ -203,6 +203,8 @@ int32_t zklc_plonky2_witness_run(const uint32_t *code, uint64_t code_len, const 
                                  const uint32_t *wire_slot, const uint32_t *wire_index, uint64_t n_wire_entries, uint32_t num_wires,
                                  uint32_t n_rows, uint64_t *wires_out, const uint32_t *pi_slots, uint32_t n_pi, uint64_t *pi_out,
                                  int32_t *status, char *err_out, uint32_t threads);
+/* the interpreter keeps its per-thread state (value arrays, one per slot) cached across calls; this frees the cache */
+void zklc_plonky2_witness_release(void);
 
 /* ---- (c) BN254 ---------------------------------------------------------------
  * G1 multi-scalar multiplication sum_i scalars[i] * points[i].

@@ -453,6 +453,7 @@ struct p2_batch {
 
 struct zklc_plonky2_circuit {
     zklc_ctx *ctx = nullptr;
+    int device = 0;   // copied from the context: destroying the circuit must not touch a context that is already gone
     zklc_plonky2_params P;
     u32 n = 0, N = 0, lde_bits = 0, nchunks = 0;
     std::vector<p2_gate> gates;
@@ -551,8 +552,8 @@ static int32_t p2_hash_no_pad(zklc_plonky2_circuit *c, hipStream_t st, const std
 
 extern "C" void zklc_plonky2_circuit_destroy(zklc_plonky2_circuit *c) {
     if (!c) return;
-    (void)hipSetDevice(c->ctx->device);
-    (void)hipStreamSynchronize(c->ctx->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
     for (void *p : c->allocs) (void)hipFree(p);
     delete c;
 }
@@ -562,6 +563,7 @@ static int32_t p2_create(zklc_ctx *ctx, const zklc_plonky2_params *params, const
                          zklc_plonky2_circuit *c) {
     const zklc_plonky2_params &P = *params;
     c->ctx = ctx;
+    c->device = ctx->device;
     c->P = P;
     c->n = 1u << P.degree_bits;
     c->lde_bits = P.degree_bits + P.rate_bits;

@@ -534,10 +534,16 @@ static Runner *runner_acquire(u32 n_slots) {
 }
 static void runner_release(Runner *r) {
     std::lock_guard<std::mutex> lk(g_pool_mutex);
-    if (g_pool.size() < 32)
+    if (g_pool.size() < 16)
         g_pool.push_back(r);
     else
         delete r;
+}
+// frees the cached interpreter states (hundreds of MB each for the Ed25519 circuit)
+extern "C" void zklc_plonky2_witness_release(void) {
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    for (Runner *r : g_pool) delete r;
+    g_pool.clear();
 }
 
 // Runs the program for `n_witnesses` partial witnesses (input_values: n_witnesses x n_inputs) on up to `threads` host
