@@ -189,6 +189,10 @@ uint32_t zklc_plonky2_last_timings(zklc_plonky2_circuit *c, double *out_ms, uint
 /* PoseidonGate witness rows (host function, no GPU): inputs n x 12, swap n (0/1, NULL = all 0) -> rows n x 135
  * in the wire layout of gnark-plonky2-verifier/plonk/gates/poseidon_gate.go:27-82 */
 int32_t zklc_poseidon_gl_gate_rows(const uint64_t *inputs, const uint64_t *swap, uint32_t n, uint64_t *rows);
+/* Poseidon-Goldilocks parameters (gnark-plonky2-verifier/poseidon/goldilocks_constants.go): all round constants (30 x 12),
+ * the optimised partial-round constants (first layer 12, one per round 22), MDS circulant + diagonal.  Used by the host
+ * circuit builder to restate PoseidonGate's constraints in-circuit (recursive verifier). */
+void zklc_poseidon_gl_constants(uint64_t *rc360, uint64_t *fp_first12, uint64_t *fp_rc22, uint64_t *mds_circ12, uint64_t *mds_diag12);
 /* Native witness generation (host, multi-threaded; no GPU): executes the generator program of a circuit built by the host
  * builder -- the witness generators of crypto/plonky2_ed25519/src/gadgets/nonnative.rs:447-705, gadgets/curve.rs:327-370,
  * crypto/plonky2_ecdsa/src/gadgets/biguint.rs:417-470 and the gate generators of crypto/plonky2_u32/src/gates -- for

@@ -51,6 +51,17 @@ uint64_t zklc_challenger::challenge() {
 
 // One PoseidonGate row per input state: wires 0..12 inputs, 12..24 outputs, 24 swap, 25..29 deltas,
 // 29..65 / 65..87 / 87..135 the S-box inputs (gnark-plonky2-verifier/plonk/gates/poseidon_gate.go:27-82).
+extern "C" void zklc_poseidon_gl_constants(uint64_t *rc360, uint64_t *fp_first12, uint64_t *fp_rc22, uint64_t *mds_circ12, uint64_t *mds_diag12) {
+    for (int i = 0; i < 360; i++) rc360[i] = PGL_RC[i];
+    for (int i = 0; i < 12; i++) fp_first12[i] = PGL_FP_FIRST[i];
+    for (int i = 0; i < 22; i++) fp_rc22[i] = PGL_FP_RC[i];
+    static const uint64_t circ[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    for (int i = 0; i < 12; i++) {
+        mds_circ12[i] = circ[i];
+        mds_diag12[i] = i == 0 ? 8 : 0;
+    }
+}
+
 extern "C" int32_t zklc_poseidon_gl_gate_rows(const uint64_t *inputs, const uint64_t *swap, uint32_t n, uint64_t *rows) {
     if (!inputs || !rows) return -1;
     for (uint32_t k = 0; k < n; k++) {

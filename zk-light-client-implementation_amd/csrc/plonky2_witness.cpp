@@ -498,7 +498,8 @@ struct Runner {
                 }
                 case OP_POSEIDON: {
                     u64 rows[135];
-                    if (zklc_poseidon_gl_gate_rows(in.data(), nullptr, 1, rows)) return fail("poseidon rows", pc);
+                    if (ni != 13 || in[12] > 1) return fail("poseidon: 12 inputs and a boolean swap expected", pc);
+                    if (zklc_poseidon_gl_gate_rows(in.data(), in.data() + 12, 1, rows)) return fail("poseidon rows", pc);
                     for (int c = 12; c < 135; c++)
                         if (c != 24) out.push_back(rows[c]);
                     break;

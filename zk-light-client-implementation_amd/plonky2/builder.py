@@ -439,19 +439,20 @@ class CircuitBuilder:
         return w[3], w[4]
 
     # ---- Poseidon (PoseidonGate rows); witness rows come from the library (zklc_poseidon_gl_gate_rows)
-    def permute(self, state12):
+    def permute(self, state12, swap=None):
+        """one PoseidonGate row; `swap` (a boolean target) exchanges inputs 0..4 and 4..8 first (plonky2 `permute_swapped`)"""
         row = self.add_gate(G.PoseidonGate())
         ins = [Target(row, i) for i in range(12)]
         for a, b in zip(state12, ins):
             self.connect(a, b)
-        swap = Target(row, G.PoseidonGate.WIRE_SWAP)
-        self.connect(swap, self.zero())
+        sw = Target(row, G.PoseidonGate.WIRE_SWAP)
+        self.connect(sw, self.zero() if swap is None else swap)
 
         def gen(v, row=row):
             from .prover import poseidon_gate_rows
-            r = poseidon_gate_rows(np.array([v], dtype=np.uint64), np.zeros(1, dtype=np.uint64))[0]
+            r = poseidon_gate_rows(np.array([v[:12]], dtype=np.uint64), np.array([v[12]], dtype=np.uint64))[0]
             return [(Target(row, c), int(r[c])) for c in range(12, 135) if c != 24]
-        self.add_generator(ins, gen, OP_POSEIDON)
+        self.add_generator(ins + [sw], gen, OP_POSEIDON)
         return [Target(row, 12 + i) for i in range(12)]
 
     def hash_n_to_hash_no_pad(self, inputs):

@@ -204,6 +204,10 @@ class ExponentiationGate(Gate):
         self.num_wires = 2 + 2 * num_power_bits
         self.params = (num_power_bits, 0, 0, 0)
 
+    @staticmethod
+    def new_from_config(cfg):
+        return ExponentiationGate(min(cfg["num_routed_wires"] - 2, (cfg["num_wires"] - 2) // 2))
+
     def id(self):
         return "ExponentiationGate { num_power_bits: %d, _phantom: %s }<D=2>" % (self.num_power_bits, _PH)
 
