@@ -294,7 +294,12 @@ class RecursiveCircuitBuilder(CircuitBuilder):
         return out
 
     def exp_from_bits_const_base(self, base, bits):
-        return self.exp_from_bits(self.constant(base), bits)
+        """base^(sum bits_i 2^i) for a constant base with ArithmeticGate operations: product *= 1 + bit (base^(2^i) - 1)
+        (the reference's recursion circuits contain no ExponentiationGate: near_bft_finality/proofs/*/common_data.json)"""
+        product = self.one()
+        for i, bit in enumerate(bits):
+            product = self.arithmetic(pow(base, 1 << i, P) - 1, product, bit, 1, product)
+        return product
 
     # ---- CosetInterpolationGate
     def interpolate_coset(self, gate, shift, values, point):
