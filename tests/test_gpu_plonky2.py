@@ -134,21 +134,29 @@ def test_reference_sha512_circuit_proof(zctx):
     print("sha512 circuit: 2^14 rows, proof stages", prover.last_timings())
 
 
-def test_reference_ed25519_circuit_proof_of_a_near_mainnet_signature(zctx):
+@pytest.fixture(scope="module")
+def approval_prover(zctx):
+    """ApprovalProver with the reference's per-signature circuit built once for the module (a few minutes of host Python)"""
+    from zklc_amd.signatures import ApprovalProver
+    ap = ApprovalProver(zctx)
+    ap.ed25519_circuit(41)
+    yield ap
+    ap.close()
+
+
+def test_reference_ed25519_circuit_proof_of_a_near_mainnet_signature(zctx, approval_prover):
     """the reference's per-signature circuit (crypto/plonky2_ed25519/src/gadgets/eddsa.rs:34-85, restated in
     zklc_amd/plonky2/ed25519_circuit.py: SHA-512 + two point decompressions + windowed [h]A + fixed-base [s]B over
     non-native 2^255-19 arithmetic) on a real approval signature of the NEAR fixture data/*_small.json: host witness
     generation, GPU proof, verifier restatement accepts; public inputs = message bits then public-key bits.
     Building the 181k-row circuit and its witness in Python takes a few minutes of host time."""
     from conftest import load_golden
-    from zklc_amd.plonky2 import wide_ecc_config, ed25519_circuit as E, sha512
+    from zklc_amd.plonky2 import ed25519_circuit as E, sha512
     j = load_golden("ed25519_near_c1_small.json")
     msg = bytes.fromhex(j["msg"])
     e = j["entries"][0]
     pk, sig = bytes.fromhex(e["validator_tail"])[1:33], bytes.fromhex(e["approval"])[2:]
-    b = CircuitBuilder(wide_ecc_config())
-    targets = E.ed25519_circuit(b, 8 * len(msg))
-    data = b.build()
+    data, targets, prover, vd = approval_prover.ed25519_circuit(len(msg))
     assert data.n == 1 << 18 and data.num_public_inputs == 8 * len(msg) + 256
     import time
     wires, pis = data.generate_witness(E.fill_ecdsa_targets(targets, msg, sig, pk))
@@ -165,9 +173,51 @@ def test_reference_ed25519_circuit_proof_of_a_near_mainnet_signature(zctx):
     bad[40] ^= 1
     with pytest.raises(AssertionError):
         data.generate_witness_native([E.fill_ecdsa_targets(targets, msg, bytes(bad), pk)])
-    prover = data.prover(zctx, HASH_GL)
-    V.verify(json.loads(json.dumps(prover.prove(wn[2], [int(x) for x in pn[2]]))), prover.verifier_data(), data.common_data())
+    V.verify(json.loads(json.dumps(prover.prove(wn[2], [int(x) for x in pn[2]]))), vd, data.common_data())
     proof = prover.prove(wires, pis)
     print("ed25519 circuit: 2^18 rows x 234 wires, 20 gate types; proof stages", prover.last_timings())
-    V.verify(json.loads(json.dumps(proof)), prover.verifier_data(), data.common_data())
+    V.verify(json.loads(json.dumps(proof)), vd, data.common_data())
     assert proof["public_inputs"] == pis
+
+
+def test_prove_approvals_on_the_reference_small_fixture(zctx, approval_prover):
+    """`prove_approvals` (near_bft_finality/src/prove_block_data/signatures.rs:43-141; its own test :287-367 runs it on
+    data/*_small.json = BASELINE configs[0]): 3 approvals -> 3 Ed25519-circuit proofs, the left fold of two `recursive_proof`
+    calls (in-circuit verification of an Ed25519 proof and of a recursion proof), and the closing recursion whose 32 public
+    inputs are sha256(valid_keys).  Every recursion proof is checked by the verifier restatement."""
+    import hashlib
+    from conftest import load_golden, near_set_arrays
+    j = load_golden("ed25519_near_c1_small.json")
+    msg, approvals, validators = near_set_arrays(j)
+    rec = approval_prover.recursion
+    seen = []
+    orig = rec.recursive_proof
+
+    def checked(first, second=None, public_inputs=None):
+        rc, proof = orig(first, second, public_inputs)
+        V.verify(json.loads(json.dumps(proof)), rc.verifier_only, rc.common)
+        seen.append((rc.data.n, len(rc.common["gates"]), rc.prover.last_timings()["total"]))
+        return rc, proof
+    rec.recursive_proof = checked
+    try:
+        (rc, proof), valid_keys = approval_prover.prove_approvals(msg, approvals, validators)
+    finally:
+        rec.recursive_proof = orig
+    n_present = sum(1 for a in approvals if len(a) == 66)
+    assert len(seen) == n_present                      # n - 1 folds + the closing proof
+    assert len(valid_keys) == 33 * n_present
+    assert proof["public_inputs"] == list(hashlib.sha256(valid_keys).digest())
+    print("prove_approvals: recursion proofs (rows, gate types, GPU ms):", seen)
+    # a tampered inner proof has no witness: recursion.rs:127-158 (test_recursive_proof_invalid)
+    bad = json.loads(json.dumps(proof))
+    bad["public_inputs"][-1] = 10000
+    with pytest.raises(AssertionError):
+        rec.recursive_proof((rc.common, rc.verifier_only, bad))
+    # the last recursion of the reference (bin/prove_block.rs:279-287): the same verifier circuit, Poseidon-BN128 Merkle caps
+    from zklc_amd.plonky2.recursion import RecursionProver
+    wrap = RecursionProver(zctx, HASH_BN128)
+    wrc, wproof = wrap.recursive_proof((rc.common, rc.verifier_only, proof))
+    V.verify(json.loads(json.dumps(wproof)), wrc.verifier_only, wrc.common)
+    golden = load_golden("plonky2_near_random_CGZP.json")["common_data"]
+    assert wrc.common["gates"] == golden["gates"]      # the wrap circuit has the gate list of the reference's final proofs
+    wrap.close()

@@ -245,8 +245,25 @@ static Big big_small(u32 x) {
 
 enum {
     OP_CONST = 0, OP_ARITH, OP_SPLIT, OP_LE_SUM, OP_U32_MULADD, OP_ADD_MANY, OP_SUB_U32, OP_RANGE_CHECK, OP_COMPARISON, OP_IS_EQUAL,
-    OP_RANDOM_ACCESS, OP_NN_ADD, OP_NN_SUB, OP_NN_MUL, OP_NN_INV, OP_DIV_REM, OP_DECOMPRESS, OP_POSEIDON
+    OP_RANDOM_ACCESS, OP_NN_ADD, OP_NN_SUB, OP_NN_MUL, OP_NN_INV, OP_DIV_REM, OP_DECOMPRESS, OP_POSEIDON,
+    // gadgets of the in-circuit verifier (plonky2/recursion.py)
+    OP_EXT_ARITH, OP_EXT_MUL, OP_EXT_INV, OP_EXPONENTIATION, OP_COSET_INTERP, OP_POSEIDON_MDS, OP_REDUCING, OP_REDUCING_EXT
 };
+
+// quadratic extension GF(p)[X]/(X^2 - 7)
+struct E2 {
+    u64 a, b;
+};
+static inline E2 e_add(E2 x, E2 y) { return {g_add(x.a, y.a), g_add(x.b, y.b)}; }
+static inline E2 e_sub(E2 x, E2 y) { return {g_sub(x.a, y.a), g_sub(x.b, y.b)}; }
+static inline E2 e_mul(E2 x, E2 y) {
+    return {g_add(g_mul(x.a, y.a), g_mul(7, g_mul(x.b, y.b))), g_add(g_mul(x.a, y.b), g_mul(x.b, y.a))};
+}
+static inline E2 e_scalar(u64 c, E2 x) { return {g_mul(c, x.a), g_mul(c, x.b)}; }
+static inline E2 e_inv(E2 x) {
+    u64 d = g_inv(g_sub(g_mul(x.a, x.a), g_mul(7, g_mul(x.b, x.b))));
+    return {g_mul(x.a, d), g_mul(g_sub(0, x.b), d)};
+}
 
 struct Runner {
     std::vector<u64> val;
@@ -502,6 +519,103 @@ struct Runner {
                     if (zklc_poseidon_gl_gate_rows(in.data(), in.data() + 12, 1, rows)) return fail("poseidon rows", pc);
                     for (int c = 12; c < 135; c++)
                         if (c != 24) out.push_back(rows[c]);
+                    break;
+                }
+                case OP_EXT_ARITH: {   // params c0, c1; in m0, m1, addend
+                    E2 o = e_add(e_scalar((u64)pr[0], e_mul({in[0], in[1]}, {in[2], in[3]})), e_scalar((u64)pr[1], {in[4], in[5]}));
+                    out.push_back(o.a);
+                    out.push_back(o.b);
+                    break;
+                }
+                case OP_EXT_MUL: {
+                    E2 o = e_scalar((u64)pr[0], e_mul({in[0], in[1]}, {in[2], in[3]}));
+                    out.push_back(o.a);
+                    out.push_back(o.b);
+                    break;
+                }
+                case OP_EXT_INV: {
+                    if (!in[0] && !in[1]) return fail("inverse of zero", pc);
+                    E2 o = e_inv({in[0], in[1]});
+                    out.push_back(o.a);
+                    out.push_back(o.b);
+                    break;
+                }
+                case OP_EXPONENTIATION: {   // in: base, n bits (little-endian); out: n intermediates, output
+                    u32 n = ni - 1;
+                    u64 cur = 1;
+                    for (u32 i = 0; i < n; i++) {
+                        u64 prev = i == 0 ? 1 : g_mul(cur, cur);
+                        cur = in[1 + n - 1 - i] ? g_mul(prev, in[0]) : prev;
+                        out.push_back(cur);
+                    }
+                    out.push_back(cur);
+                    break;
+                }
+                case OP_COSET_INTERP: {   // params: subgroup_bits, degree, weights[2^bits]; in: shift, values, point
+                    u32 sb = (u32)pr[0], d = (u32)pr[1], np_ = 1u << sb, nint = (np_ - 2) / (d - 1);
+                    if (ni != 1 + 2 * np_ + 2 || np > 2 + 64 || np != 2 + np_) return fail("coset interpolation: bad arity", pc);
+                    if (!in[0]) return fail("coset interpolation: zero shift", pc);
+                    u64 gen = g_pow(1753635133440165772ULL, 1ULL << (32 - sb)), dom[64], x = 1;
+                    for (u32 i = 0; i < np_; i++) {
+                        dom[i] = x;
+                        x = g_mul(x, gen);
+                    }
+                    E2 pt = {in[1 + 2 * np_], in[2 + 2 * np_]};
+                    E2 shifted = e_scalar(g_inv(in[0]), pt);
+                    out.push_back(shifted.a);
+                    out.push_back(shifted.b);
+                    E2 ev = {0, 0}, prod = {1, 0};
+                    auto partial = [&](u32 s, u32 e) {
+                        for (u32 i = s; i < e; i++) {
+                            E2 term = e_sub(shifted, {dom[i], 0});
+                            E2 wv = e_scalar((u64)pr[2 + i], {in[1 + 2 * i], in[2 + 2 * i]});
+                            ev = e_add(e_mul(ev, term), e_mul(wv, prod));
+                            prod = e_mul(prod, term);
+                        }
+                    };
+                    partial(0, d);
+                    for (u32 i = 0; i < nint; i++) {
+                        out.push_back(ev.a);
+                        out.push_back(ev.b);
+                        out.push_back(prod.a);
+                        out.push_back(prod.b);
+                        u32 s = 1 + (d - 1) * (i + 1), e = s + d - 1 < np_ ? s + d - 1 : np_;
+                        partial(s, e);
+                    }
+                    out.push_back(ev.a);
+                    out.push_back(ev.b);
+                    break;
+                }
+                case OP_POSEIDON_MDS: {   // 12 extension elements in, 12 out
+                    static const u64 circ[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+                    for (int r = 0; r < 12; r++) {
+                        u128 a = 0, b = 0;
+                        for (int i = 0; i < 12; i++) {
+                            int j = (i + r) % 12;
+                            a += (u128)in[2 * j] * circ[i];
+                            b += (u128)in[2 * j + 1] * circ[i];
+                        }
+                        if (r == 0) {
+                            a += (u128)in[0] * 8;
+                            b += (u128)in[1] * 8;
+                        }
+                        out.push_back((u64)(a % GLP));
+                        out.push_back((u64)(b % GLP));
+                    }
+                    break;
+                }
+                case OP_REDUCING:
+                case OP_REDUCING_EXT: {   // params n; in: alpha, old acc, n coefficients; out: the n accumulators (last = output)
+                    u32 n = (u32)pr[0];
+                    bool ext = op == OP_REDUCING_EXT;
+                    if (ni != 4 + (ext ? 2 * n : n)) return fail("reducing: bad arity", pc);
+                    E2 alpha = {in[0], in[1]}, acc = {in[2], in[3]};
+                    for (u32 i = 0; i < n; i++) {
+                        E2 c = ext ? E2{in[4 + 2 * i], in[5 + 2 * i]} : E2{in[4 + i], 0};
+                        acc = e_add(e_mul(acc, alpha), c);
+                        out.push_back(acc.a);
+                        out.push_back(acc.b);
+                    }
                     break;
                 }
                 default: return fail("unknown opcode", pc);

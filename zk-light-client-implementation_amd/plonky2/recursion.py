@@ -340,7 +340,7 @@ class RecursiveCircuitBuilder(CircuitBuilder):
                 s = 1 + (d - 1) * (i + 1)
                 ev, prod = partial(s, min(s + d - 1, np_), ev, prod)
             return res + [(Target(row, start_val), ev[0]), (Target(row, start_val + 1), ev[1])]
-        self.add_generator(ins, gen, OP_COSET_INTERP, (gate.subgroup_bits, gate.degree))
+        self.add_generator(ins, gen, OP_COSET_INTERP, (gate.subgroup_bits, gate.degree) + tuple(gate.weights))
         return (Target(row, start_val), Target(row, start_val + 1))
 
     # ---- PoseidonMdsGate on extension targets
@@ -833,3 +833,51 @@ def recursive_witness(targets, inner_proofs, public_inputs=()):
     for t, v in zip(targets["public_inputs"], public_inputs):
         pw[t] = int(v) % P
     return pw
+
+
+class RecursiveCircuit:
+    """what `recursive_proof` returns first in the reference (CircuitData): `.common`, `.verifier_only`, and the prover"""
+
+    def __init__(self, data, targets, prover):
+        self.data, self.targets, self.prover = data, targets, prover
+        self.common = data.common_data()
+        self.verifier_only = prover.verifier_data()
+
+
+class RecursionProver:
+    """`recursive_proof` (near_bft_finality/src/prove_crypto/recursion.rs:16-97) on one GPU context.
+
+    The reference rebuilds the verifier circuit on every call (recursion.rs:36,94); the circuit depends only on the inner
+    circuits' common data and the number of public inputs, so it is built and uploaded once per distinct shape and reused:
+    a fold (prove_block_data/signatures.rs:97-105) settles on two or three shapes."""
+
+    def __init__(self, ctx, hasher=0, threads=None):
+        self.ctx, self.hasher, self.threads = ctx, hasher, threads
+        self._cache = {}
+
+    def circuit_for(self, commons, num_public_inputs=0):
+        import json
+        key = json.dumps([commons, num_public_inputs], sort_keys=True)
+        rc = self._cache.get(key)
+        if rc is None:
+            data, targets = recursive_circuit(commons, num_public_inputs)
+            rc = self._cache[key] = RecursiveCircuit(data, targets, data.prover(self.ctx, self.hasher))
+        return rc
+
+    def recursive_proof(self, first, second=None, public_inputs=None):
+        """first / second: (common_data, verifier_only_data, proof_with_public_inputs) of the inner proofs (JSON schema of the
+        reference's files; Poseidon-Goldilocks config).  Returns (RecursiveCircuit, proof) -- recursion.rs:95-96.  Raises
+        AssertionError if an inner proof does not verify (no witness exists)."""
+        inners = [first] + ([second] if second is not None else [])
+        pis = [int(x) for x in (public_inputs or [])]
+        rc = self.circuit_for([c for c, _, _ in inners], len(pis))
+        pw = recursive_witness(rc.targets, [(p, v) for _, v, p in inners], pis)
+        if rc.data._program is None:
+            rc.data.witness_program(pw)         # first proof of this shape: compile the generators (and check the witness)
+        wires, wpis = rc.data.generate_witness_native([pw], threads=self.threads)
+        return rc, rc.prover.prove(wires[0], [int(x) for x in wpis[0]])
+
+    def close(self):
+        for rc in self._cache.values():
+            rc.prover.close()
+        self._cache = {}

@@ -84,3 +84,71 @@ def verify_approvals(ctx, msg, approvals, validators, strict=True):
             v = validators[p]
             valid_stake += int.from_bytes(bytes(v[len(v) - STAKE_BYTES:]), "little")
     return bytes(valid_keys), valid_pos, valid_stake, total_stake
+
+
+class ApprovalProver:
+    """`prove_approvals` (signatures.rs:43-141) on one GPU: batched native pre-check, one proof of the reference's Ed25519
+    circuit per present approval (`ed25519_proof_reuse_circuit`, prove_crypto/ed25519.rs:44-64: circuits cached per message
+    length), the left fold `agg = recursive_proof(agg, sig_i)` (:97-105) and the closing `recursive_proof(agg, None,
+    sha256(valid_keys))` (:125-139).  Everything after the pre-check is plonky2 proving on the GPU
+    (zklc_amd.plonky2.Prover); witnesses come from the native interpreter (csrc/plonky2_witness.cpp)."""
+
+    def __init__(self, ctx, witness_threads=None):
+        from .plonky2 import HASH_GL
+        from .plonky2.recursion import RecursionProver
+        self.ctx = ctx
+        self.threads = witness_threads
+        self._ed = {}                       # message length in bits -> (CircuitData, targets, Prover, verifier_only)
+        self.recursion = RecursionProver(ctx, HASH_GL, threads=witness_threads)
+
+    def ed25519_circuit(self, msg_len_bytes, example=None):
+        """get_ed25519_circuit_targets (ed25519.rs:18-42): build once per message length"""
+        from .plonky2 import CircuitBuilder, HASH_GL, wide_ecc_config
+        from .plonky2 import ed25519_circuit as E
+        ent = self._ed.get(msg_len_bytes)
+        if ent is None:
+            b = CircuitBuilder(wide_ecc_config())
+            targets = E.ed25519_circuit(b, 8 * msg_len_bytes)
+            data = b.build()
+            prover = data.prover(self.ctx, HASH_GL)
+            ent = self._ed[msg_len_bytes] = (data, targets, prover, prover.verifier_data())
+        if example is not None and ent[0]._program is None:
+            ent[0].witness_program(example)
+        return ent
+
+    def ed25519_proofs(self, msg, sigs, pks):
+        """one proof per (signature, public key): (common, verifier_only, proof) triples"""
+        from .plonky2 import ed25519_circuit as E
+        data, targets, prover, vd = self.ed25519_circuit(len(msg))
+        fills = [E.fill_ecdsa_targets(targets, msg, bytes(s), bytes(p)) for s, p in zip(sigs, pks)]
+        if fills:
+            self.ed25519_circuit(len(msg), example=fills[0])
+        common = data.common_data()
+        out = []
+        chunk = max(1, self.threads or 4)
+        for c0 in range(0, len(fills), chunk):
+            wires, pis = data.generate_witness_native(fills[c0:c0 + chunk], threads=self.threads)
+            for k in range(len(wires)):
+                out.append((common, vd, prover.prove(wires[k], [int(x) for x in pis[k]])))
+        return out
+
+    def prove_approvals(self, msg, approvals, validators):
+        """-> ((RecursiveCircuit, proof), valid_keys); raises InvalidSignature like the reference's panic (:119-121)"""
+        import hashlib
+        valid_keys, valid_pos, _, _ = verify_approvals(self.ctx, msg, approvals, validators, strict=True)
+        if not valid_pos:
+            raise ValueError("no approvals present")         # the reference indexes agg_data_proof[0] (:131) and panics
+        _, pks, sigs = slice_approvals(approvals, validators)
+        proofs = self.ed25519_proofs(msg, [s.tobytes() for s in sigs], [p.tobytes() for p in pks])
+        agg = proofs[0]
+        for nxt in proofs[1:]:
+            rc, proof = self.recursion.recursive_proof(agg, nxt)
+            agg = (rc.common, rc.verifier_only, proof)
+        rc, proof = self.recursion.recursive_proof(agg, None, list(hashlib.sha256(valid_keys).digest()))
+        return (rc, proof), valid_keys
+
+    def close(self):
+        for _, _, prover, _ in self._ed.values():
+            prover.close()
+        self._ed = {}
+        self.recursion.close()
