@@ -325,44 +325,22 @@ def run_bn254_extras(ctx, dev, reduce_max, barrier, world):
 
 
 def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
-    """plonky2 proofs of synthetic circuits with the reference's shapes (zklc_amd/plonky2/synthetic.py)."""
+    """plonky2 proofs of the reference's circuits: the per-signature Ed25519 circuit (zklc_amd/plonky2/ed25519_circuit.py), the
+    recursion circuits of the fold and the BN128 wrap (zklc_amd/plonky2/recursion.py), then one Block_i signature sub-DAG."""
+    import hashlib
+    import queue
+    import threading
     import torch
-    from zklc_amd.plonky2 import synthetic as SY, standard_recursion_config, wide_ecc_config, HASH_GL, HASH_BN128
-    shapes = [("ed25519_circuit_2p18x234", 18, wide_ecc_config(), None, HASH_GL, 584),
-              ("recursion_2p12x135", 12, standard_recursion_config(), SY.recursion_shape_mix, HASH_GL, 16),
-              ("wrap_bn128_2p12x135", 12, standard_recursion_config(), SY.recursion_shape_mix, HASH_BN128, 16)]
-    out, provers, circuits = {}, {}, {}
-    ed_targets = None
-    for name, bits, cfg, mixf, hasher, npi in shapes:
-        host_s = None
-        if mixf is None:
-            # the reference's per-signature circuit itself (crypto/plonky2_ed25519/src/gadgets/eddsa.rs:34-85 restated in
-            # zklc_amd/plonky2/ed25519_circuit.py) with the witness of a real NEAR approval signature (fixture C1, entry 0)
-            from zklc_amd.plonky2 import CircuitBuilder, ed25519_circuit as E
-            t0 = time.perf_counter()
-            j = json.load(open(os.path.join(ROOT, "tests", "golden", "ed25519_near_c1_small.json")))
-            msg, e0 = bytes.fromhex(j["msg"]), j["entries"][0]
-            bld = CircuitBuilder(cfg)
-            targets = E.ed25519_circuit(bld, 8 * len(msg))
-            ed_targets = targets
-            data = bld.build()
-            t1 = time.perf_counter()
-            ents = j["entries"]
-            fills = [E.fill_ecdsa_targets(targets, msg, bytes.fromhex(x["approval"])[2:], bytes.fromhex(x["validator_tail"])[1:33])
-                     for x in ents]
-            data.witness_program(fills[0])          # one run of the Python generators fixes the interpreter program
-            t2 = time.perf_counter()
-            wn, pn = data.generate_witness_native(fills)       # csrc/plonky2_witness.cpp, one host thread per signature
-            t3 = time.perf_counter()
-            wires, pis = wn[0], [int(x) for x in pn[0]]
-            host_s = {"circuit_build_s": t1 - t0, "witness_program_python_s": t2 - t1,
-                      "native_witness_s_per_signature": (t3 - t2) / len(fills), "native_witness_threads": len(fills)}
-            assert data.degree_bits == bits
-        else:
-            data, wires, pis = SY.synthetic_circuit(bits, cfg, mixf(cfg), num_public_inputs=npi, seed=1 + rank)
-        prover = data.prover(ctx, hasher)
-        d_w = torch.from_numpy(wires.view(np.int64)).to(dev)
-        fn = lambda prover=prover, d_w=d_w, pis=pis: prover.prove_dev(d_w.data_ptr(), pis, stream=stream.cuda_stream)
+    import zklc_amd
+    from zklc_amd import signatures as SG
+    from zklc_amd.plonky2 import CircuitBuilder, HASH_GL, HASH_BN128, wide_ecc_config, ed25519_circuit as E
+    from zklc_amd.plonky2.recursion import RecursionProver
+    out = {}
+    ed_name = "ed25519_circuit_2p18x234"
+
+    def time_proof(prover, wires, pis, sp, bits):
+        d_w = torch.from_numpy(np.ascontiguousarray(wires).view(np.int64)).to(dev)
+        fn = lambda: prover.prove_dev(d_w.data_ptr(), pis, stream=sp)
         fn()
         barrier()
         reps = 3 if bits > 14 else 10
@@ -370,20 +348,76 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         for _ in range(reps):
             fn()
         barrier()
-        ms = reduce_max((time.perf_counter() - t0) / reps * 1e3)
-        tm = prover.last_timings()
+        return reduce_max((time.perf_counter() - t0) / reps * 1e3)
+
+    def describe(data, prover, ms, what):
+        cfg = data.config
         # algorithmic bytes of one proof = the four committed LDE matrices written once + read once by the Merkle hashing
         widths = data.num_constants + cfg["num_routed_wires"] + cfg["num_wires"] + 2 * (1 + data.num_partial_products) + 2 * 8
-        out[name] = {"ms_per_proof": ms, "proofs_per_s": world * 1e3 / ms, "proof_bytes": prover.proof_bytes,
-                     "rows": 1 << bits, "wires": cfg["num_wires"], "committed_polys": widths, "gate_types": len(data.gates),
-                     "circuit": ("reference Ed25519 circuit, real NEAR signature witness" if mixf is None
-                                 else "synthetic circuit of the reference's shape and gate types"),
-                     "stages_ms": {k: round(v, 3) for k, v in tm.items()}}
-        if host_s:
-            out[name]["host_python_untimed"] = host_s
-        provers[name] = (fn, prover)
-        circuits[name] = (data, d_w, pis, hasher)
-        prover.close()
+        return {"ms_per_proof": ms, "proofs_per_s": world * 1e3 / ms, "proof_bytes": prover.proof_bytes, "rows": data.n,
+                "rows_used": sum(1 for g, _ in data.builder.rows if g.id() != "NoopGate"), "wires": cfg["num_wires"],
+                "committed_polys": widths, "gate_types": len(data.gates), "circuit": what,
+                "stages_ms": {k: round(v, 3) for k, v in prover.last_timings().items()}}
+
+    # ---- a4-a6: the reference's per-signature circuit (crypto/plonky2_ed25519/src/gadgets/eddsa.rs:34-85) with the witnesses of
+    # the three real NEAR approval signatures of fixture C1
+    t0 = time.perf_counter()
+    j = json.load(open(os.path.join(ROOT, "tests", "golden", "ed25519_near_c1_small.json")))
+    msg = bytes.fromhex(j["msg"])
+    bld = CircuitBuilder(wide_ecc_config())
+    ed_targets = E.ed25519_circuit(bld, 8 * len(msg))
+    ed_data = bld.build()
+    t1 = time.perf_counter()
+    fills = [E.fill_ecdsa_targets(ed_targets, msg, bytes.fromhex(x["approval"])[2:], bytes.fromhex(x["validator_tail"])[1:33])
+             for x in j["entries"]]
+    ed_data.witness_program(fills[0])          # one run of the Python generators fixes the interpreter program
+    t2 = time.perf_counter()
+    wn, pn = ed_data.generate_witness_native(fills)       # csrc/plonky2_witness.cpp, one host thread per signature
+    t3 = time.perf_counter()
+    ed_prover = ed_data.prover(ctx, HASH_GL)
+    ed_common, ed_vd = ed_data.common_data(), ed_prover.verifier_data()
+    ms = time_proof(ed_prover, wn[0], [int(x) for x in pn[0]], stream.cuda_stream, 18)
+    out[ed_name] = describe(ed_data, ed_prover, ms, "reference Ed25519 circuit, real NEAR signature witness")
+    out[ed_name]["host_python_untimed"] = {"circuit_build_s": t1 - t0, "witness_program_python_s": t2 - t1,
+                                           "native_witness_s_per_signature": (t3 - t2) / len(fills), "native_witness_threads": len(fills)}
+    c1_proofs = [ed_prover.prove_bytes(wn[k], [int(x) for x in pn[k]]) for k in range(len(fills))]
+    del wn
+
+    # ---- a7: `recursive_proof` (prove_crypto/recursion.rs:16-97).  The fold of signatures.rs:97-105 uses two circuit shapes --
+    # R(ed, ed) for the first step, R(R, ed) for every later one (its common data is a fixed point) -- the closing proof carries
+    # sha256(valid_keys) as 32 public inputs (:125-139) and the last recursion runs with Poseidon-BN128 Merkle caps
+    # (bin/prove_block.rs:279-287).  All of them live on the fold thread's own context (= HIP stream).
+    nthreads = max(2, args.prove_streams)
+    fold_ctx = zklc_amd.Context(torch.cuda.current_device(), high_priority=True)
+    rp, rpw = RecursionProver(fold_ctx, HASH_GL), RecursionProver(fold_ctx, HASH_BN128)
+    ed3 = [(ed_common, ed_vd, p_) for p_ in c1_proofs]
+    shapes_t = {}
+
+    def build_step(name, prover_, *a, **kw):
+        t_ = time.perf_counter()
+        rc, proof = prover_.recursive_proof(*a, raw=True, **kw)
+        shapes_t[name] = (time.perf_counter() - t_, rc)
+        return (rc.common, rc.verifier_only, proof)
+    r1 = build_step("fold_first_R(ed,ed)", rp, ed3[0], ed3[1])
+    r2 = build_step("fold_R(R,ed)", rp, r1, ed3[2])
+    assert r2[0] == r1[0], "the fold's common data must be a fixed point"
+    pis32 = list(hashlib.sha256(b"bench").digest())
+    rf = build_step("closing_R(R)+32PI", rp, r2, None, pis32)
+    rw = build_step("wrap_bn128_R(closing)", rpw, rf)
+    fold_steps = {"fold_first_R(ed,ed)": (rp, (ed3[0], ed3[1]), {}), "fold_R(R,ed)": (rp, (r1, ed3[2]), {}),
+                  "closing_R(R)+32PI": (rp, (r2, None, pis32), {}), "wrap_bn128_R(closing)": (rpw, (rf,), {})}
+    for name, (prover_, a, kw) in fold_steps.items():
+        build_s, rc = shapes_t[name]
+        prover_.recursive_proof(*a, raw=True, **kw)          # second run: circuit resident, program compiled
+        host = dict(prover_.last_host_ms)
+        wires = rc.wire_buffer()[0].copy()
+        pis_ = pis32 if "32PI" in name else []
+        ms = time_proof(rc.prover, wires, pis_, fold_ctx.stream_ptr(), rc.data.degree_bits)
+        key = "recursion_%s_2p%dx135" % (name, rc.data.degree_bits)
+        out[key] = describe(rc.data, rc.prover, ms, "in-circuit verifier (recursive_proof) over real inner proofs")
+        out[key]["host_ms_per_call"] = {k: round(v, 3) for k, v in host.items()}
+        out[key]["host_python_untimed"] = {"first_call_s_circuit_build_upload_program": build_s}
+
     # ---- one Block_i signature sub-DAG, end to end, on the reference's own fixture (BASELINE configs[1]/[2]):
     # data/validators_ordered.json (100 validators) + data/next_block_header.json: 66 present approvals of one 41-byte message.
     #   a3  batched Ed25519 pre-verification of the present approvals on the GPU (signatures.rs:79)
@@ -391,44 +425,30 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     #       in pinned memory, overlapped with proving
     #   a6  one proof of the reference Ed25519 circuit per approval; `--prove-streams` - 1 host threads, each with its own zklc
     #       context (= HIP stream) and resident circuit, keep that many proofs in flight
-    #   a7  the serial fold: one recursion-shape proof per approval as soon as its signature proof exists, then the BN128 wrap
-    #       (synthetic circuits of the golden common_data shape: the recursive verifier circuit is not restated yet)
-    import queue
-    import threading
-    import zklc_amd
-    from zklc_amd.plonky2 import ed25519_circuit as E
-    ed_name = "ed25519_circuit_2p18x234"
-    ed_data = circuits[ed_name][0]
+    #   a7  the left fold agg = recursive_proof(agg, sig_i) as soon as signature proof i exists, the closing proof with
+    #       sha256(valid_keys), then the BN128 wrap -- one host thread + stream
     c2 = json.load(open(os.path.join(ROOT, "tests", "golden", "ed25519_near_c2_100.json")))
     c2_msg = bytes.fromhex(c2["msg"])
-    present = [(bytes.fromhex(x["approval"])[2:], bytes.fromhex(x["validator_tail"])[1:33]) for x in c2["entries"]
-               if len(bytes.fromhex(x["approval"])) == 66]
+    approvals = [bytes.fromhex(e["approval"]) for e in c2["entries"]]
+    validators = [len(e["account_id"]).to_bytes(4, "little") + e["account_id"].encode() + bytes.fromhex(e["validator_tail"])
+                  for e in c2["entries"]]
+    _, pks_, sigs_ = SG.slice_approvals(approvals, validators)
+    present = [(s_.tobytes(), p_.tobytes()) for s_, p_ in zip(sigs_, pks_)]
     n_sig = len(present)
     fills = [E.fill_ecdsa_targets(ed_targets, c2_msg, sg, pk_) for sg, pk_ in present]
-    nthreads = max(2, args.prove_streams)
-    workers = []
-    for t in range(nthreads):
-        wctx = ctx if t == 0 else zklc_amd.Context(torch.cuda.current_device())
-        fns = {}
-        if t < nthreads - 1:
-            fns[ed_name] = ed_data.prover(wctx, HASH_GL)
-        else:
-            for name in ("recursion_2p12x135", "wrap_bn128_2p12x135"):
-                data, d_w, pis, hasher = circuits[name]
-                pr = data.prover(wctx, hasher)
-                fns[name] = (lambda pr=pr, d_w=d_w, pis=pis, sp=wctx.stream_ptr(): pr.prove_dev(d_w.data_ptr(), pis, stream=sp), pr)
-                fns[name][0]()
-        workers.append((wctx, fns))
+    workers = [(ctx, ed_prover)] + [(c_, ed_data.prover(c_, HASH_GL)) for c_ in
+                                    (zklc_amd.Context(torch.cuda.current_device()) for _ in range(nthreads - 2))]
     wchunk = max(1, min(12, host_cores() // max(1, world) - nthreads))   # host threads of this rank's witness producer
     nbuf = 2
     nw_, n_rows = ed_data.config["num_wires"], ed_data.n
     pinned = [torch.zeros((wchunk, nw_, n_rows), dtype=torch.int64).pin_memory() for _ in range(nbuf)]
     views = [p_.numpy().view(np.uint64) for p_ in pinned]
-    for w in workers[:-1]:       # warm every Ed25519 prover once (also pages the pinned buffers in)
+    for _, pr in workers:       # warm every Ed25519 prover once (also pages the pinned buffers in)
         data_w, pis_w = ed_data.generate_witness_native(fills[:1], out=views[0][:1])
-        w[1][ed_name].prove_host_ptr(views[0][0].ctypes.data, [int(x) for x in pis_w[0]])
+        pr.prove_host_ptr(views[0][0].ctypes.data, [int(x) for x in pis_w[0]])
     barrier()
     ed_done = [threading.Event() for _ in range(n_sig)]
+    ed_proofs = [None] * n_sig
     free_slots, ready = queue.Queue(), queue.Queue()
     for sl in range(nbuf):
         free_slots.put(sl)
@@ -436,6 +456,8 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     lock = threading.Lock()
     errors = []
     tw = [0.0]
+    fold_host = {"inputs": 0.0, "witness": 0.0, "prove": 0.0}
+    result = {}
 
     def fail(e):
         errors.append(e)
@@ -461,14 +483,14 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         except Exception as e:  # pragma: no cover
             fail(e)
 
-    def ed_worker(fns):
+    def ed_worker(pr):
         try:
             while True:
                 item = ready.get()
                 if item is None:
                     return
                 i, sl, k, pis_ = item
-                fns[ed_name].prove_host_ptr(views[sl][k].ctypes.data, pis_)
+                ed_proofs[i] = pr.prove_host_ptr(views[sl][k].ctypes.data, pis_)
                 ed_done[i].set()
                 with lock:
                     slot_left[sl] -= 1
@@ -477,26 +499,34 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         except Exception as e:  # pragma: no cover
             fail(e)
 
-    def fold_worker(fns):
+    def fold_worker(valid_keys):
         try:
+            agg = None
             for i in range(n_sig):
                 ed_done[i].wait()
                 if errors:
                     return
-                fns["recursion_2p12x135"][0]()
-            fns["wrap_bn128_2p12x135"][0]()
+                nxt = (ed_common, ed_vd, ed_proofs[i])
+                if agg is None:
+                    agg = nxt
+                    continue
+                rc, proof = rp.recursive_proof(agg, nxt, raw=True)
+                for k in fold_host:
+                    fold_host[k] += rp.last_host_ms[k]
+                agg = (rc.common, rc.verifier_only, proof)
+            rc, proof = rp.recursive_proof(agg, None, list(hashlib.sha256(valid_keys).digest()), raw=True)
+            result["closing"] = (rc, proof)
+            result["wrap"] = rpw.recursive_proof((rc.common, rc.verifier_only, proof), raw=True)
         except Exception as e:  # pragma: no cover
             fail(e)
 
-    pk_arr = np.frombuffer(b"".join(p_ for _, p_ in present), np.uint8)
-    sg_arr = np.frombuffer(b"".join(s_ for s_, _ in present), np.uint8)
     t0 = time.perf_counter()
-    ok = ctx.ed25519_verify_batch(pk_arr, sg_arr, c2_msg)                       # a3: the native pre-check of signatures.rs:79
-    assert int(ok.sum()) == n_sig, "fixture approvals must verify"
+    valid_keys, valid_pos, _, _ = SG.verify_approvals(ctx, c2_msg, approvals, validators)   # a3: the pre-check of signatures.rs:79
+    assert len(valid_pos) == n_sig, "fixture approvals must verify"
     t_verify = time.perf_counter() - t0
     threads = [threading.Thread(target=witness_producer)]
-    threads += [threading.Thread(target=ed_worker, args=(w[1],)) for w in workers[:-1]]
-    threads.append(threading.Thread(target=fold_worker, args=(workers[-1][1],)))
+    threads += [threading.Thread(target=ed_worker, args=(pr,)) for _, pr in workers]
+    threads.append(threading.Thread(target=fold_worker, args=(valid_keys,)))
     for th in threads:
         th.start()
     for th in threads:
@@ -505,24 +535,30 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     block_s = reduce_max(time.perf_counter() - t0)
     if errors:
         raise errors[0]
+    from zklc_amd.plonky2 import serialization as S
+    closing = S.proof_from_bytes(result["closing"][1], result["closing"][0].common, HASH_GL)
+    assert closing["public_inputs"] == list(hashlib.sha256(valid_keys).digest())
     out["block_i"] = {"metric": "Block_i signature sub-DAG proofs/s, end to end from the approval bytes (reference fixture: 100 validators, "
                                 "%d present approvals): GPU pre-verification, native witness generation, %d proofs of the reference "
-                                "Ed25519 circuit, serial fold of %d recursion-shape proofs, 1 BN128 wrap; every rank proves its own block"
-                                % (n_sig, n_sig, n_sig),
+                                "Ed25519 circuit, the left fold of %d recursive_proof calls, the closing proof with sha256(valid_keys) "
+                                "and the BN128 wrap; every rank proves its own block" % (n_sig, n_sig, n_sig - 1),
                       "value": world / block_s, "unit": "proofs/s", "seconds_per_block": block_s, "streams": nthreads,
                       "approvals": n_sig, "witness_chunk": wchunk, "witness_cpu_seconds_total": tw[0], "preverify_ms": t_verify * 1e3,
+                      "fold_thread_seconds": {k: round(v / 1e3, 3) for k, v in fold_host.items()},
+                      "wrap_proof_bytes": len(result["wrap"][1]),
                       "cpu_baseline": None,
-                      "note": "signature proofs: the reference circuit (restated) on the fixture's real signatures, witness generation "
-                              "inside the timed region (host threads, overlapped); recursion and wrap proofs: synthetic circuits of "
-                              "the reference's shape and gate types (the recursive verifier circuit is not restated yet); the "
-                              "reference CPU prover cannot be built here (no Rust toolchain) and publishes no time for this step"}
-    for wctx, fns in workers:
-        for v in fns.values():
-            (v[1] if isinstance(v, tuple) else v).close()
-        if wctx is not ctx:
-            wctx.close()
-    for _, prover in provers.values():
-        prover.close()
+                      "note": "every proof is a proof of the reference's own circuit (restated): Ed25519 circuit on the fixture's real "
+                              "signatures, in-circuit verifier for the fold; witness generation inside the timed region (host "
+                              "threads, overlapped); circuits are built once before the timed region and reused (the reference "
+                              "rebuilds the recursion circuit on every call); the reference CPU prover cannot be built here (no "
+                              "Rust toolchain) and publishes no time for this step"}
+    for c_, pr in workers:
+        pr.close()
+        if c_ is not ctx:
+            c_.close()
+    rp.close()
+    rpw.close()
+    fold_ctx.close()
     return out
 
 

@@ -34,6 +34,9 @@ typedef struct zklc_ctx zklc_ctx;
 /* One context per process-per-GPU rank.  Owns a stream, staging buffers and
  * the constant tables (Ed25519 base-point table, NTT twiddles, ...). */
 int32_t zklc_init(zklc_ctx **out, int32_t device_id);
+/* same, with the context's stream created at the device's highest stream priority when `high_priority` != 0: for the short,
+ * latency-critical proofs of a dependent chain (the fold of signatures.rs:97-105) sharing the GPU with long throughput work */
+int32_t zklc_init_priority(zklc_ctx **out, int32_t device_id, int32_t high_priority);
 void zklc_destroy(zklc_ctx *ctx);
 const char *zklc_strerror(int32_t code);
 /* last HIP error string seen by this context (for ZKLC_ERR_HIP) */

@@ -134,3 +134,25 @@ def test_two_inner_proofs(hostsim, inner_proof):
     rdata, targets = R.recursive_circuit([common, common])
     w, pis = rdata.generate_witness(R.recursive_witness(targets, [(proof, vd), (proof, vd)]))
     assert pis == [] and not gate_constraint_failures(hostsim, rdata, w, pis)
+
+
+def test_native_witness_and_bytes_fast_path(inner_proof):
+    """the compiled generator program (csrc/plonky2_witness.cpp) reproduces the Python generators' wire matrix, and an inner
+    proof given as `to_bytes` bytes lands on the same program inputs as its JSON form"""
+    from zklc_amd.plonky2 import serialization as S
+    common, proof, vd = inner_proof
+    data, targets = R.recursive_circuit([common], 2)
+    rc = R.RecursiveCircuit(data, targets, None, [common], 0)
+    pw = R.recursive_witness(targets, [(proof, vd)], [5, 6])
+    w, pis = data.generate_witness(pw)
+    raw = S.proof_to_bytes(proof, common, 0)
+    rc.compile(pw, [raw])
+    v_json = rc.input_vector([(vd, proof)], [5, 6])
+    v_raw = rc.input_vector([(vd, raw)], [5, 6])
+    assert np.array_equal(v_json, v_raw)
+    wn, pn = data.generate_witness_native(None, input_values=v_raw[None, :])
+    assert np.array_equal(wn[0], w) and [int(x) for x in pn[0]] == pis
+    bad = bytearray(raw)
+    bad[8 * 100] ^= 1
+    with pytest.raises(AssertionError):
+        data.generate_witness_native(None, input_values=rc.input_vector([(vd, bytes(bad))], [5, 6])[None, :])

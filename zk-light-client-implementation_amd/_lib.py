@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libzklc_mi355.so")
 _u8p = ctypes.c_void_p
 _SIGS = {
     "zklc_init": (ctypes.c_int32, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32]),
+    "zklc_init_priority": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32]),
     "zklc_destroy": (None, [ctypes.c_void_p]),
     "zklc_strerror": (ctypes.c_char_p, [ctypes.c_int32]),
     "zklc_last_hip_error": (ctypes.c_char_p, [ctypes.c_void_p]),

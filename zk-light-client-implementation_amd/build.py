@@ -26,7 +26,7 @@ def _newest(paths):
 
 
 HOST_CXX = os.environ.get("CXX", "g++")
-HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
+HOST_FLAGS = ["-O3", "-funroll-loops", "-std=c++17", "-fPIC", "-pthread", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
 
 
 def _compile(src, obj, log):

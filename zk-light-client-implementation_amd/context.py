@@ -23,10 +23,10 @@ def _host_u8(x, name):
 class Context:
     """One zklc_ctx: a device, a stream, staging buffers and constant tables."""
 
-    def __init__(self, device_id=0):
+    def __init__(self, device_id=0, high_priority=False):
         self._lib = _lib.load()
         h = ctypes.c_void_p()
-        rc = self._lib.zklc_init(ctypes.byref(h), int(device_id))
+        rc = self._lib.zklc_init_priority(ctypes.byref(h), int(device_id), 1 if high_priority else 0)
         if rc != 0:
             raise _lib.ZklcError(rc)
         self._h = h

@@ -34,7 +34,9 @@ extern "C" const char *zklc_strerror(int32_t code) {
 
 extern "C" const char *zklc_last_hip_error(zklc_ctx *ctx) { return ctx ? ctx->last_err.c_str() : ""; }
 
-extern "C" int32_t zklc_init(zklc_ctx **out, int32_t device_id) {
+extern "C" int32_t zklc_init(zklc_ctx **out, int32_t device_id) { return zklc_init_priority(out, device_id, 0); }
+
+extern "C" int32_t zklc_init_priority(zklc_ctx **out, int32_t device_id, int32_t high_priority) {
     if (!out || device_id < 0) return ZKLC_ERR_INVALID_ARG;
     *out = nullptr;
     int count = 0;
@@ -49,7 +51,10 @@ extern "C" int32_t zklc_init(zklc_ctx **out, int32_t device_id) {
         return code;
     };
     if (hipSetDevice(device_id) != hipSuccess) return fail(ZKLC_ERR_NO_DEVICE);
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return fail(ZKLC_ERR_HIP);
+    int prio_low = 0, prio_high = 0;   // numerically lower = higher priority
+    if (high_priority && hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_high = 0;
+    if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, high_priority ? prio_high : 0) != hipSuccess)
+        return fail(ZKLC_ERR_HIP);
     if ((rc = zklc_ed25519_init(ctx))) return fail(rc);
     *out = ctx;
     return ZKLC_OK;

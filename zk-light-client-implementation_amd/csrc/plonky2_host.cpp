@@ -62,6 +62,42 @@ extern "C" void zklc_poseidon_gl_constants(uint64_t *rc360, uint64_t *fp_first12
     }
 }
 
+// Host-side arithmetic for the witness rows: 64x64->128 products in one instruction, sums of products reduced once.
+typedef unsigned __int128 u128h;
+static inline u64 h_red(u128h x) { return gl_reduce128((u64)x, (u64)(x >> 64)); }
+static inline u64 h_mul(u64 a, u64 b) { return h_red((u128h)a * b); }
+static inline u64 h_sbox(u64 x) {
+    u64 x2 = h_mul(x, x), x3 = h_mul(x2, x), x4 = h_mul(x2, x2);
+    return h_mul(x3, x4);
+}
+// sum of up to 12 products of canonical values: < 12 * 2^128, kept as a 128-bit sum plus a carry count (2^128 = -2^32 mod p... folded
+// through 2^128 mod p = p - 2^32 = 0xFFFFFFFE00000001)
+struct h_acc {
+    u128h s = 0;
+    u64 carries = 0;
+    inline void add(u64 a, u64 b) {
+        u128h t = (u128h)a * b;
+        s += t;
+        carries += s < t;
+    }
+    inline u64 result() const {
+        u64 r = h_red(s);
+        return carries ? gl_add(r, h_mul(carries, 0xFFFFFFFE00000001ULL)) : r;
+    }
+};
+static inline void h_mds(u64 *s) {
+    static const u64 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u64 d[24], o[12];
+    for (int i = 0; i < 12; i++) d[i] = d[i + 12] = s[i];
+    for (int r = 0; r < 12; r++) {
+        u128h a = 0;   // 12 terms < 2^64 * 41 and one < 2^64 * 8: no overflow
+        for (int i = 0; i < 12; i++) a += (u128h)d[i + r] * C[i];
+        if (r == 0) a += (u128h)d[0] * 8;
+        o[r] = h_red(a);
+    }
+    for (int i = 0; i < 12; i++) s[i] = o[i];
+}
+
 extern "C" int32_t zklc_poseidon_gl_gate_rows(const uint64_t *inputs, const uint64_t *swap, uint32_t n, uint64_t *rows) {
     if (!inputs || !rows) return -1;
     for (uint32_t k = 0; k < n; k++) {
@@ -83,31 +119,34 @@ extern "C" int32_t zklc_poseidon_gl_gate_rows(const uint64_t *inputs, const uint
             for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PGL_RC[12 * r + i]);
             if (r)
                 for (int i = 0; i < 12; i++) w[29 + 12 * (r - 1) + i] = s[i];
-            for (int i = 0; i < 12; i++) s[i] = pgl_sbox(s[i]);
-            pgl_mds(s);
+            for (int i = 0; i < 12; i++) s[i] = h_sbox(s[i]);
+            h_mds(s);
         }
         for (int i = 0; i < 12; i++) s[i] = gl_add(s[i], PGL_FP_FIRST[i]);
         u64 t[12];
         t[0] = s[0];
-        for (int d = 1; d < 12; d++) t[d] = 0;
-        for (int r = 1; r < 12; r++)
-            for (int d = 1; d < 12; d++) t[d] = gl_add(t[d], gl_mul(s[r], PGL_FP_INIT[(r - 1) * 11 + d - 1]));
+        for (int d = 1; d < 12; d++) {
+            h_acc a;
+            for (int r = 1; r < 12; r++) a.add(s[r], PGL_FP_INIT[(r - 1) * 11 + d - 1]);
+            t[d] = a.result();
+        }
         for (int i = 0; i < 12; i++) s[i] = t[i];
         for (int r = 0; r < 22; r++) {
             w[65 + r] = s[0];
-            u64 s0 = gl_add(pgl_sbox(s[0]), PGL_FP_RC[r]);
-            u64 d = gl_mul(s0, 25);
-            for (int j = 1; j < 12; j++) d = gl_add(d, gl_mul(s[j], PGL_FP_WHATS[r * 11 + j - 1]));
-            for (int j = 1; j < 12; j++) s[j] = gl_add(s[j], gl_mul(s0, PGL_FP_VS[r * 11 + j - 1]));
-            s[0] = d;
+            u64 s0 = gl_add(h_sbox(s[0]), PGL_FP_RC[r]);
+            h_acc a;
+            a.add(s0, 25);
+            for (int j = 1; j < 12; j++) a.add(s[j], PGL_FP_WHATS[r * 11 + j - 1]);
+            for (int j = 1; j < 12; j++) s[j] = h_red((u128h)s0 * PGL_FP_VS[r * 11 + j - 1] + s[j]);
+            s[0] = a.result();
         }
         for (int r = 0; r < 4; r++) {
             for (int i = 0; i < 12; i++) {
                 s[i] = gl_add(s[i], PGL_RC[12 * (26 + r) + i]);
                 w[87 + 12 * r + i] = s[i];
-                s[i] = pgl_sbox(s[i]);
+                s[i] = h_sbox(s[i]);
             }
-            pgl_mds(s);
+            h_mds(s);
         }
         for (int i = 0; i < 12; i++) w[12 + i] = s[i];
     }

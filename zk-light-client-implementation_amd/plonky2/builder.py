@@ -641,8 +641,9 @@ class CircuitData:
         self._program["n_slots"] = len(slot_of) + 1
         return self._program
 
-    def generate_witness_native(self, inputs_list, out=None, threads=None):
-        """inputs_list: partial witnesses ({Target: value} with the same keys as the example given to witness_program).
+    def generate_witness_native(self, inputs_list, out=None, threads=None, input_values=None):
+        """inputs_list: partial witnesses ({Target: value} with the same keys as the example given to witness_program), or
+        `input_values`: the same as a uint64 array [k, n_inputs] in the order of witness_program()["input_targets"].
         Returns (wires uint64 [k, num_wires, n], public inputs uint64 [k, n_pi]); raises if a witness does not exist.
         `out` may be a zero-initialised buffer of that shape reused across calls (only the circuit's wire cells are written)."""
         import ctypes
@@ -650,8 +651,12 @@ class CircuitData:
         from .. import _lib
         pr = self._program
         assert pr is not None, "call witness_program(example_inputs) first"
-        k = len(inputs_list)
-        vals = np.array([[int(w[t]) for t in pr["input_targets"]] for w in inputs_list], dtype=np.uint64).reshape(k, -1)
+        if input_values is not None:
+            vals = np.ascontiguousarray(input_values, dtype=np.uint64).reshape(-1, len(pr["input_targets"]))
+            k = vals.shape[0]
+        else:
+            k = len(inputs_list)
+            vals = np.array([[int(w[t]) for t in pr["input_targets"]] for w in inputs_list], dtype=np.uint64).reshape(k, -1)
         nw = self.config["num_wires"]
         wires = out if out is not None else np.zeros((k, nw, self.n), dtype=np.uint64)
         assert wires.shape == (k, nw, self.n) and wires.dtype == np.uint64 and wires.flags["C_CONTIGUOUS"]

@@ -838,10 +838,65 @@ def recursive_witness(targets, inner_proofs, public_inputs=()):
 class RecursiveCircuit:
     """what `recursive_proof` returns first in the reference (CircuitData): `.common`, `.verifier_only`, and the prover"""
 
-    def __init__(self, data, targets, prover):
+    def __init__(self, data, targets, prover, inner_commons, inner_hasher):
         self.data, self.targets, self.prover = data, targets, prover
         self.common = data.common_data()
-        self.verifier_only = prover.verifier_data()
+        self.verifier_only = prover.verifier_data() if prover is not None else None
+        self.inner_commons, self.inner_hasher = inner_commons, inner_hasher
+        self._pos = None
+        self._maps = None
+
+    def compile(self, example_pw, example_raws):
+        """first proof of this shape: compile the generators into the native program (this also checks the witness) and
+        index the program's inputs, so that later inner proofs go from their bytes to the input vector by one gather.
+        example_raws: the inner proofs of the example as bytes (layout templates)"""
+        import numpy as np
+        from . import serialization as S
+        self.data.witness_program(example_pw)
+        self._pos = {t: i for i, t in enumerate(self.data._program["input_targets"])}
+        self._maps = []
+        for pt, common, raw in zip(self.targets["proofs"], self.inner_commons, example_raws):
+            tmp = {}
+            set_proof_with_pis_target(tmp, pt, S.proof_offsets(raw, common, self.inner_hasher))
+            pos = np.array([self._pos[t] for t in tmp], dtype=np.int64)
+            off = np.array(list(tmp.values()), dtype=np.int64)
+            self._maps.append((pos, off[:, None] + np.arange(8, dtype=np.int64)[None, :], len(raw)))
+
+    def wire_buffer(self):
+        """the host wire matrix of this circuit, allocated once (pinned when a GPU is present: the prover uploads it with one
+        DMA); the witness interpreter rewrites the same cells on every run"""
+        if getattr(self, "_wbuf", None) is None:
+            import numpy as np
+            shape = (1, self.data.config["num_wires"], self.data.n)
+            try:
+                import torch
+                self._wpin = torch.zeros(shape, dtype=torch.int64)
+                if torch.cuda.is_available():
+                    self._wpin = self._wpin.pin_memory()
+                self._wbuf = self._wpin.numpy().view(np.uint64)
+            except ImportError:
+                self._wbuf = np.zeros(shape, dtype=np.uint64)
+        return self._wbuf
+
+    def input_vector(self, inner_proofs, public_inputs):
+        """inner_proofs: [(verifier_only_json, proof bytes or proof json)]"""
+        import numpy as np
+        vals = np.zeros(len(self._pos), dtype=np.uint64)
+        tmp = {}
+        for k, (vd, proof) in enumerate(inner_proofs):
+            if isinstance(proof, (bytes, bytearray, memoryview)):
+                pos, gather, size = self._maps[k]
+                if len(proof) != size:
+                    raise ValueError("inner proof %d: %d bytes, expected %d" % (k, len(proof), size))
+                vals[pos] = np.ascontiguousarray(np.frombuffer(proof, dtype=np.uint8)[gather]).view("<u8")[:, 0]
+            else:
+                set_proof_with_pis_target(tmp, self.targets["proofs"][k], proof)
+            set_verifier_data_target(tmp, self.targets["verifier_data"][k], vd)
+        for t, v in zip(self.targets["public_inputs"], public_inputs):
+            tmp[t] = int(v) % P
+        for t, v in tmp.items():
+            vals[self._pos[t]] = v
+        return vals
 
 
 class RecursionProver:
@@ -849,10 +904,11 @@ class RecursionProver:
 
     The reference rebuilds the verifier circuit on every call (recursion.rs:36,94); the circuit depends only on the inner
     circuits' common data and the number of public inputs, so it is built and uploaded once per distinct shape and reused:
-    a fold (prove_block_data/signatures.rs:97-105) settles on two or three shapes."""
+    a fold (prove_block_data/signatures.rs:97-105) settles on two shapes plus the closing one."""
 
-    def __init__(self, ctx, hasher=0, threads=None):
-        self.ctx, self.hasher, self.threads = ctx, hasher, threads
+    def __init__(self, ctx, hasher=0, threads=None, inner_hasher=0):
+        self.ctx, self.hasher, self.threads, self.inner_hasher = ctx, hasher, threads, inner_hasher
+        assert inner_hasher == 0, "the in-circuit verifier handles Poseidon-Goldilocks inner proofs"
         self._cache = {}
 
     def circuit_for(self, commons, num_public_inputs=0):
@@ -861,21 +917,33 @@ class RecursionProver:
         rc = self._cache.get(key)
         if rc is None:
             data, targets = recursive_circuit(commons, num_public_inputs)
-            rc = self._cache[key] = RecursiveCircuit(data, targets, data.prover(self.ctx, self.hasher))
+            rc = self._cache[key] = RecursiveCircuit(data, targets, data.prover(self.ctx, self.hasher), list(commons), self.inner_hasher)
         return rc
 
-    def recursive_proof(self, first, second=None, public_inputs=None):
-        """first / second: (common_data, verifier_only_data, proof_with_public_inputs) of the inner proofs (JSON schema of the
-        reference's files; Poseidon-Goldilocks config).  Returns (RecursiveCircuit, proof) -- recursion.rs:95-96.  Raises
-        AssertionError if an inner proof does not verify (no witness exists)."""
+    def recursive_proof(self, first, second=None, public_inputs=None, raw=False):
+        """first / second: (common_data, verifier_only_data, proof) of the inner proofs -- the proof either in the JSON schema
+        of the reference's proof_with_public_inputs.json or as `ProofWithPublicInputs::to_bytes` bytes (signatures.rs:225-230);
+        Poseidon-Goldilocks config.  Returns (RecursiveCircuit, proof) -- recursion.rs:95-96 -- with the proof as JSON, or as
+        bytes if `raw`.  Raises AssertionError if an inner proof does not verify (no witness exists)."""
+        from . import serialization as S
         inners = [first] + ([second] if second is not None else [])
         pis = [int(x) for x in (public_inputs or [])]
         rc = self.circuit_for([c for c, _, _ in inners], len(pis))
-        pw = recursive_witness(rc.targets, [(p, v) for _, v, p in inners], pis)
-        if rc.data._program is None:
-            rc.data.witness_program(pw)         # first proof of this shape: compile the generators (and check the witness)
-        wires, wpis = rc.data.generate_witness_native([pw], threads=self.threads)
-        return rc, rc.prover.prove(wires[0], [int(x) for x in wpis[0]])
+        if rc._pos is None:
+            is_raw = [isinstance(p, (bytes, bytearray, memoryview)) for _, _, p in inners]
+            as_json = [(S.proof_from_bytes(bytes(p), c, self.inner_hasher) if r else p, v) for (c, v, p), r in zip(inners, is_raw)]
+            raws = [bytes(p) if r else S.proof_to_bytes(p, c, self.inner_hasher) for (c, v, p), r in zip(inners, is_raw)]
+            rc.compile(recursive_witness(rc.targets, as_json, pis), raws)
+        import time
+        t0 = time.perf_counter()
+        vals = rc.input_vector([(v, p) for _, v, p in inners], pis)
+        t1 = time.perf_counter()
+        wires, wpis = rc.data.generate_witness_native(None, out=rc.wire_buffer(), threads=1, input_values=vals[None, :])
+        t2 = time.perf_counter()
+        out = rc.prover.prove_host_ptr(wires.ctypes.data, [int(x) for x in wpis[0]])
+        t3 = time.perf_counter()
+        self.last_host_ms = {"inputs": (t1 - t0) * 1e3, "witness": (t2 - t1) * 1e3, "prove": (t3 - t2) * 1e3}
+        return rc, (out if raw else S.proof_from_bytes(out, rc.common, self.hasher))
 
     def close(self):
         for rc in self._cache.values():

@@ -42,13 +42,25 @@ def shapes(common):
 
 
 class _Reader:
-    def __init__(self, b, hasher):
-        self.b, self.o, self.hasher = memoryview(b), 0, hasher
+    """offsets=True: every field element is reported as its byte offset instead of its value (proof_offsets)"""
+
+    def __init__(self, b, hasher, offsets=False):
+        self.b, self.o, self.hasher, self.offsets = memoryview(b), 0, hasher, offsets
 
     def u64s(self, n):
-        v = struct.unpack_from("<%dQ" % n, self.b, self.o)
+        if self.offsets:
+            v = [self.o + 8 * i for i in range(n)]
+            if self.o + 8 * n > len(self.b):
+                raise ValueError("proof bytes too short")
+        else:
+            v = struct.unpack_from("<%dQ" % n, self.b, self.o)
         self.o += 8 * n
         return list(v)
+
+    def count(self):
+        v = struct.unpack_from("<Q", self.b, self.o)[0]
+        self.o += 8
+        return v
 
     def exts(self, n):
         v = self.u64s(2 * n)
@@ -67,9 +79,16 @@ class _Reader:
         return {"siblings": [self.hash() for _ in range(n)]}
 
 
-def proof_from_bytes(data, common, hasher):
+def proof_offsets(template, common, hasher):
+    """the proof_from_bytes structure of `template` (any proof of the circuit) with byte offsets in place of the field
+    elements: proofs of one circuit all have the same layout, so a consumer can gather its inputs straight from the bytes"""
+    assert hasher == HASH_GL
+    return proof_from_bytes(template, common, hasher, offsets=True)
+
+
+def proof_from_bytes(data, common, hasher, offsets=False):
     sh = shapes(common)
-    r = _Reader(data, hasher)
+    r = _Reader(data, hasher, offsets)
     cap = lambda: [r.hash() for _ in range(sh["cap"])]
     proof = {"wires_cap": cap(), "plonk_zs_partial_products_cap": cap(), "quotient_polys_cap": cap()}
     proof["openings"] = {k: r.exts(n) for k, n in sh["openings"]}
@@ -85,7 +104,7 @@ def proof_from_bytes(data, common, hasher):
     pow_witness = r.u64s(1)[0]
     proof["opening_proof"] = {"commit_phase_merkle_caps": caps, "query_round_proofs": rounds, "final_poly": {"coeffs": final},
                               "pow_witness": pow_witness}
-    npi = r.u64s(1)[0]
+    npi = r.count()
     pis = r.u64s(npi)
     if r.o != len(data):
         raise ValueError("trailing bytes in proof: %d of %d consumed" % (r.o, len(data)))
