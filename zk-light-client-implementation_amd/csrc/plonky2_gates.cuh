@@ -74,12 +74,25 @@ struct p2_vars {
     ZKLC_M gl2 wa(u32 j) const { return gl2_make(w(j), w(j + 1)); }
 };
 
-// prod_{k < base} (x - k)
+// prod_{k < base} (x - k); the result is LOOSE (any u64 congruent to it: what p2_consumer::emit multiplies by alpha^k).
+// The two-bit limbs of the u32 gates dominate the constraint count of the Ed25519 circuit: x (x-1)(x-2)(x-3) = y (y + 2) with
+// y = x (x - 3) takes two multiplications instead of three.
 ZKLC_D u64 p2_range_product(u64 x, u32 base) {
+    if (base == 4) {
+        u64 y = gl_mul_loose(x, gl_sub(x, 3));
+        return gl_mul_loose(y, gl_add_lc(y, 2));
+    }
     u64 acc = x;
-    for (u32 k = 1; k < base; k++) acc = gl_mul(acc, gl_sub(x, k));
+    for (u32 k = 1; k < base; k++) acc = gl_mul_loose(acc, gl_sub(x, k));
     return acc;
 }
+// 4 * a for a loose a: (a << 2) + (a >> 62) * (2^32 - 1), one wrap possible
+ZKLC_D u64 p2_mul4_loose(u64 a) {
+    u64 hi = a >> 62, t = (hi << 32) - hi, r = (a << 2) + t;
+    return r + ((r < t) ? GL_EPS : 0);
+}
+// Horner step of sum_j limb_j 4^j: loose accumulator, canonical limb
+ZKLC_D u64 p2_horner4(u64 acc, u64 limb) { return gl_add_lc(p2_mul4_loose(acc), limb); }
 
 ZKLC_D void p2_eval_constant(const p2_vars &v, u32 n, p2_consumer &out) {
     for (u32 i = 0; i < n; i++) out.emit(gl_sub(v.c(i), v.w(i)));
@@ -116,7 +129,13 @@ ZKLC_D void p2_eval_mul_ext(const p2_vars &v, u32 num_ops, p2_consumer &out) {
 
 ZKLC_D void p2_eval_base_sum(const p2_vars &v, u32 num_limbs, u32 base, p2_consumer &out) {
     u64 acc = 0;
-    for (u32 i = num_limbs; i-- > 0;) acc = gl_add(gl_mul(acc, base), v.w(1 + i));
+    if (base == 2)
+        for (u32 i = num_limbs; i-- > 0;) acc = gl_add(gl_add(acc, acc), v.w(1 + i));
+    else if (base == 4) {
+        for (u32 i = num_limbs; i-- > 0;) acc = p2_horner4(acc, v.w(1 + i));
+        acc = gl_canonical(acc);
+    } else
+        for (u32 i = num_limbs; i-- > 0;) acc = gl_add(gl_mul(acc, base), v.w(1 + i));
     out.emit(gl_sub(acc, v.w(0)));
     for (u32 i = 0; i < num_limbs; i++) out.emit(p2_range_product(v.w(1 + i), base));
 }
@@ -312,12 +331,12 @@ ZKLC_D void p2_eval_u32_arithmetic(const p2_vars &v, u32 num_ops, p2_consumer &o
             u64 l = v.w(6 * num_ops + 32 * i + j);
             out.emit(p2_range_product(l, 4));
             if (j < 16)
-                comb_lo = gl_add(gl_mul(comb_lo, 4), l);
+                comb_lo = p2_horner4(comb_lo, l);
             else
-                comb_hi = gl_add(gl_mul(comb_hi, 4), l);
+                comb_hi = p2_horner4(comb_hi, l);
         }
-        out.emit(gl_sub(comb_lo, lo));
-        out.emit(gl_sub(comb_hi, hi));
+        out.emit(gl_sub(gl_canonical(comb_lo), lo));
+        out.emit(gl_sub(gl_canonical(comb_hi), hi));
     }
 }
 
@@ -334,12 +353,12 @@ ZKLC_D void p2_eval_u32_add_many(const p2_vars &v, u32 num_addends, u32 num_ops,
             u64 l = v.w(per * num_ops + 18 * i + j);
             out.emit(p2_range_product(l, 4));
             if (j < 16)
-                comb_res = gl_add(gl_mul(comb_res, 4), l);
+                comb_res = p2_horner4(comb_res, l);
             else
-                comb_carry = gl_add(gl_mul(comb_carry, 4), l);
+                comb_carry = p2_horner4(comb_carry, l);
         }
-        out.emit(gl_sub(comb_res, res));
-        out.emit(gl_sub(comb_carry, carry));
+        out.emit(gl_sub(gl_canonical(comb_res), res));
+        out.emit(gl_sub(gl_canonical(comb_carry), carry));
     }
 }
 
@@ -353,9 +372,9 @@ ZKLC_D void p2_eval_u32_subtraction(const p2_vars &v, u32 num_ops, p2_consumer &
         for (u32 j = 16; j-- > 0;) {
             u64 l = v.w(5 * num_ops + 16 * i + j);
             out.emit(p2_range_product(l, 4));
-            comb = gl_add(gl_mul(comb, 4), l);
+            comb = p2_horner4(comb, l);
         }
-        out.emit(gl_sub(comb, res));
+        out.emit(gl_sub(gl_canonical(comb), res));
         out.emit(gl_mul(bout, gl_sub(1, bout)));
     }
 }
@@ -364,8 +383,8 @@ ZKLC_D void p2_eval_u32_subtraction(const p2_vars &v, u32 num_ops, p2_consumer &
 ZKLC_D void p2_eval_u32_range_check(const p2_vars &v, u32 n, p2_consumer &out) {
     for (u32 i = 0; i < n; i++) {
         u64 sum = 0;
-        for (u32 j = 16; j-- > 0;) sum = gl_add(gl_mul(sum, 4), v.w(n + 16 * i + j));
-        out.emit(gl_sub(sum, v.w(i)));
+        for (u32 j = 16; j-- > 0;) sum = p2_horner4(sum, v.w(n + 16 * i + j));
+        out.emit(gl_sub(gl_canonical(sum), v.w(i)));
         for (u32 j = 0; j < 16; j++) out.emit(p2_range_product(v.w(n + 16 * i + j), 4));
     }
 }
@@ -375,10 +394,18 @@ ZKLC_D void p2_eval_comparison(const p2_vars &v, u32 num_bits, u32 num_chunks, p
     const u32 chunk_bits = (num_bits + num_chunks - 1) / num_chunks;
     const u32 chunk_size = 1u << chunk_bits;
     u64 c1 = 0, c2 = 0;
-    for (u32 i = num_chunks; i-- > 0;) {
-        c1 = gl_add(gl_mul(c1, chunk_size), v.w(4 + i));
-        c2 = gl_add(gl_mul(c2, chunk_size), v.w(4 + num_chunks + i));
-    }
+    if (chunk_size == 4) {
+        for (u32 i = num_chunks; i-- > 0;) {
+            c1 = p2_horner4(c1, v.w(4 + i));
+            c2 = p2_horner4(c2, v.w(4 + num_chunks + i));
+        }
+        c1 = gl_canonical(c1);
+        c2 = gl_canonical(c2);
+    } else
+        for (u32 i = num_chunks; i-- > 0;) {
+            c1 = gl_add(gl_mul(c1, chunk_size), v.w(4 + i));
+            c2 = gl_add(gl_mul(c2, chunk_size), v.w(4 + num_chunks + i));
+        }
     out.emit(gl_sub(c1, v.w(0)));
     out.emit(gl_sub(c2, v.w(1)));
     u64 msd = 0;
