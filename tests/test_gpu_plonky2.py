@@ -158,16 +158,19 @@ def test_reference_ed25519_circuit_proof_of_a_near_mainnet_signature(zctx, appro
     pk, sig = bytes.fromhex(e["validator_tail"])[1:33], bytes.fromhex(e["approval"])[2:]
     data, targets, prover, vd = approval_prover.ed25519_circuit(len(msg))
     assert data.n == 1 << 18 and data.num_public_inputs == 8 * len(msg) + 256
+    import os
     import time
-    wires, pis = data.generate_witness(E.fill_ecdsa_targets(targets, msg, sig, pk))
-    assert pis == sha512.array_to_bits(msg) + sha512.array_to_bits(pk)
-    # native witness generation (csrc/plonky2_witness.cpp): all three signatures of the fixture, identical to the Python one
+    # native witness generation (csrc/plonky2_witness.cpp): all three signatures of the fixture
     data.witness_program(E.fill_ecdsa_targets(targets, msg, sig, pk))
     sigs = [(bytes.fromhex(x["approval"])[2:], bytes.fromhex(x["validator_tail"])[1:33]) for x in j["entries"]]
     t0 = time.time()
     wn, pn = data.generate_witness_native([E.fill_ecdsa_targets(targets, msg, s_, p_) for s_, p_ in sigs])
     print("native witness generation: %.2f s for %d signatures" % (time.time() - t0, len(sigs)))
-    assert np.array_equal(wn[0], wires) and [int(x) for x in pn[0]] == pis
+    wires, pis = wn[0], [int(x) for x in pn[0]]
+    assert pis == sha512.array_to_bits(msg) + sha512.array_to_bits(pk)
+    if os.environ.get("ZKLC_SLOW_TESTS"):     # ~1 min of host Python: the Python generators give the same matrix cell for cell
+        wp, pp = data.generate_witness(E.fill_ecdsa_targets(targets, msg, sig, pk))
+        assert np.array_equal(wp, wires) and pp == pis
     # a corrupted signature has no witness (the reference's generators / prover fail the same way)
     bad = bytearray(sig)
     bad[40] ^= 1

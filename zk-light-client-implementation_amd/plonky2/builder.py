@@ -46,14 +46,42 @@ def root_of_unity(log_n):
     return pow(POWER_OF_TWO_GENERATOR, 1 << (32 - log_n), P)
 
 
+def gl_mul_np(a, b):
+    """elementwise a * b mod p on uint64 arrays of canonical values (host-side preprocessing only: sigma values)"""
+    a, b = np.asarray(a, dtype=np.uint64), np.asarray(b, dtype=np.uint64)
+    m32 = np.uint64(0xFFFFFFFF)
+    s32 = np.uint64(32)
+    a0, a1, b0, b1 = a & m32, a >> s32, b & m32, b >> s32
+    p00, p01, p10, p11 = a0 * b0, a0 * b1, a1 * b0, a1 * b1
+    mid = (p00 >> s32) + (p01 & m32) + (p10 & m32)                       # < 3 * 2^32
+    lo = (p00 & m32) | ((mid & m32) << s32)
+    hi = p11 + (p01 >> s32) + (p10 >> s32) + (mid >> s32)                # the product is hi * 2^64 + lo
+    # 2^64 = 2^32 - 1, 2^96 = -1 (mod p):  lo - hi_hi + hi_lo * (2^32 - 1)
+    hi_hi, hi_lo = hi >> s32, hi & m32
+    t0 = lo - hi_hi
+    t0 = np.where(lo < hi_hi, t0 - m32, t0)                              # borrow: -2^64 = -(2^32 - 1)
+    t1 = hi_lo * m32
+    r = t0 + t1
+    r = np.where(r < t1, r + m32, r)                                     # carry: +2^64 = +(2^32 - 1)
+    return np.where(r >= np.uint64(P), r - np.uint64(P), r)
+
+
+VIRTUAL_BASE = 1 << 40        # integer keys: wire (row, col) -> row * 256 + col; virtual target idx -> VIRTUAL_BASE + idx
+
+
+def key_is_wire(k):
+    return k < VIRTUAL_BASE
+
+
 class Target:
-    __slots__ = ("row", "col", "idx")
+    __slots__ = ("row", "col", "idx", "k")
 
     def __init__(self, row=None, col=None, idx=None):
         self.row, self.col, self.idx = row, col, idx
+        self.k = (row << 8) | col if idx is None else VIRTUAL_BASE + idx
 
     def key(self):
-        return ("w", self.row, self.col) if self.idx is None else ("v", self.idx)
+        return self.k
 
     def __repr__(self):
         return "Wire(%d,%d)" % (self.row, self.col) if self.idx is None else "Virtual(%d)" % self.idx
@@ -62,6 +90,7 @@ class Target:
 class CircuitBuilder:
     def __init__(self, config=None):
         self.config = config or standard_recursion_config()
+        assert self.config["num_wires"] <= 256, "target keys pack the column into 8 bits"
         self.rows = []            # (gate, constants)
         self.n_virtual = 0
         self.parent = {}          # union-find over target keys
@@ -103,7 +132,7 @@ class CircuitBuilder:
         return root
 
     def connect(self, a, b):
-        ra, rb = self._find(a.key()), self._find(b.key())
+        ra, rb = self._find(a.k), self._find(b.k)
         if ra != rb:
             self.parent[ra] = rb
 
@@ -112,10 +141,12 @@ class CircuitBuilder:
         self.rows.append((gate, [c % P for c in constants]))
         return len(self.rows) - 1
 
-    def add_generator(self, inputs, fn, op=None, params=()):
+    def add_generator(self, inputs, fn, op=None, params=(), outs=None):
         """fn(values of inputs) -> [(target, value)]; (op, params) name the same computation for the native interpreter
-        (csrc/plonky2_witness.cpp), which must emit its outputs in the order fn returns them"""
-        self.generators.append((list(inputs), fn, op, tuple(int(x) for x in params)))
+        (csrc/plonky2_witness.cpp), which must emit its outputs in the order fn returns them.  `outs` = the targets fn sets, in
+        that order: when every generator declares them, the interpreter program is compiled without running the Python
+        generators (CircuitData.witness_program)."""
+        self.generators.append((list(inputs), fn, op, tuple(int(x) for x in params), None if outs is None else list(outs)))
 
     # ---- constants
     def constant(self, c):
@@ -129,7 +160,7 @@ class CircuitBuilder:
         self.rows[row][1][k] = c
         self._const_slot[1] += 1
         t = Target(row, k)
-        self.add_generator([], lambda v, t=t, c=c: [(t, c)], OP_CONST, (c,))
+        self.add_generator([], lambda v, t=t, c=c: [(t, c)], OP_CONST, (c,), outs=[t])
         self._const_targets[c] = t
         self._target_const[t.key()] = c
         return t
@@ -160,7 +191,7 @@ class CircuitBuilder:
         self.connect(m1, w[1])
         self.connect(addend, w[2])
         self.add_generator([w[0], w[1], w[2]],
-                           lambda v, w=w, c0=c0, c1=c1: [(w[3], (c0 * v[0] * v[1] + c1 * v[2]) % P)], OP_ARITH, (c0, c1))
+                           lambda v, w=w, c0=c0, c1=c1: [(w[3], (c0 * v[0] * v[1] + c1 * v[2]) % P)], OP_ARITH, (c0, c1), outs=[w[3]])
         return w[3]
 
     def mul(self, a, b):
@@ -189,7 +220,7 @@ class CircuitBuilder:
         def gen(v, bits=bits, num_bits=num_bits):
             assert v[0] < (1 << num_bits), "split_le: value does not fit"
             return [(bits[i], (v[0] >> i) & 1) for i in range(num_bits)]
-        self.add_generator([s], gen, OP_SPLIT, (2, num_bits))
+        self.add_generator([s], gen, OP_SPLIT, (2, num_bits), outs=bits)
         return bits
 
     def le_sum(self, bits):
@@ -203,7 +234,7 @@ class CircuitBuilder:
         for b, l in zip(bits, limbs):
             self.connect(b, l)
         s = Target(row, 0)
-        self.add_generator(limbs, lambda v, s=s: [(s, sum(x << i for i, x in enumerate(v)) % P)], OP_LE_SUM)
+        self.add_generator(limbs, lambda v, s=s: [(s, sum(x << i for i, x in enumerate(v)) % P)], OP_LE_SUM, outs=[s])
         return s
 
     # ---- U32AddManyGate (crypto/plonky2_u32/src/gadgets/arithmetic_u32.rs:157-183 `add_many_u32`)
@@ -248,7 +279,7 @@ class CircuitBuilder:
             out += [(limbs[j], (lo >> (2 * j)) & 3) for j in range(16)]
             out += [(limbs[16 + j], (hi >> (2 * j)) & 3) for j in range(2)]
             return out
-        self.add_generator(ins, gen, OP_ADD_MANY)
+        self.add_generator(ins, gen, OP_ADD_MANY, outs=[res, carry] + limbs)
         return res, carry
 
     def sub_u32(self, x, y, borrow):
@@ -269,7 +300,7 @@ class CircuitBuilder:
             res = d + (bout << 32)
             assert 0 <= res < (1 << 32)
             return [(w[3], res), (w[4], bout)] + [(limbs[j], (res >> (2 * j)) & 3) for j in range(16)]
-        self.add_generator(w[:3], gen, OP_SUB_U32)
+        self.add_generator(w[:3], gen, OP_SUB_U32, outs=[w[3], w[4]] + limbs)
         return w[3], w[4]
 
     def range_check_u32(self, vals):
@@ -288,7 +319,7 @@ class CircuitBuilder:
                 assert x < (1 << 32), "range_check_u32: value exceeds 32 bits"
                 out += [(Target(row, n + 16 * i + j), (x >> (2 * j)) & 3) for j in range(16)]
             return out
-        self.add_generator(ins, gen, OP_RANGE_CHECK)
+        self.add_generator(ins, gen, OP_RANGE_CHECK, outs=[Target(row, n + 16 * i + j) for i in range(n) for j in range(16)])
 
     def _comparison(self, a, b, num_bits=32):
         """one ComparisonGate row: result = (a <= b)  (crypto/plonky2_u32/src/gates/comparison.rs generator)"""
@@ -321,7 +352,12 @@ class CircuitBuilder:
                 out.append((Target(row, 4 + 5 * nc + i), (top >> i) & 1))
             out.append((Target(row, 2), (top >> cb) & 1))
             return out
-        self.add_generator([wa, wb], gen, OP_COMPARISON, (nc, cb))
+        outs = []
+        for i in range(nc):
+            outs += [Target(row, 4 + i), Target(row, 4 + nc + i), Target(row, 4 + 2 * nc + i), Target(row, 4 + 3 * nc + i),
+                     Target(row, 4 + 4 * nc + i)]
+        outs += [Target(row, 3)] + [Target(row, 4 + 5 * nc + i) for i in range(cb + 1)] + [Target(row, 2)]
+        self.add_generator([wa, wb], gen, OP_COMPARISON, (nc, cb), outs=outs)
         return Target(row, 2)
 
     def list_le(self, a, b, num_bits=32):
@@ -355,7 +391,7 @@ class CircuitBuilder:
         equal, inv = self.add_virtual_target(), self.add_virtual_target()
         self.add_generator([x, y], lambda v, equal=equal, inv=inv: [(equal, 1 if v[0] == v[1] else 0),
                                                                     (inv, 0 if v[0] == v[1] else pow((v[0] - v[1]) % P, P - 2, P))],
-                           OP_IS_EQUAL)
+                           OP_IS_EQUAL, outs=[equal, inv])
         not_equal = self.not_(equal)
         diff = self.sub(x, y)
         self.connect(self.mul(diff, equal), self.zero())
@@ -375,7 +411,7 @@ class CircuitBuilder:
         def gen(v, limbs=limbs, base=base, num_limbs=num_limbs):
             assert v[0] < base ** num_limbs, "split_le_base: value does not fit"
             return [(limbs[i], (v[0] // base ** i) % base) for i in range(num_limbs)]
-        self.add_generator([s], gen, OP_SPLIT, (base, num_limbs))
+        self.add_generator([s], gen, OP_SPLIT, (base, num_limbs), outs=limbs)
         return limbs
 
     def random_access(self, index, items):
@@ -406,7 +442,7 @@ class CircuitBuilder:
             idx = v[0]
             assert idx < (1 << bits), "random_access: index out of range"
             return [(w_claim, v[1 + idx])] + [(w_bits[i], (idx >> i) & 1) for i in range(bits)]
-        self.add_generator([w_idx] + w_items, gen, OP_RANDOM_ACCESS, (bits,))
+        self.add_generator([w_idx] + w_items, gen, OP_RANDOM_ACCESS, (bits,), outs=[w_claim] + w_bits)
         return w_claim
 
     # ---- U32ArithmeticGate: (lo, hi) = m0*m1 + addend on 32-bit values
@@ -435,7 +471,7 @@ class CircuitBuilder:
             res = [(w[3], lo), (w[4], hi), (w[5], inv)]
             res += [(limbs[j], (out >> (2 * j)) & 3) for j in range(32)]
             return res
-        self.add_generator(w[:3], gen, OP_U32_MULADD)
+        self.add_generator(w[:3], gen, OP_U32_MULADD, outs=[w[3], w[4], w[5]] + limbs)
         return w[3], w[4]
 
     # ---- Poseidon (PoseidonGate rows); witness rows come from the library (zklc_poseidon_gl_gate_rows)
@@ -452,7 +488,7 @@ class CircuitBuilder:
             from .prover import poseidon_gate_rows
             r = poseidon_gate_rows(np.array([v[:12]], dtype=np.uint64), np.array([v[12]], dtype=np.uint64))[0]
             return [(Target(row, c), int(r[c])) for c in range(12, 135) if c != 24]
-        self.add_generator(ins + [sw], gen, OP_POSEIDON)
+        self.add_generator(ins + [sw], gen, OP_POSEIDON, outs=[Target(row, c) for c in range(12, 135) if c != 24])
         return [Target(row, 12 + i) for i in range(12)]
 
     def hash_n_to_hash_no_pad(self, inputs):
@@ -505,18 +541,28 @@ class CircuitData:
             for k, c in enumerate(cs):
                 row_consts[k, r] = c
         routed = b.config["num_routed_wires"]
-        # sigma: every routed wire maps to the next wire of its copy class (cyclically)
-        classes = {}
-        for k in list(b.parent):
-            if k[0] == "w":
-                classes.setdefault(b._find(k), []).append((k[2], k[1]))   # (col, row)
+        # sigma: every routed wire maps to the next wire of its copy class (cyclically; members ordered by (column, row))
         sig_col = np.tile(np.arange(routed, dtype=np.int64)[:, None], (1, n))
         sig_row = np.tile(np.arange(n, dtype=np.int64)[None, :], (routed, 1))
-        for members in classes.values():
-            members.sort()
-            assert all(c < routed for c, _ in members), "copy constraint on a non-routed wire"
-            for (c0, r0), (c1, r1) in zip(members, members[1:] + members[:1]):
-                sig_col[c0, r0], sig_row[c0, r0] = c1, r1
+        pk = np.fromiter(b.parent.keys(), dtype=np.int64, count=len(b.parent))
+        find = b._find
+        pr = np.fromiter((find(k) for k in b.parent), dtype=np.int64, count=len(b.parent))
+        wk, wr = pk[pk < VIRTUAL_BASE], pr[pk < VIRTUAL_BASE]
+        root_wires = np.unique(pr[pr < VIRTUAL_BASE])          # a class root has no parent entry: add it to its own class
+        wk, wr = np.concatenate([wk, root_wires]), np.concatenate([wr, root_wires])
+        if len(wk):
+            col, row = wk & 255, wk >> 8
+            assert int(col.max()) < routed, "copy constraint on a non-routed wire"
+            o = np.lexsort((row, col, wr))
+            col, row, wr = col[o], row[o], wr[o]
+            first = np.ones(len(wr), dtype=bool)
+            first[1:] = wr[1:] != wr[:-1]
+            start = np.maximum.accumulate(np.where(first, np.arange(len(wr)), 0))       # index of the first member of my class
+            nxt = np.arange(len(wr)) + 1
+            last = np.ones(len(wr), dtype=bool)
+            last[:-1] = first[1:]
+            nxt[last] = start[last]
+            sig_col[col, row], sig_row[col, row] = col[nxt], row[nxt]
         self.builder = b
         self._plan = None
         self._trace = None
@@ -578,28 +624,27 @@ class CircuitData:
         for i in range(1, n):
             sub[i] = sub[i - 1] * w % P
         self.subgroup = sub
-        # sigma_j(w^i) = k_is[col'] * w^(row'): one field multiplication per cell, done column by column
-        sub_arr = np.array(sub, dtype=object)
-        sig = np.zeros((routed, n), dtype=np.uint64)
-        ident = np.arange(n, dtype=np.int64)
-        for j in range(routed):
-            cols, rows = sig_col[j], sig_row[j]
-            if np.all(cols == j) and np.array_equal(rows, ident):
-                sig[j] = np.array([self.k_is[j] * x % P for x in sub], dtype=np.uint64)
-            else:
-                k_of = np.array([self.k_is[c] for c in cols], dtype=object)
-                sig[j] = np.array((k_of * sub_arr[rows]) % P, dtype=np.uint64)
+        # sigma_j(w^i) = k_is[col'] * w^(row'): one field multiplication per cell
+        sub_arr = np.array(sub, dtype=np.uint64)
+        k_arr = np.array(self.k_is, dtype=np.uint64)
+        sig = gl_mul_np(k_arr[sig_col], sub_arr[sig_row])
         self.sigmas = sig
         self.fri_arity_bits = fri_reduction_arity_bits(cfg, self.degree_bits)
         self.num_public_inputs = num_public_inputs
 
     # ---- native witness generation (csrc/plonky2_witness.cpp)
-    def witness_program(self, example_inputs):
-        """Compile the circuit's generators into the interpreter's program.  `example_inputs` is any satisfiable partial
-        witness {Target: value}: one run of the Python generators fixes the execution order and the output slots."""
+    def witness_program(self, example_inputs, trace_python=False):
+        """Compile the circuit's generators into the interpreter's program.  `example_inputs`: a partial witness {Target: value}
+        (or just the list of its targets) naming the circuit's inputs.  When every generator declares its outputs the program is
+        assembled from the dependency structure alone (numpy, no generator is run); otherwise (or with trace_python) one run
+        of the Python generators on the example -- which must then be satisfiable -- fixes the order and the output slots."""
         if self._program is not None:
             return self._program
         b = self.builder
+        assert self.config["num_wires"] * self.n < (1 << 32)
+        if not trace_python and all(g[4] is not None for g in b.generators):
+            self._program = self._compile_program(list(example_inputs))
+            return self._program
         self._trace = []
         try:
             self.generate_witness(example_inputs)
@@ -616,21 +661,20 @@ class CircuitData:
             return s_
         code, pvals = [], []
         for gi, out_keys in trace:
-            ins, _, op, params = b.generators[gi]
+            ins, _, op, params, _ = b.generators[gi]
             assert op is not None, "generator without a native opcode"
             code += [op, len(params), len(ins), len(out_keys)]
             pvals += [x - (1 << 64) if x >= (1 << 63) else x for x in params]
             code += [slot(find(t)) for t in ins] + [slot(k) for k in out_keys]
-        in_targets = list(example_inputs.keys())
+        in_targets = list(example_inputs.keys()) if isinstance(example_inputs, dict) else list(example_inputs)
         ws, wi = [], []
         n_rows = self.n
-        for k in list(b.parent) + [k for k in slot_of if k[0] == "w" and k not in b.parent]:
-            if k[0] == "w":
+        for k in list(b.parent) + [k for k in slot_of if k < VIRTUAL_BASE and k not in b.parent]:
+            if k < VIRTUAL_BASE:
                 r = b._find(k)
                 if r in slot_of:
                     ws.append(slot_of[r])
-                    wi.append(k[2] * n_rows + k[1])
-        assert self.config["num_wires"] * n_rows < (1 << 32)
+                    wi.append((k & 255) * n_rows + (k >> 8))
         order = np.argsort(np.array(wi, dtype=np.int64), kind="stable")      # scatter in address order
         self._program = {
             "code": np.array(code, dtype=np.uint32), "params": np.array(pvals + [0], dtype=np.int64),
@@ -640,6 +684,100 @@ class CircuitData:
         }
         self._program["n_slots"] = len(slot_of) + 1
         return self._program
+
+    def _compile_program(self, in_targets):
+        """the interpreter program from the generators' declared inputs / outputs: copy classes -> dense slots, a topological
+        order (creation order when it already is one), instruction words and the slot -> wire-cell scatter list, all as array
+        operations (the Ed25519 circuit has ~2 M generators over ~40 M targets)"""
+        b = self.builder
+        gens = b.generators
+        G_ = len(gens)
+        assert all(g[2] is not None for g in gens), "generator without a native opcode"
+        ins_len = np.fromiter((len(g[0]) for g in gens), dtype=np.int64, count=G_)
+        outs_len = np.fromiter((len(g[4]) for g in gens), dtype=np.int64, count=G_)
+        par_len = np.fromiter((len(g[3]) for g in gens), dtype=np.int64, count=G_)
+        ops = np.fromiter((g[2] for g in gens), dtype=np.int64, count=G_)
+        ins_k = np.fromiter((t.k for g in gens for t in g[0]), dtype=np.int64, count=int(ins_len.sum()))
+        outs_k = np.fromiter((t.k for g in gens for t in g[4]), dtype=np.int64, count=int(outs_len.sum()))
+        params = np.fromiter((x - (1 << 64) if x >= (1 << 63) else x for g in gens for x in g[3]), dtype=np.int64,
+                             count=int(par_len.sum()))
+        in_k = np.array([t.k for t in in_targets], dtype=np.int64)
+        pi_k = np.array([t.k for t in b.public_inputs], dtype=np.int64)
+        # copy classes: key -> root for the keys that were ever connected, identity for the rest
+        pk = np.fromiter(b.parent.keys(), dtype=np.int64, count=len(b.parent))
+        find = b._find
+        pr = np.fromiter((find(k) for k in b.parent), dtype=np.int64, count=len(b.parent))
+        o = np.argsort(pk, kind="stable")
+        pk, pr = pk[o], pr[o]
+
+        def roots(keys):
+            if len(pk) == 0 or len(keys) == 0:
+                return keys.copy()
+            idx = np.minimum(np.searchsorted(pk, keys), len(pk) - 1)
+            hit = pk[idx] == keys
+            r = keys.copy()
+            r[hit] = pr[idx[hit]]
+            return r
+        parts = [roots(ins_k), roots(outs_k), roots(in_k), roots(pi_k)]
+        uniq, inv = np.unique(np.concatenate(parts), return_inverse=True)
+        # wire cells to fill: every connected wire, every wire a generator names, and the class roots that are wires
+        wire_k = np.unique(np.concatenate([pk[pk < VIRTUAL_BASE], ins_k[ins_k < VIRTUAL_BASE], outs_k[outs_k < VIRTUAL_BASE],
+                                           in_k[in_k < VIRTUAL_BASE], uniq[uniq < VIRTUAL_BASE]]))
+        n_slots = len(uniq)
+        cuts = np.cumsum([len(p) for p in parts])
+        in_slots, out_slots, input_slots, pi_slots = inv[:cuts[0]], inv[cuts[0]:cuts[1]], inv[cuts[1]:cuts[2]], inv[cuts[2]:]
+        # order: creation order if every input is a circuit input or produced by an earlier generator; else multi-pass scheduling
+        in_off, out_off = np.cumsum(ins_len) - ins_len, np.cumsum(outs_len) - outs_len
+        gen_of_in = np.repeat(np.arange(G_, dtype=np.int64), ins_len)
+        producer = np.full(n_slots, G_, dtype=np.int64)
+        np.minimum.at(producer, out_slots, np.repeat(np.arange(G_, dtype=np.int64), outs_len))
+        producer[input_slots] = -1
+        if np.all(producer[in_slots] < gen_of_in):
+            order = np.arange(G_, dtype=np.int64)
+        else:
+            avail = np.zeros(n_slots, dtype=bool)
+            avail[input_slots] = True
+            done, pending = [], range(G_)
+            il, ol = ins_len.tolist(), outs_len.tolist()
+            io, oo = in_off.tolist(), out_off.tolist()
+            while len(pending):
+                rest = []
+                for g in pending:
+                    if il[g] == 0 or avail[in_slots[io[g]:io[g] + il[g]]].all():
+                        done.append(g)
+                        avail[out_slots[oo[g]:oo[g] + ol[g]]] = True
+                    else:
+                        rest.append(g)
+                assert len(rest) < len(pending), "witness program: %d generators can never run" % len(rest)
+                pending = rest
+            order = np.array(done, dtype=np.int64)
+        # instruction words: [opcode, n_params, n_in, n_out, ins..., outs...]
+        il, ol = ins_len[order], outs_len[order]
+        length = 4 + il + ol
+        starts = np.cumsum(length) - length
+        code = np.empty(int(length.sum()), dtype=np.uint32)
+        code[starts], code[starts + 1], code[starts + 2], code[starts + 3] = ops[order], par_len[order], il, ol
+
+        def gather(dst0, lens, src_off, src):
+            tot = int(lens.sum())
+            within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(lens) - lens, lens)
+            code[np.repeat(dst0, lens) + within] = src[np.repeat(src_off, lens) + within]
+        gather(starts + 4, il, in_off[order], in_slots)
+        gather(starts + 4 + il, ol, out_off[order], out_slots)
+        pl = par_len[order]
+        tot = int(pl.sum())
+        within = np.arange(tot, dtype=np.int64) - np.repeat(np.cumsum(pl) - pl, pl)
+        pvals = params[np.repeat((np.cumsum(par_len) - par_len)[order], pl) + within]
+        # every wire cell whose copy class has a slot receives that slot's value
+        wr = roots(wire_k)
+        idx = np.minimum(np.searchsorted(uniq, wr), n_slots - 1)
+        has = uniq[idx] == wr
+        wire_k, idx = wire_k[has], idx[has]
+        wi = (wire_k & 255) * self.n + (wire_k >> 8)
+        o = np.argsort(wi, kind="stable")
+        return {"code": code, "params": np.concatenate([pvals, np.zeros(1, dtype=np.int64)]), "input_targets": in_targets,
+                "input_slots": input_slots.astype(np.uint32), "wire_slot": idx[o].astype(np.uint32),
+                "wire_index": wi[o].astype(np.uint32), "pi_slots": pi_slots.astype(np.uint32), "n_slots": n_slots + 1}
 
     def generate_witness_native(self, inputs_list, out=None, threads=None, input_values=None):
         """inputs_list: partial witnesses ({Target: value} with the same keys as the example given to witness_program), or
@@ -700,21 +838,25 @@ class CircuitData:
             "num_lookup_polys": 0, "num_lookup_selectors": 0, "luts": [],
         }
 
-    # ---- witness generation (plonky2 `generate_partial_witness`): run generators until no progress
-    def generate_witness(self, inputs):
-        """inputs: {Target: value}.  Returns (wires u64[num_wires, n], public input values)."""
-        b = self.builder
+    def _ensure_plan(self):
         if self._plan is None:
             # the copy classes are final once the circuit is built: resolve every target to its class once
+            b = self.builder
             rep = {}
 
             def find(t):
-                k = t.key()
+                k = t.k
                 r = rep.get(k)
                 if r is None:
                     r = rep[k] = b._find(k)
                 return r
-            self._plan = ([([find(t) for t in ins], fn, gi) for gi, (ins, fn, _, _) in enumerate(b.generators)], find)
+            self._plan = ([([find(t) for t in ins], fn, gi) for gi, (ins, fn, _, _, _) in enumerate(b.generators)], find)
+
+    # ---- witness generation (plonky2 `generate_partial_witness`): run generators until no progress
+    def generate_witness(self, inputs):
+        """inputs: {Target: value}.  Returns (wires u64[num_wires, n], public input values)."""
+        b = self.builder
+        self._ensure_plan()
         plan, find = self._plan
         vals = {}
 
@@ -748,12 +890,12 @@ class CircuitData:
             pending = rest
         wires = np.zeros((self.config["num_wires"], self.n), dtype=np.uint64)
         for k, v in vals.items():
-            if k[0] == "w":
-                wires[k[2], k[1]] = v
+            if k < VIRTUAL_BASE:
+                wires[k & 255, k >> 8] = v
         for k in b.parent:
-            if k[0] == "w":
+            if k < VIRTUAL_BASE:
                 r = b._find(k)
                 if r in vals:
-                    wires[k[2], k[1]] = vals[r]
+                    wires[k & 255, k >> 8] = vals[r]
         pis = [vals[find(t)] for t in b.public_inputs]
         return wires, pis

@@ -165,7 +165,7 @@ class Gadgets:
             av, bvv = value_of(v[:a_len]), value_of(v[a_len:])
             q, r = divmod(av, bvv)
             return list(zip(div, limbs_of(q, len(div)))) + list(zip(rem, limbs_of(r, len(rem))))
-        self.b.add_generator(a + bv, gen, OP_DIV_REM, (a_len, len(div), len(rem)))
+        self.b.add_generator(a + bv, gen, OP_DIV_REM, (a_len, len(div), len(rem)), outs=div + rem)
         div_b = self.mul_biguint(div, bv)
         self.connect_biguint(a, self.add_biguint(div_b, rem))
         self.b.assert_one(self.cmp_biguint(rem, bv))
@@ -184,7 +184,7 @@ class Gadgets:
             t = x + y
             ov = 1 if t > m else 0                                    # nonnative.rs:487 (strict: t == m stays unreduced)
             return list(zip(s, limbs_of(t - m * ov, 8))) + [(overflow, ov)]
-        self.b.add_generator(a + bv, gen, OP_NN_ADD, [len(a)] + limbs_of(m, 8))
+        self.b.add_generator(a + bv, gen, OP_NN_ADD, [len(a)] + limbs_of(m, 8), outs=s + [overflow])
         expected = self.add_biguint(a, bv)
         modulus = self.constant_biguint(m)
         actual = self.add_biguint(s, self.mul_biguint_by_bool(modulus, overflow))
@@ -199,7 +199,7 @@ class Gadgets:
         def gen(v, diff=diff, overflow=overflow, na=len(a), m=m):
             x, y = value_of(v[:na]) % m, value_of(v[na:]) % m
             return list(zip(diff, limbs_of((x - y) % m, 8))) + [(overflow, 1 if x < y else 0)]
-        self.b.add_generator(a + bv, gen, OP_NN_SUB, [len(a)] + limbs_of(m, 8))
+        self.b.add_generator(a + bv, gen, OP_NN_SUB, [len(a)] + limbs_of(m, 8), outs=diff + [overflow])
         self.b.range_check_u32(diff)
         self.b.assert_bool(overflow)
         diff_plus_b = self.add_biguint(diff, bv)
@@ -216,7 +216,7 @@ class Gadgets:
             x, y = value_of(v[:na]) % m, value_of(v[na:]) % m
             q, r = divmod(x * y, m)
             return list(zip(prod, limbs_of(r, 8))) + list(zip(overflow, limbs_of(q, len(overflow))))
-        self.b.add_generator(a + bv, gen, OP_NN_MUL, [len(a), len(overflow)] + limbs_of(m, 8))
+        self.b.add_generator(a + bv, gen, OP_NN_MUL, [len(a), len(overflow)] + limbs_of(m, 8), outs=prod + overflow)
         self.b.range_check_u32(prod)
         self.b.range_check_u32(overflow)
         expected = self.mul_biguint(a, bv)
@@ -236,7 +236,7 @@ class Gadgets:
             xv = value_of(v) % m
             iv = pow(xv, m - 2, m)
             return list(zip(inv, limbs_of(iv, n))) + list(zip(div, limbs_of((xv * iv - 1) // m, n)))
-        self.b.add_generator(x, gen, OP_NN_INV, [n] + limbs_of(m, 8))
+        self.b.add_generator(x, gen, OP_NN_INV, [n] + limbs_of(m, 8), outs=inv + div)
         product = self.mul_biguint(x, inv)
         modulus = self.constant_biguint(m)
         expected = self.add_biguint(self.mul_biguint(modulus, div), self.constant_biguint(1))
@@ -329,7 +329,7 @@ class Gadgets:
             sign, y = val >> 255, val & ((1 << 255) - 1)
             x = _recover_x(y % P25519, sign)
             return list(zip(p[0], limbs_of(x, 8))) + list(zip(p[1], limbs_of(y, 8)))
-        self.b.add_generator(pv, gen, OP_DECOMPRESS)
+        self.b.add_generator(pv, gen, OP_DECOMPRESS, outs=p[0] + p[1])
         pv2 = self.point_compress(p)
         for a, bb in zip(pv, pv2):
             self.b.connect(a, bb)

@@ -144,7 +144,7 @@ class RecursiveCircuitBuilder(CircuitBuilder):
             def gen(v, w=w, c0=c0):
                 o = e_scalar(c0, e_mul((v[0], v[1]), (v[2], v[3])))
                 return [(w[4], o[0]), (w[5], o[1])]
-            self.add_generator(w[:4], gen, OP_EXT_MUL, (c0,))
+            self.add_generator(w[:4], gen, OP_EXT_MUL, (c0,), outs=w[4:6])
             out = (w[4], w[5])
         else:
             gate = G.ArithmeticExtensionGate.new_from_config(self.config)
@@ -161,7 +161,7 @@ class RecursiveCircuitBuilder(CircuitBuilder):
             def gen(v, w=w, c0=c0, c1=c1):
                 o = e_add(e_scalar(c0, e_mul((v[0], v[1]), (v[2], v[3]))), e_scalar(c1, (v[4], v[5])))
                 return [(w[6], o[0]), (w[7], o[1])]
-            self.add_generator(w[:6], gen, OP_EXT_ARITH, (c0, c1))
+            self.add_generator(w[:6], gen, OP_EXT_ARITH, (c0, c1), outs=w[6:8])
             out = (w[6], w[7])
         self._ext_memo[key] = out
         return out
@@ -197,7 +197,7 @@ class RecursiveCircuitBuilder(CircuitBuilder):
     def div_add_ext(self, x, y, z):
         """x / y + z: the inverse of y is a witness, constrained by y * inv == 1"""
         inv = self.add_virtual_ext()
-        self.add_generator([y[0], y[1]], lambda v, inv=inv: list(zip(inv, e_inv((v[0], v[1])))), OP_EXT_INV)
+        self.add_generator([y[0], y[1]], lambda v, inv=inv: list(zip(inv, e_inv((v[0], v[1])))), OP_EXT_INV, outs=list(inv))
         self.connect_ext(self.mul_ext(y, inv), self.one_ext())
         return self.mul_add_ext(x, inv, z)
 
@@ -237,6 +237,12 @@ class RecursiveCircuitBuilder(CircuitBuilder):
         for t in bits[num_bits:]:
             self.assert_zero(t)
         sums = [Target(r, 0) for r in rows]
+        if k > 1:       # generators first, in dependency order (the program compiler then keeps the creation order)
+            self.add_generator([x], lambda v, sums=sums, nl=nl: [(s, (v[0] >> (nl * i)) & ((1 << nl) - 1)) for i, s in enumerate(sums)],
+                               OP_SPLIT, (1 << nl, k), outs=sums)
+        for r, s in zip(rows, sums):
+            limbs = [Target(r, 1 + i) for i in range(nl)]
+            self.add_generator([s], lambda v, limbs=limbs: [(t, (v[0] >> i) & 1) for i, t in enumerate(limbs)], OP_SPLIT, (2, nl), outs=limbs)
         if k == 1:
             self.connect(sums[0], x)
         else:
@@ -244,11 +250,6 @@ class RecursiveCircuitBuilder(CircuitBuilder):
             for s in reversed(sums[:-1]):
                 acc = self.arithmetic(1 << nl, acc, self.one(), 1, s)
             self.connect(acc, x)
-            self.add_generator([x], lambda v, sums=sums, nl=nl: [(s, (v[0] >> (nl * i)) & ((1 << nl) - 1)) for i, s in enumerate(sums)],
-                               OP_SPLIT, (1 << nl, k))
-        for r, s in zip(rows, sums):
-            limbs = [Target(r, 1 + i) for i in range(nl)]
-            self.add_generator([s], lambda v, limbs=limbs: [(t, (v[0] >> i) & 1) for i, t in enumerate(limbs)], OP_SPLIT, (2, nl))
         return bits[:num_bits]
 
     def range_check(self, x, num_bits):
@@ -290,7 +291,7 @@ class RecursiveCircuitBuilder(CircuitBuilder):
                 cur = prev * (base_v if v[1 + n - 1 - i] else 1) % P
                 res.append((Target(row, 2 + n + i), cur))
             return res + [(out, cur)]
-        self.add_generator([Target(row, 0)] + wb, gen, OP_EXPONENTIATION)
+        self.add_generator([Target(row, 0)] + wb, gen, OP_EXPONENTIATION, outs=[Target(row, 2 + n + i) for i in range(n)] + [out])
         return out
 
     def exp_from_bits_const_base(self, base, bits):
@@ -340,7 +341,12 @@ class RecursiveCircuitBuilder(CircuitBuilder):
                 s = 1 + (d - 1) * (i + 1)
                 ev, prod = partial(s, min(s + d - 1, np_), ev, prod)
             return res + [(Target(row, start_val), ev[0]), (Target(row, start_val + 1), ev[1])]
-        self.add_generator(ins, gen, OP_COSET_INTERP, (gate.subgroup_bits, gate.degree) + tuple(gate.weights))
+        outs = [Target(row, start_inter + 4 * ni), Target(row, start_inter + 4 * ni + 1)]
+        for i in range(ni):
+            outs += [Target(row, start_inter + 2 * i), Target(row, start_inter + 2 * i + 1),
+                     Target(row, start_inter + 2 * (ni + i)), Target(row, start_inter + 2 * (ni + i) + 1)]
+        outs += [Target(row, start_val), Target(row, start_val + 1)]
+        self.add_generator(ins, gen, OP_COSET_INTERP, (gate.subgroup_bits, gate.degree) + tuple(gate.weights), outs=outs)
         return (Target(row, start_val), Target(row, start_val + 1))
 
     # ---- PoseidonMdsGate on extension targets
@@ -366,7 +372,7 @@ class RecursiveCircuitBuilder(CircuitBuilder):
                 a1 += v[2 * r + 1] * diag[r]
                 res += [(Target(row, 24 + 2 * r), a0 % P), (Target(row, 25 + 2 * r), a1 % P)]
             return res
-        self.add_generator(ins, gen, OP_POSEIDON_MDS)
+        self.add_generator(ins, gen, OP_POSEIDON_MDS, outs=[Target(row, 24 + k) for k in range(24)])
         return [(Target(row, 24 + 2 * r), Target(row, 25 + 2 * r)) for r in range(12)]
 
     # ---- hashing
@@ -434,7 +440,11 @@ class ReducingFactor:
                     c = 0 if i == n - 1 else start_accs + 2 * i
                     res += [(Target(row, c), acc_v[0]), (Target(row, c + 1), acc_v[1])]
                 return res
-            b.add_generator(ins, gen, OP_REDUCING_EXT if ext else OP_REDUCING, (n,))
+            outs = []
+            for i in range(n):
+                c = 0 if i == n - 1 else start_accs + 2 * i
+                outs += [Target(row, c), Target(row, c + 1)]
+            b.add_generator(ins, gen, OP_REDUCING_EXT if ext else OP_REDUCING, (n,), outs=outs)
             acc = (Target(row, 0), Target(row, 1))
         return acc
 
@@ -847,8 +857,8 @@ class RecursiveCircuit:
         self._maps = None
 
     def compile(self, example_pw, example_raws):
-        """first proof of this shape: compile the generators into the native program (this also checks the witness) and
-        index the program's inputs, so that later inner proofs go from their bytes to the input vector by one gather.
+        """first proof of this shape: compile the generators into the native program and index the program's inputs, so that
+        later inner proofs go from their bytes to the input vector by one gather.
         example_raws: the inner proofs of the example as bytes (layout templates)"""
         import numpy as np
         from . import serialization as S
