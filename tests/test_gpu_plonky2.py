@@ -67,6 +67,20 @@ def test_bad_witness_is_rejected(zctx):
     bad[3, row] ^= 1      # a copy-constrained output: the permutation product does not close -> ZKLC_ERR_INVALID_ARG
     with pytest.raises(zklc_amd.ZklcError):
         prover.prove_bytes(bad, pis)
+    # EVERY connected wire is bound by the permutation argument, the union-find representatives of the copy classes included:
+    # changing any single one of them (and nothing else) must break the grand product
+    b = data.builder
+    classes = {}
+    for k in list(b.parent) + [b._find(k) for k in b.parent]:
+        if k < (1 << 40):
+            classes.setdefault(b._find(k), set()).add(k)
+    connected = sorted(k for members in classes.values() if len(members) > 1 for k in members)
+    assert len(connected) > 20
+    for k in connected[::3]:
+        bad = wires.copy()
+        bad[k & 255, k >> 8] ^= 1
+        with pytest.raises(zklc_amd.ZklcError):
+            prover.prove_bytes(bad, pis)
     bad = wires.copy()
     bad[79, row] ^= 1     # only a gate constraint breaks: a proof comes out (as with plonky2) and the verifier rejects it
     proof = prover.prove(bad, pis)
