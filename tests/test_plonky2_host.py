@@ -250,3 +250,21 @@ def test_sigma_cycles_are_exactly_the_copy_classes():
         seen |= ids
         cyc = {c for c, s_ in cycle_of.items() if s_ in ids}
         assert cyc == members
+
+
+def test_proof_files_round_trip_with_the_golden_proof(tmp_path):
+    """write_proof_files / read_proof_files (prove_block.rs:320-458 layout): the golden proof.bin of the reference goes through
+    unchanged, the JSON side is the golden proof.json, and hash.json is the block hash carried in public inputs 1..33"""
+    j = load_golden("plonky2_near_random_CGZP.json")
+    raw = open(os.path.join(GOLDEN, "plonky2_near_random_CGZP_proof.bin"), "rb").read()
+    common, vd = j["common_data"], j["verifier_data"]
+    S.write_proof_files(str(tmp_path), common, vd, raw, S.HASH_BN128)
+    assert open(tmp_path / "proof.bin", "rb").read() == raw
+    c2, v2, p2 = S.read_proof_files(str(tmp_path), S.HASH_BN128)
+    assert c2 == common and v2 == vd
+    assert S.proof_to_bytes(p2, common, S.HASH_BN128) == raw
+    assert p2["public_inputs"] == j["proof"]["public_inputs"]
+    hash_hex = open(tmp_path / "hash.json").read()
+    assert bytes.fromhex(hash_hex) == bytes(int(x) for x in j["proof"]["public_inputs"][1:33])
+    import base58_min
+    assert base58_min.encode(bytes.fromhex(hash_hex)).startswith("CGZP")      # the directory name of the golden proof

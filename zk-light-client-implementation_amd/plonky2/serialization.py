@@ -168,3 +168,46 @@ def proof_size(common, hasher):
         per += 16 * (1 << a) + 1 + max(bits - sh["cap_height"], 0) * hb
     n += per * sh["rounds"] + 16 * sh["final_len"] + 8 + 8 + 8 * common["num_public_inputs"]
     return n
+
+
+def write_proof_files(directory, common, verifier_only, proof, hasher, prefix=""):
+    """The files near_bft_finality/src/bin/prove_block.rs:320-458 writes next to a proof (`<prefix>proof.bin`, `<prefix>proof.json`,
+    `<prefix>common_data.json`, `<prefix>verifier_data.json`; prefix "b0_" / "bn_" for the epoch blocks, "" otherwise) and, when the
+    proof has the 33+ public inputs of a block proof, `<prefix>hash.json` = hex of public inputs 1..33 (:305-311,441-443).
+    `proof` is the JSON form or the `to_bytes` bytes.  `verifier_data.bin` (VerifierCircuitData::to_bytes with plonky2's gate
+    serializer) is not produced: nothing on this path reads it back (gnark reads the JSON files)."""
+    import json
+    import os
+    os.makedirs(directory, exist_ok=True)
+    if isinstance(proof, (bytes, bytearray, memoryview)):
+        raw, pj = bytes(proof), proof_from_bytes(bytes(proof), common, hasher)
+    else:
+        raw, pj = proof_to_bytes(proof, common, hasher), proof
+    with open(os.path.join(directory, prefix + "proof.bin"), "wb") as f:
+        f.write(raw)
+    for name, obj in (("proof.json", pj), ("common_data.json", common), ("verifier_data.json", verifier_only)):
+        with open(os.path.join(directory, prefix + name), "w") as f:
+            json.dump(obj, f, indent=2)
+    pis = pj["public_inputs"]
+    if len(pis) >= 33 and all(int(x) < 256 for x in pis[1:33]):
+        with open(os.path.join(directory, prefix + "hash.json"), "w") as f:
+            f.write(bytes(int(x) for x in pis[1:33]).hex())
+
+
+def read_proof_files(directory, hasher, prefix=""):
+    """(common, verifier_only, proof json) as the reference reads them back (signatures.rs:225-230 from bytes; the gnark service
+    from the JSON files): proof.bin wins over proof.json when both exist"""
+    import json
+    import os
+    with open(os.path.join(directory, prefix + "common_data.json")) as f:
+        common = json.load(f)
+    with open(os.path.join(directory, prefix + "verifier_data.json")) as f:
+        vd = json.load(f)
+    pbin = os.path.join(directory, prefix + "proof.bin")
+    if os.path.exists(pbin):
+        with open(pbin, "rb") as f:
+            proof = proof_from_bytes(f.read(), common, hasher)
+    else:
+        with open(os.path.join(directory, prefix + "proof.json")) as f:
+            proof = json.load(f)
+    return common, vd, proof
