@@ -276,6 +276,88 @@ __global__ void __launch_bounds__(256) gl_merkle_level_kernel(const u64 *__restr
     o[1] = make_ulonglong2(h[2], h[3]);
 }
 
+// ---- cooperative Poseidon for SMALL trees: one permutation per 16-lane group (lane g < 12 holds state element g).
+// A lane-per-permutation kernel needs ~35 k dependent instructions = ~58 us per Merkle level however few nodes the level has;
+// the top ~13 levels of every tree and the small FRI trees are pure latency.  Here a permutation is ~5 k instructions per
+// lane: S-box on the lane's own element, the MDS layer as 12 LDS reads of the group's elements (circulant row of lane g), and
+// the partial rounds in the dense form -- S-box on lane 0 only, the same MDS layer, optimised round constants (first layer 12,
+// then one per round) -- which is the same permutation (oracle/poseidon_gl.py::permute_naive, tests/test_oracle_poseidon.py).
+#define PGL_COOP_GROUPS 16   // 16-lane groups per 256-thread workgroup
+__device__ __forceinline__ u64 pgl_coop_mds(u64 s, u32 g, u64 *grp) {
+    const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    __syncthreads();            // the previous layer's reads are done
+    if (g < 12) grp[g] = s;
+    __syncthreads();
+    u64 sl = 0, sh = 0;
+    const u32 gg = g < 12 ? g : 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        u32 j = gg + i;
+        j = j >= 12 ? j - 12 : j;
+        u64 v = grp[j];
+        sl += (u64)(u32)v * C[i];
+        sh += (v >> 32) * C[i];
+    }
+    if (gg == 0) {
+        sl += (u64)(u32)s * 8;
+        sh += (s >> 32) * 8;
+    }
+    u64 l = sl + (sh << 32);
+    u64 h = (sh >> 32) + (l < sl);
+    return gl_reduce128_loose(l, h);
+}
+// permutes the group's state in place; every lane of the workgroup must call it (barriers inside)
+__device__ __forceinline__ u64 pgl_coop_permute(u64 s, u32 g, u64 *grp) {
+    const u32 gg = g < 12 ? g : 0;
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) s = pgl_coop_mds(pgl_sbox_l(gl_add_lc(s, PGL_RC[12 * r + gg])), g, grp);
+    s = gl_add_lc(s, PGL_FP_FIRST[gg]);
+#pragma unroll 1
+    for (int r = 0; r < 22; r++) {
+        u64 t = pgl_sbox_l(s);
+        if (r < 21) t = gl_add_lc(t, PGL_FP_RC[r]);
+        s = pgl_coop_mds(g == 0 ? t : s, g, grp);
+    }
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) s = pgl_coop_mds(pgl_sbox_l(gl_add_lc(s, PGL_RC[12 * (26 + r) + gg])), g, grp);
+    return gl_canonical(s);
+}
+// parents[i] = two_to_one(children[2i], children[2i+1]), one 16-lane group per parent
+__global__ void __launch_bounds__(256)
+gl_merkle_level_coop_kernel(const u64 *__restrict__ children, u64 *__restrict__ parents, u32 n_parents) {
+    __shared__ u64 sh[PGL_COOP_GROUPS][12];
+    const u32 g = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    u32 node = blockIdx.x * PGL_COOP_GROUPS + grp;
+    const bool live = node < n_parents;
+    if (!live) node = n_parents - 1;
+    u64 s = g < 8 ? children[(size_t)node * 8 + g] : 0;
+    s = pgl_coop_permute(s, g, sh[grp]);
+    if (live && g < 4) parents[(size_t)node * 4 + g] = s;
+}
+// leaf digests (hash_or_noop of `width` elements), one 16-lane group per leaf; same addressing as gl_hash_leaves_kernel
+__global__ void __launch_bounds__(256)
+gl_hash_leaves_coop_kernel(const u64 *__restrict__ mat, size_t stride, size_t leaf_stride, u32 width, u32 n_leaves,
+                           u64 *__restrict__ digests) {
+    __shared__ u64 sh[PGL_COOP_GROUPS][12];
+    const u32 g = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    u32 leaf = blockIdx.x * PGL_COOP_GROUPS + grp;
+    const bool live = leaf < n_leaves;
+    if (!live) leaf = n_leaves - 1;
+    const u64 *in = mat + (size_t)leaf * leaf_stride;
+    u64 s = 0;
+    if (width <= 4) {
+        if (g < width) s = in[(size_t)g * stride];
+    } else {
+#pragma unroll 1
+        for (u32 off = 0; off < width; off += 8) {
+            if (g < 8 && off + g < width) s = in[(size_t)(off + g) * stride];
+            s = pgl_coop_permute(s, g, sh[grp]);
+        }
+    }
+    if (live && g < 4) digests[(size_t)leaf * 4 + g] = s;
+}
+#define PGL_COOP_MAX_NODES (1u << 14)   // above this the lane-per-permutation kernels fill the chip and are cheaper per permutation
+
 // ---------------------------------------------------------------- host side
 static u64 host_gl_mul(u64 a, u64 b) {
     unsigned __int128 x = (unsigned __int128)a * b;
@@ -492,14 +574,23 @@ int32_t zklc_gl_merkle_commit_strided(zklc_ctx *ctx, hipStream_t st, const uint6
                                       uint32_t log_leaves, uint32_t width, uint32_t cap_height, uint64_t *d_tree) {
     ZKLC_HIP(ctx, hipSetDevice(ctx->device));
     u32 n = 1u << log_leaves;
-    hipLaunchKernelGGL(gl_hash_leaves_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_mat, (size_t)stride, (size_t)leaf_stride,
-                       width, n, d_tree);
+    static const bool coop = !getenv("ZKLC_NO_COOP_POSEIDON");
+    if (coop && n <= PGL_COOP_MAX_NODES)
+        hipLaunchKernelGGL(gl_hash_leaves_coop_kernel, dim3((n + PGL_COOP_GROUPS - 1) / PGL_COOP_GROUPS), dim3(256), 0, st, d_mat,
+                           (size_t)stride, (size_t)leaf_stride, width, n, d_tree);
+    else
+        hipLaunchKernelGGL(gl_hash_leaves_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_mat, (size_t)stride, (size_t)leaf_stride,
+                           width, n, d_tree);
     ZKLC_HIP(ctx, hipGetLastError());
     u64 *level = d_tree;
     for (u32 l = 0; l < log_leaves - cap_height; l++) {
         u32 parents = n >> (l + 1);
         u64 *next = level + (4ULL << (log_leaves - l));
-        hipLaunchKernelGGL(gl_merkle_level_kernel, dim3((parents + 255) / 256), dim3(256), 0, st, (const u64 *)level, next, parents);
+        if (coop && parents <= PGL_COOP_MAX_NODES)
+            hipLaunchKernelGGL(gl_merkle_level_coop_kernel, dim3((parents + PGL_COOP_GROUPS - 1) / PGL_COOP_GROUPS), dim3(256), 0, st,
+                               (const u64 *)level, next, parents);
+        else
+            hipLaunchKernelGGL(gl_merkle_level_kernel, dim3((parents + 255) / 256), dim3(256), 0, st, (const u64 *)level, next, parents);
         ZKLC_HIP(ctx, hipGetLastError());
         level = next;
     }
