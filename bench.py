@@ -438,7 +438,9 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     fills = [E.fill_ecdsa_targets(ed_targets, c2_msg, sg, pk_) for sg, pk_ in present]
     workers = [(ctx, ed_prover)] + [(c_, ed_data.prover(c_, HASH_GL)) for c_ in
                                     (zklc_amd.Context(torch.cuda.current_device()) for _ in range(nthreads - 2))]
-    wchunk = max(1, min(12, host_cores() // max(1, world) - nthreads))   # host threads of this rank's witness producer
+    # host threads of this rank's witness producer; two pinned buffers of wchunk x 490 MB each: smaller chunks when several ranks
+    # share the host
+    wchunk = max(1, min(12 if world == 1 else 6, host_cores() // max(1, world) - nthreads))
     nbuf = 2
     nw_, n_rows = ed_data.config["num_wires"], ed_data.n
     pinned = [torch.zeros((wchunk, nw_, n_rows), dtype=torch.int64).pin_memory() for _ in range(nbuf)]
