@@ -144,7 +144,9 @@ enum zklc_plonky2_gate_type {
     ZKLC_GATE_COSET_INTERPOLATION /* p0 = subgroup_bits, p1 = degree; extra = weights then subgroup points */,
     ZKLC_GATE_U32_ARITHMETIC /* p0 = num_ops */, ZKLC_GATE_U32_ADD_MANY /* p0 = num_addends, p1 = num_ops */,
     ZKLC_GATE_U32_SUBTRACTION /* p0 = num_ops */, ZKLC_GATE_U32_RANGE_CHECK /* p0 = num_input_limbs */,
-    ZKLC_GATE_COMPARISON /* p0 = num_bits, p1 = num_chunks */
+    ZKLC_GATE_COMPARISON /* p0 = num_bits, p1 = num_chunks */,
+    /* crypto/plonky2_u32/src/gates/{interleave_u32,uninterleave_to_u32,uninterleave_to_b32}.rs (SHA-256 circuits); p0 = num_ops */
+    ZKLC_GATE_U32_INTERLEAVE, ZKLC_GATE_UNINTERLEAVE_TO_U32, ZKLC_GATE_UNINTERLEAVE_TO_B32
 };
 typedef struct {
     uint32_t type;            /* zklc_plonky2_gate_type */

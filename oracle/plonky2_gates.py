@@ -13,6 +13,7 @@ and the in-tree custom gates of the Ed25519/SHA circuits:
   crypto/plonky2_u32/src/gates/subtraction_u32.rs           U32SubtractionGate
   crypto/plonky2_u32/src/gates/range_check_u32.rs           U32RangeCheckGate
   crypto/plonky2_u32/src/gates/comparison.rs                ComparisonGate
+  crypto/plonky2_u32/src/gates/{interleave_u32,uninterleave_to_u32,uninterleave_to_b32}.rs  (SHA-256 circuits)
 and the vanishing-polynomial combination of plonk/plonk.go:60-250.
 
 Every evaluator is written once over a field adapter K (BaseK = Goldilocks integers, used by the prover
@@ -544,6 +545,52 @@ class ComparisonGate(Gate):
         return out
 
 
+class U32InterleaveGate(Gate):
+    """interleave_u32.rs:103-139 `eval_unfiltered`"""
+    degree = 2
+
+    def __init__(self, num_ops):
+        self.n = num_ops
+        self.num_constraints = num_ops * 34
+
+    def eval(self, K, c, w, pih):
+        out = []
+        for i in range(self.n):
+            bits = [w[2 * self.n + 32 * i + j] for j in range(32)]           # big-endian
+            out.append(K.sub(reduce_with_powers(K, bits[::-1], K.const(2)), w[2 * i]))
+            out.append(K.sub(reduce_with_powers(K, bits[::-1], K.const(4)), w[2 * i + 1]))
+            out.extend(_range_product(K, b, 2) for b in bits)
+        return out
+
+
+class UninterleaveToU32Gate(Gate):
+    """uninterleave_to_u32.rs:112-159 `eval_unfiltered`; with to_b32 the weights are 4^(31-j) (uninterleave_to_b32.rs)"""
+    degree, to_b32 = 2, False
+
+    def __init__(self, num_ops):
+        self.n = num_ops
+        self.num_constraints = num_ops * 67
+
+    def eval(self, K, c, w, pih):
+        out = []
+        for i in range(self.n):
+            bits = [w[3 * self.n + 64 * i + j] for j in range(64)]
+            out.append(K.sub(reduce_with_powers(K, bits[::-1], K.const(2)), w[3 * i]))
+            ev, od = K.zero, K.zero
+            for j in range(32):
+                coeff = K.const(1 << (2 * (31 - j)) if self.to_b32 else 1 << (31 - j))
+                ev = K.add(ev, K.mul(coeff, bits[2 * j]))
+                od = K.add(od, K.mul(coeff, bits[2 * j + 1]))
+            out.append(K.sub(ev, w[3 * i + 1]))
+            out.append(K.sub(od, w[3 * i + 2]))
+            out.extend(_range_product(K, b, 2) for b in bits)
+        return out
+
+
+class UninterleaveToB32Gate(UninterleaveToU32Gate):
+    to_b32 = True
+
+
 GATE_PATTERNS = [
     (re.compile(r"^NoopGate"), lambda m: NoopGate()),
     (re.compile(r"^ConstantGate \{ num_consts: (\d+) \}"), lambda m: ConstantGate(int(m[1]))),
@@ -566,6 +613,9 @@ GATE_PATTERNS = [
     (re.compile(r"^U32SubtractionGate \{ num_ops: (\d+)"), lambda m: U32SubtractionGate(int(m[1]))),
     (re.compile(r"^U32RangeCheckGate \{ num_input_limbs: (\d+)"), lambda m: U32RangeCheckGate(int(m[1]))),
     (re.compile(r"^ComparisonGate \{ num_bits: (\d+), num_chunks: (\d+)"), lambda m: ComparisonGate(int(m[1]), int(m[2]))),
+    (re.compile(r"^U32InterleaveGate \{ num_ops: (\d+)"), lambda m: U32InterleaveGate(int(m[1]))),
+    (re.compile(r"^UninterleaveToU32Gate \{ num_ops: (\d+)"), lambda m: UninterleaveToU32Gate(int(m[1]))),
+    (re.compile(r"^UninterleaveToB32Gate \{ num_ops: (\d+)"), lambda m: UninterleaveToB32Gate(int(m[1]))),
 ]
 
 

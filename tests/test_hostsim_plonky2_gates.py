@@ -20,7 +20,7 @@ GATES = [
     G.RandomAccessGate(1, 20, 0), G.ReducingGate(43), G.ReducingExtensionGate(32), G.ExponentiationGate(66),
     G.CosetInterpolationGate(4, 6, SY.barycentric_weights(4)), G.CosetInterpolationGate(3, 3, SY.barycentric_weights(3)),
     G.U32ArithmeticGate(6), G.U32AddManyGate(3, 9), G.U32AddManyGate(11, 5), G.U32SubtractionGate(11), G.U32RangeCheckGate(8),
-    G.ComparisonGate(32, 16), G.ComparisonGate(10, 5),
+    G.ComparisonGate(32, 16), G.ComparisonGate(10, 5), G.U32InterleaveGate(3), G.UninterleaveToU32Gate(2), G.UninterleaveToB32Gate(2),
 ]
 
 

@@ -23,7 +23,8 @@
 enum p2_gate_type {
     P2_NOOP = 0, P2_CONSTANT, P2_PUBLIC_INPUT, P2_ARITHMETIC, P2_ARITHMETIC_EXT, P2_MUL_EXT, P2_BASE_SUM, P2_POSEIDON,
     P2_POSEIDON_MDS, P2_RANDOM_ACCESS, P2_REDUCING, P2_REDUCING_EXT, P2_EXPONENTIATION, P2_COSET_INTERPOLATION,
-    P2_U32_ARITHMETIC, P2_U32_ADD_MANY, P2_U32_SUBTRACTION, P2_U32_RANGE_CHECK, P2_COMPARISON, P2_NUM_GATE_TYPES
+    P2_U32_ARITHMETIC, P2_U32_ADD_MANY, P2_U32_SUBTRACTION, P2_U32_RANGE_CHECK, P2_COMPARISON,
+    P2_U32_INTERLEAVE, P2_UNINTERLEAVE_TO_U32, P2_UNINTERLEAVE_TO_B32, P2_NUM_GATE_TYPES
 };
 
 // mirrors zklc_plonky2_gate of include/zklc.h
@@ -433,6 +434,44 @@ ZKLC_D void p2_eval_comparison(const p2_vars &v, u32 num_bits, u32 num_chunks, p
     out.emit(gl_sub(v.w(2), v.w(4 + 5 * num_chunks + chunk_bits)));
 }
 
+// interleave_u32.rs:103-139: per op (x, x_interleaved) routed, then 32 big-endian bits; x = sum bits 2^(31-j),
+// x_interleaved = sum bits 4^(31-j) (the bits of x spread over the even positions of a 64-bit word)
+ZKLC_D void p2_eval_u32_interleave(const p2_vars &v, u32 num_ops, p2_consumer &out) {
+    for (u32 i = 0; i < num_ops; i++) {
+        u64 x = 0, xi = 0;
+        for (u32 j = 0; j < 32; j++) {
+            u64 b = v.w(2 * num_ops + 32 * i + j);
+            x = gl_add(gl_add(x, x), b);
+            xi = p2_horner4(xi, b);
+        }
+        out.emit(gl_sub(x, v.w(2 * i)));
+        out.emit(gl_sub(gl_canonical(xi), v.w(2 * i + 1)));
+        for (u32 j = 0; j < 32; j++) out.emit(p2_range_product(v.w(2 * num_ops + 32 * i + j), 2));
+    }
+}
+// uninterleave_to_u32.rs:112-159 / uninterleave_to_b32.rs: per op (x_interleaved, evens, odds) routed, then 64 big-endian bits;
+// evens / odds collect bits 2j / 2j+1 with weights 2^(31-j) (to_u32) or 4^(31-j) (to_b32: the halves stay interleaved)
+ZKLC_D void p2_eval_uninterleave(const p2_vars &v, u32 num_ops, bool to_b32, p2_consumer &out) {
+    for (u32 i = 0; i < num_ops; i++) {
+        u64 x = 0, ev = 0, od = 0;
+        for (u32 j = 0; j < 32; j++) {
+            u64 be = v.w(3 * num_ops + 64 * i + 2 * j), bo = v.w(3 * num_ops + 64 * i + 2 * j + 1);
+            x = gl_add(gl_add(gl_add(x, x), be), gl_add(gl_add(gl_add(x, x), be), bo));   // x = 4x + 2 be + bo
+            if (to_b32) {
+                ev = p2_horner4(ev, be);
+                od = p2_horner4(od, bo);
+            } else {
+                ev = gl_add(gl_add(ev, ev), be);
+                od = gl_add(gl_add(od, od), bo);
+            }
+        }
+        out.emit(gl_sub(x, v.w(3 * i)));
+        out.emit(gl_sub(gl_canonical(ev), v.w(3 * i + 1)));
+        out.emit(gl_sub(gl_canonical(od), v.w(3 * i + 2)));
+        for (u32 j = 0; j < 64; j++) out.emit(p2_range_product(v.w(3 * num_ops + 64 * i + j), 2));
+    }
+}
+
 ZKLC_D void p2_eval_gate(const p2_gate &g, const p2_vars &v, const u64 *extra, p2_consumer &out) {
     switch (g.type) {
         case P2_NOOP: break;
@@ -454,6 +493,9 @@ ZKLC_D void p2_eval_gate(const p2_gate &g, const p2_vars &v, const u64 *extra, p
         case P2_U32_SUBTRACTION: p2_eval_u32_subtraction(v, g.p[0], out); break;
         case P2_U32_RANGE_CHECK: p2_eval_u32_range_check(v, g.p[0], out); break;
         case P2_COMPARISON: p2_eval_comparison(v, g.p[0], g.p[1], out); break;
+        case P2_U32_INTERLEAVE: p2_eval_u32_interleave(v, g.p[0], out); break;
+        case P2_UNINTERLEAVE_TO_U32: p2_eval_uninterleave(v, g.p[0], false, out); break;
+        case P2_UNINTERLEAVE_TO_B32: p2_eval_uninterleave(v, g.p[0], true, out); break;
         default: break;
     }
 }

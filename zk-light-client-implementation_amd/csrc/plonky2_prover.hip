@@ -246,6 +246,7 @@ static p2_gate_kernel_fn p2_gate_kernel_of(u32 type) {
         P2_CASE(P2_BASE_SUM) P2_CASE(P2_POSEIDON) P2_CASE(P2_POSEIDON_MDS) P2_CASE(P2_RANDOM_ACCESS) P2_CASE(P2_REDUCING)
         P2_CASE(P2_REDUCING_EXT) P2_CASE(P2_EXPONENTIATION) P2_CASE(P2_COSET_INTERPOLATION) P2_CASE(P2_U32_ARITHMETIC)
         P2_CASE(P2_U32_ADD_MANY) P2_CASE(P2_U32_SUBTRACTION) P2_CASE(P2_U32_RANGE_CHECK) P2_CASE(P2_COMPARISON)
+        P2_CASE(P2_U32_INTERLEAVE) P2_CASE(P2_UNINTERLEAVE_TO_U32) P2_CASE(P2_UNINTERLEAVE_TO_B32)
 #undef P2_CASE
         default: return nullptr;   // P2_NOOP: no constraints
     }

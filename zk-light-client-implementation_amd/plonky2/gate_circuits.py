@@ -400,4 +400,22 @@ def eval_gate_circuit(K, g, c, w, pih):
         return out
     if code == G.COMPARISON:
         return _eval_comparison(K, g, w)
+    if code == G.U32_INTERLEAVE:
+        out, n = [], g.num_ops
+        for i in range(n):
+            bits = [w[2 * n + 32 * i + j] for j in range(32)]
+            out.append(K.sub(_reduce_with_powers(K, bits[::-1], 2), w[2 * i]))
+            out.append(K.sub(_reduce_with_powers(K, bits[::-1], 4), w[2 * i + 1]))
+            out.extend(_range_product(K, b_, 2) for b_ in bits)
+        return out
+    if code in (G.UNINTERLEAVE_TO_U32, G.UNINTERLEAVE_TO_B32):
+        out, n = [], g.num_ops
+        base = 4 if code == G.UNINTERLEAVE_TO_B32 else 2
+        for i in range(n):
+            bits = [w[3 * n + 64 * i + j] for j in range(64)]
+            out.append(K.sub(_reduce_with_powers(K, bits[::-1], 2), w[3 * i]))
+            out.append(K.sub(_reduce_with_powers(K, bits[0::2][::-1], base), w[3 * i + 1]))
+            out.append(K.sub(_reduce_with_powers(K, bits[1::2][::-1], base), w[3 * i + 2]))
+            out.extend(_range_product(K, b_, 2) for b_ in bits)
+        return out
     raise ValueError("no in-circuit evaluator for " + g.id())

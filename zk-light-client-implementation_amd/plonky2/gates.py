@@ -15,7 +15,7 @@ import re
 # type codes shared with csrc/plonky2_gates.cuh
 NOOP, CONSTANT, PUBLIC_INPUT, ARITHMETIC, ARITHMETIC_EXT, MUL_EXT, BASE_SUM, POSEIDON, POSEIDON_MDS, RANDOM_ACCESS, \
     REDUCING, REDUCING_EXT, EXPONENTIATION, COSET_INTERPOLATION, U32_ARITHMETIC, U32_ADD_MANY, U32_SUBTRACTION, \
-    U32_RANGE_CHECK, COMPARISON = range(19)
+    U32_RANGE_CHECK, COMPARISON, U32_INTERLEAVE, UNINTERLEAVE_TO_U32, UNINTERLEAVE_TO_B32 = range(22)
 
 _PH = "PhantomData<plonky2_field::goldilocks_field::GoldilocksField>"
 
@@ -316,6 +316,47 @@ class ComparisonGate(Gate):
         return "ComparisonGate { num_bits: %d, num_chunks: %d, _phantom: %s }<D=2>" % (self.num_bits, self.num_chunks, _PH)
 
 
+class U32InterleaveGate(Gate):
+    """crypto/plonky2_u32/src/gates/interleave_u32.rs:37-95: per op (x, x_interleaved) routed, then 32 big-endian bits per op"""
+    code, degree = U32_INTERLEAVE, 2
+
+    def __init__(self, num_ops):
+        self.num_ops = num_ops
+        self.num_constraints = num_ops * 34
+        self.num_wires = num_ops * 34
+        self.params = (num_ops, 0, 0, 0)
+
+    @staticmethod
+    def new_from_config(cfg):
+        return U32InterleaveGate(min(cfg["num_wires"] // 34, cfg["num_routed_wires"] // 2))
+
+    def id(self):
+        return "U32InterleaveGate { num_ops: %d }" % self.num_ops
+
+
+class UninterleaveToU32Gate(Gate):
+    """uninterleave_to_u32.rs:32-94: per op (x_interleaved, evens, odds) routed, then 64 big-endian bits per op"""
+    code, degree, NAME = UNINTERLEAVE_TO_U32, 2, "UninterleaveToU32Gate"
+
+    def __init__(self, num_ops):
+        self.num_ops = num_ops
+        self.num_constraints = num_ops * 67
+        self.num_wires = num_ops * 67
+        self.params = (num_ops, 0, 0, 0)
+
+    @classmethod
+    def new_from_config(cls, cfg):
+        return cls(min(cfg["num_wires"] // 67, cfg["num_routed_wires"] // 3))
+
+    def id(self):
+        return "%s { num_ops: %d }" % (self.NAME, self.num_ops)
+
+
+class UninterleaveToB32Gate(UninterleaveToU32Gate):
+    """uninterleave_to_b32.rs: same layout, the two halves stay in interleaved (base-4) form"""
+    code, NAME = UNINTERLEAVE_TO_B32, "UninterleaveToB32Gate"
+
+
 _PATTERNS = [
     (r"^NoopGate", lambda m: NoopGate()),
     (r"^ConstantGate \{ num_consts: (\d+) \}", lambda m: ConstantGate(int(m[1]))),
@@ -338,6 +379,9 @@ _PATTERNS = [
     (r"^U32SubtractionGate \{ num_ops: (\d+)", lambda m: U32SubtractionGate(int(m[1]))),
     (r"^U32RangeCheckGate \{ num_input_limbs: (\d+)", lambda m: U32RangeCheckGate(int(m[1]))),
     (r"^ComparisonGate \{ num_bits: (\d+), num_chunks: (\d+)", lambda m: ComparisonGate(int(m[1]), int(m[2]))),
+    (r"^U32InterleaveGate \{ num_ops: (\d+)", lambda m: U32InterleaveGate(int(m[1]))),
+    (r"^UninterleaveToU32Gate \{ num_ops: (\d+)", lambda m: UninterleaveToU32Gate(int(m[1]))),
+    (r"^UninterleaveToB32Gate \{ num_ops: (\d+)", lambda m: UninterleaveToB32Gate(int(m[1]))),
 ]
 
 
