@@ -247,7 +247,9 @@ enum {
     OP_CONST = 0, OP_ARITH, OP_SPLIT, OP_LE_SUM, OP_U32_MULADD, OP_ADD_MANY, OP_SUB_U32, OP_RANGE_CHECK, OP_COMPARISON, OP_IS_EQUAL,
     OP_RANDOM_ACCESS, OP_NN_ADD, OP_NN_SUB, OP_NN_MUL, OP_NN_INV, OP_DIV_REM, OP_DECOMPRESS, OP_POSEIDON,
     // gadgets of the in-circuit verifier (plonky2/recursion.py)
-    OP_EXT_ARITH, OP_EXT_MUL, OP_EXT_INV, OP_EXPONENTIATION, OP_COSET_INTERP, OP_POSEIDON_MDS, OP_REDUCING, OP_REDUCING_EXT
+    OP_EXT_ARITH, OP_EXT_MUL, OP_EXT_INV, OP_EXPONENTIATION, OP_COSET_INTERP, OP_POSEIDON_MDS, OP_REDUCING, OP_REDUCING_EXT,
+    // crypto/plonky2_u32/src/gates/{interleave_u32,uninterleave_to_u32,uninterleave_to_b32}.rs generators
+    OP_INTERLEAVE, OP_UNINTERLEAVE
 };
 
 // quadratic extension GF(p)[X]/(X^2 - 7)
@@ -616,6 +618,26 @@ struct Runner {
                         out.push_back(acc.a);
                         out.push_back(acc.b);
                     }
+                    break;
+                }
+                case OP_INTERLEAVE: {   // in x (u32); out: x with its bits spread to the even positions, then 32 big-endian bits
+                    if (in[0] >> 32) return fail("interleave: value exceeds 32 bits", pc);
+                    u64 xi = 0;
+                    for (int j = 0; j < 32; j++) xi |= ((in[0] >> j) & 1) << (2 * j);
+                    out.push_back(xi);
+                    for (int j = 0; j < 32; j++) out.push_back((in[0] >> (31 - j)) & 1);
+                    break;
+                }
+                case OP_UNINTERLEAVE: {   // param to_b32; in x; out: evens, odds, 64 big-endian bits
+                    const u32 step = pr[0] ? 2 : 1;
+                    u64 ev = 0, od = 0;
+                    for (int j = 0; j < 32; j++) {
+                        ev |= ((in[0] >> (2 * j + 1)) & 1) << (step * j);
+                        od |= ((in[0] >> (2 * j)) & 1) << (step * j);
+                    }
+                    out.push_back(ev);
+                    out.push_back(od);
+                    for (int j = 0; j < 64; j++) out.push_back((in[0] >> (63 - j)) & 1);
                     break;
                 }
                 default: return fail("unknown opcode", pc);

@@ -22,6 +22,7 @@ P = 2**64 - 2**32 + 1
 # instruction set of the native witness interpreter (csrc/plonky2_witness.cpp)
 OP_CONST, OP_ARITH, OP_SPLIT, OP_LE_SUM, OP_U32_MULADD, OP_ADD_MANY, OP_SUB_U32, OP_RANGE_CHECK, OP_COMPARISON, OP_IS_EQUAL, \
     OP_RANDOM_ACCESS, OP_NN_ADD, OP_NN_SUB, OP_NN_MUL, OP_NN_INV, OP_DIV_REM, OP_DECOMPRESS, OP_POSEIDON = range(18)
+OP_INTERLEAVE, OP_UNINTERLEAVE = 26, 27      # 18..25: the recursion gadgets (recursion.py)
 UNUSED_SELECTOR = (1 << 32) - 1
 GENERATOR = 7
 POWER_OF_TWO_GENERATOR = 1753635133440165772
@@ -104,6 +105,7 @@ class CircuitBuilder:
         self._addmany_slot = {}
         self._target_const = {}
         self._sub_slot = None
+        self._il_slot, self._ul_slot = None, {}
 
     # ---- targets / copy constraints
     def add_virtual_target(self):
@@ -473,6 +475,116 @@ class CircuitBuilder:
             return res
         self.add_generator(w[:3], gen, OP_U32_MULADD, outs=[w[3], w[4], w[5]] + limbs)
         return w[3], w[4]
+
+    # ---- interleaved ("B32") representation: crypto/plonky2_u32/src/gadgets/interleaved_u32.rs
+    def interleave_u32(self, x):
+        """:75-83 -- the bits of x spread over the even positions of a 64-bit word (U32InterleaveGate)"""
+        gate = G.U32InterleaveGate.new_from_config(self.config)
+        if self._il_slot is None or self._il_slot[1] == gate.num_ops:
+            self._il_slot = [self.add_gate(gate), 0]
+        row, i = self._il_slot
+        self._il_slot[1] += 1
+        wx, wi = Target(row, 2 * i), Target(row, 2 * i + 1)
+        self.connect(wx, x)
+        bits = [Target(row, 2 * gate.num_ops + 32 * i + j) for j in range(32)]
+
+        def gen(v, wi=wi, bits=bits):
+            xv = v[0]
+            assert xv < (1 << 32), "interleave_u32: value exceeds 32 bits"
+            bv = [(xv >> (31 - j)) & 1 for j in range(32)]                  # big-endian
+            return [(wi, sum(b << (2 * (31 - j)) for j, b in enumerate(bv)))] + list(zip(bits, bv))
+        self.add_generator([wx], gen, OP_INTERLEAVE, outs=[wi] + bits)
+        return wi
+
+    def _uninterleave(self, x, to_b32):
+        cls = G.UninterleaveToB32Gate if to_b32 else G.UninterleaveToU32Gate
+        gate = cls.new_from_config(self.config)
+        slot = self._ul_slot.get(to_b32)
+        if slot is None or slot[1] == gate.num_ops:
+            slot = self._ul_slot[to_b32] = [self.add_gate(gate), 0]
+        row, i = slot
+        slot[1] += 1
+        wx, we, wo = (Target(row, 3 * i + k) for k in range(3))
+        self.connect(wx, x)
+        bits = [Target(row, 3 * gate.num_ops + 64 * i + j) for j in range(64)]
+
+        def gen(v, we=we, wo=wo, bits=bits, to_b32=to_b32):
+            bv = [(v[0] >> (63 - j)) & 1 for j in range(64)]               # big-endian
+            step = 2 if to_b32 else 1
+            ev = sum(bv[2 * j] << (step * (31 - j)) for j in range(32))
+            od = sum(bv[2 * j + 1] << (step * (31 - j)) for j in range(32))
+            return [(we, ev), (wo, od)] + list(zip(bits, bv))
+        self.add_generator([wx], gen, OP_UNINTERLEAVE, (1 if to_b32 else 0,), outs=[we, wo] + bits)
+        return we, wo
+
+    def uninterleave_to_u32(self, x):
+        """:85-99 -- (bits at the even positions, bits at the odd positions) of a 64-bit word as two u32"""
+        return self._uninterleave(x, False)
+
+    def uninterleave_to_b32(self, x):
+        """:101-115 -- the same halves, left in interleaved form"""
+        return self._uninterleave(x, True)
+
+    def and_xor_b32(self, x, y):
+        """:145-148: the sum of two interleaved words has (a AND b) at the even and (a XOR b) at the odd positions"""
+        return self.uninterleave_to_b32(self.add(x, y))
+
+    def and_xor_u32(self, x, y):
+        return self.and_xor_b32(self.interleave_u32(x), self.interleave_u32(y))
+
+    def and_xor_b32_to_u32(self, x, y):
+        return self.uninterleave_to_u32(self.add(x, y))
+
+    def and_xor_u32_to_u32(self, x, y):
+        return self.and_xor_b32_to_u32(self.interleave_u32(x), self.interleave_u32(y))
+
+    def and_u32(self, x, y):
+        return self.and_xor_u32_to_u32(x, y)[0]
+
+    def xor_u32(self, x, y):
+        return self.and_xor_u32_to_u32(x, y)[1]
+
+    def unsafe_xor_many_u32(self, xs):
+        """:117-143"""
+        xs = list(xs)
+        if len(xs) == 0:
+            return self.zero()
+        if len(xs) == 1:
+            return xs[0]
+        if len(xs) <= 3:
+            t = self.xor_u32(xs[0], xs[1])
+            return t if len(xs) == 2 else self.xor_u32(t, xs[2])
+        r = self.interleave_u32(xs[0])
+        for i in range((len(xs) - 3) // 2):
+            a, c = self.interleave_u32(xs[1 + 2 * i]), self.interleave_u32(xs[2 + 2 * i])
+            r = self.uninterleave_to_b32(self.add(self.add(r, a), c))[1]
+        if len(xs) % 2 == 0:
+            r = self.and_xor_b32(r, self.interleave_u32(xs[-3]))[1]
+        a, c = self.interleave_u32(xs[-2]), self.interleave_u32(xs[-1])
+        return self.uninterleave_to_u32(self.add(self.add(r, a), c))[1]
+
+    def mul_u32(self, a, b):
+        return self.mul_add_u32(a, b, self.zero())
+
+    def add_u32(self, a, b):
+        """arithmetic_u32.rs:139-142"""
+        return self.mul_add_u32(a, self.one(), b)
+
+    def not_u32(self, a):
+        return self.sub_u32(self.constant(0xFFFFFFFF), a, self.zero())[0]
+
+    def lsh_u32(self, a, n):
+        return self.mul_u32(a, self.constant(1 << n))[0]
+
+    def rsh_u32(self, a, n):
+        return a if n == 0 else self.mul_u32(a, self.constant(1 << (32 - n)))[1]
+
+    def lrot_u32(self, a, n):
+        lo, hi = self.mul_u32(a, self.constant(1 << n))
+        return self.add_u32(lo, hi)[0]
+
+    def rrot_u32(self, a, n):
+        return self.lrot_u32(a, 32 - n)
 
     # ---- Poseidon (PoseidonGate rows); witness rows come from the library (zklc_poseidon_gl_gate_rows)
     def permute(self, state12, swap=None):
