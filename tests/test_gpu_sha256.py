@@ -42,3 +42,31 @@ def test_sha256_proofs_and_their_recursion(zctx):
         rp.recursive_proof(proofs[0], (proofs[1][0], proofs[1][1], bad), pis)
     rp.close()
     sp.close()
+
+
+def test_prove_header_hash_and_bp_hash(zctx):
+    """header_bphash.rs:34-139 and its tests :153-221: block hash = sha256(sha256(sha256(inner_lite) || sha256(inner_rest)) ||
+    prev_hash) proven as three SHA-256 proofs chained by recursion; bp_hash = sha256 of the borsh validator list (fixture C1)"""
+    from conftest import load_golden, near_set_arrays
+    from zklc_amd.header_bphash import BlockHashProver
+    pgl.use_c_port()
+    bp = BlockHashProver(zctx)
+    prev_hash = hashlib.sha256(b"prev").digest()
+    inner_lite = bytes((5 * i + 1) & 0xFF for i in range(208))          # INNER_LITE_BYTES (types.rs:19)
+    inner_rest = bytes((3 * i + 2) & 0xFF for i in range(330))
+    inner = hashlib.sha256(hashlib.sha256(inner_lite).digest() + hashlib.sha256(inner_rest).digest()).digest()
+    header_hash = hashlib.sha256(inner + prev_hash).digest()
+    common, vd, proof = bp.prove_header_hash(header_hash, prev_hash, inner_lite, inner_rest)
+    V.verify(json.loads(json.dumps(proof)), vd, common)
+    assert proof["public_inputs"] == [int.from_bytes(header_hash[4 * i:4 * i + 4], "big") for i in range(8)]
+    with pytest.raises(AssertionError):
+        bp.prove_header_hash(hashlib.sha256(b"not the hash").digest(), prev_hash, inner_lite, inner_rest)
+    # optional extra recursion that sets caller-chosen public inputs (:97-109)
+    common, vd, proof = bp.prove_header_hash(header_hash, prev_hash, inner_lite, inner_rest, public_inputs=[1, 2, 3])
+    V.verify(json.loads(json.dumps(proof)), vd, common)
+    assert proof["public_inputs"] == [1, 2, 3]
+    _, _, validators = near_set_arrays(load_golden("ed25519_near_c1_small.json"))
+    data = len(validators).to_bytes(4, "little") + b"".join(validators)
+    common, vd, proof = bp.prove_bp_hash(hashlib.sha256(data).digest(), validators)
+    V.verify(json.loads(json.dumps(proof)), vd, common)
+    bp.close()

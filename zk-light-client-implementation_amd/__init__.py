@@ -15,3 +15,4 @@ from ._lib import ZklcError, load, LIB_PATH, declared_symbols  # noqa: F401
 from .context import Context  # noqa: F401
 from . import signatures  # noqa: F401
 from . import distributed  # noqa: F401
+from . import header_bphash  # noqa: F401
