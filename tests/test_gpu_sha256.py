@@ -70,3 +70,21 @@ def test_prove_header_hash_and_bp_hash(zctx):
     common, vd, proof = bp.prove_bp_hash(hashlib.sha256(data).digest(), validators)
     V.verify(json.loads(json.dumps(proof)), vd, common)
     bp.close()
+
+
+def test_prove_valid_keys_stakes_on_the_small_fixture(zctx):
+    """keys_stakes.rs:282-343: the keys / stakes circuit proof, the SHA-256 proof of valid_keys and their recursion on fixture C1"""
+    from conftest import load_golden, near_set_arrays
+    from zklc_amd.keys_stakes import KeysStakesProver
+    pgl.use_c_port()
+    msg, approvals, validators = near_set_arrays(load_golden("ed25519_near_c1_small.json"))
+    valid_keys = b"".join(bytes([pos]) + v[-48:-16] for pos, (a, v) in enumerate(zip(approvals, validators)) if len(a) == 66)
+    kp = KeysStakesProver(zctx)
+    common, vd, proof = kp.prove_valid_keys_stakes_in_validators_list(valid_keys, hashlib.sha256(valid_keys).digest(), validators)
+    V.verify(json.loads(json.dumps(proof)), vd, common)
+    assert bytes(proof["public_inputs"][:len(valid_keys)]) == valid_keys
+    stake = sum(int.from_bytes(v[-16:], "little") for a, v in zip(approvals, validators) if len(a) == 66)
+    assert int.from_bytes(bytes(proof["public_inputs"][len(valid_keys):]), "little") == stake
+    with pytest.raises(AssertionError):
+        kp.prove_valid_keys_stakes_in_validators_list(valid_keys, hashlib.sha256(b"x").digest(), validators)
+    kp.close()

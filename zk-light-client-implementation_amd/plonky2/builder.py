@@ -208,6 +208,19 @@ class CircuitBuilder:
     def mul_add(self, a, b, c):
         return self.arithmetic(1, a, b, 1, c)
 
+    def mul_sub(self, a, b, c):
+        return self.arithmetic(1, a, b, P - 1, c)
+
+    def select(self, b, x, y):
+        """plonky2 `select`: b ? x : y as b*x - (b*y - y)"""
+        return self.mul_sub(b, x, self.mul_sub(b, y, y))
+
+    def neg_one(self):
+        return self.constant(P - 1)
+
+    def two(self):
+        return self.constant(2)
+
     def mul_const(self, c, a):
         return self.arithmetic(c, a, self.one(), 0, self.zero())
 
