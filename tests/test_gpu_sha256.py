@@ -88,3 +88,30 @@ def test_prove_valid_keys_stakes_on_the_small_fixture(zctx):
     with pytest.raises(AssertionError):
         kp.prove_valid_keys_stakes_in_validators_list(valid_keys, hashlib.sha256(b"x").digest(), validators)
     kp.close()
+
+
+def test_primitive_proofs_and_the_reference_recursion_test(zctx):
+    """primitives.rs tests :336-456 and recursion.rs:100-125 (`two_thirds` proof folded by `recursive_proof`)"""
+    from zklc_amd.primitives import PrimitiveProver
+    pgl.use_c_port()
+    pp = PrimitiveProver(zctx)
+    third = 0x1234567890ABCDEF
+    v, v1 = 3 * third, 2 * third + 5
+    tt = pp.two_thirds(v1.to_bytes(17, "little"), v.to_bytes(17, "little"))
+    V.verify(json.loads(json.dumps(tt[2])), tt[1], tt[0])
+    assert tt[2]["public_inputs"] == list(v1.to_bytes(17, "little"))
+    with pytest.raises(AssertionError):
+        pp.two_thirds((2 * third - 5).to_bytes(17, "little"), v.to_bytes(17, "little"))
+    ch = pp.prove_consecutive_heights((105971807).to_bytes(8, "little"), (105971806).to_bytes(8, "little"))
+    V.verify(json.loads(json.dumps(ch[2])), ch[1], ch[0])
+    eq = pp.prove_eq_array(bytes(range(32)), bytes(range(32)))
+    V.verify(json.loads(json.dumps(eq[2])), eq[1], eq[0])
+    rp = RecursionProver(zctx, HASH_GL)
+    rc, rproof = rp.recursive_proof(tt)
+    V.verify(json.loads(json.dumps(rproof)), rc.verifier_only, rc.common)
+    bad = json.loads(json.dumps(tt[2]))
+    bad["public_inputs"][-1] = 10000          # recursion.rs:152
+    with pytest.raises(AssertionError):
+        rp.recursive_proof((tt[0], tt[1], bad))
+    rp.close()
+    pp.close()

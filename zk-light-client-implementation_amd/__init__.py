@@ -16,4 +16,5 @@ from .context import Context  # noqa: F401
 from . import signatures  # noqa: F401
 from . import distributed  # noqa: F401
 from . import header_bphash  # noqa: F401
+from . import primitives  # noqa: F401
 from . import keys_stakes  # noqa: F401

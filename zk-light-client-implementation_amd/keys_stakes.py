@@ -8,29 +8,23 @@ valid_keys and the 17-byte valid stake sum as public inputs; a SHA-256 proof of 
 approvals proof) and one recursion proof tie it together.  The circuit depends on the positions listed in valid_keys, exactly as
 in the reference (:73-75), so it is built per call.
 """
-from .plonky2.builder import P
 from .plonky2.recursion import RecursiveCircuitBuilder
+from .primitives import byte_and_carry, select_not_smaller, times_small, upper_bytes_match
 
 STAKE_BYTES, PK_HASH_BYTES = 16, 32
 STAKE_SUM_LEN = STAKE_BYTES + 1
-CONSTANT1, CONSTANT2 = 0xFFFFFFFEFFFFFF00, 0xFFFFFFFF00000000
 
 
 def keys_stakes_circuit(valid_keys, validator_lens):
     """keys_stakes.rs:29-243: returns (CircuitData, validator byte targets, valid_keys byte targets)"""
     b = RecursiveCircuitBuilder()
-    zero, neg_one = b.zero(), b.neg_one()
     vt = [b.add_virtual_targets(n) for n in validator_lens]
     kt = b.add_virtual_targets(len(valid_keys))
-
-    def byte_and_carry(t):
-        bits = b.split_le_63(t, 64)
-        return b.le_sum_small(bits[0:8]), b.le_sum_small(bits[8:16])
 
     def add_stake(acc, val):
         crr = b.zero()
         for j in range(STAKE_BYTES):
-            acc[j], crr = byte_and_carry(b.add(b.add(acc[j], val[len(val) - STAKE_BYTES + j]), crr))
+            acc[j], crr = byte_and_carry(b, b.add(b.add(acc[j], val[len(val) - STAKE_BYTES + j]), crr))
         acc[STAKE_SUM_LEN - 1] = b.add(acc[STAKE_SUM_LEN - 1], crr)
 
     valid_sum = [b.zero()] * STAKE_SUM_LEN
@@ -43,43 +37,11 @@ def keys_stakes_circuit(valid_keys, validator_lens):
     all_sum = [b.zero()] * STAKE_SUM_LEN
     for val in vt:
         add_stake(all_sum, val)
-    c1, c2, seven, h = b.constant(CONSTANT1), b.constant(CONSTANT2), b.constant(7), b.constant(100)
-
-    def upper_bytes_match(sub):
-        """:119-131 -- how many of the bytes 1..7 of `sub` equal those of the pattern chosen by (sub == -1)"""
-        chs = b.select(b.is_equal(sub, neg_one), c2, c1)
-        cb, sb = b.split_le_63(chs, 64), b.split_le_63(sub, 64)
-        s = zero
-        for j in range(8, 64, 8):
-            s = b.add(s, b.is_equal(b.le_sum_small(cb[j:j + 8]), b.le_sum_small(sb[j:j + 8])))
-        return s
-    b.connect(upper_bytes_match(b.sub(valid_sum[STAKE_SUM_LEN - 1], h)), seven)
-    b.connect(upper_bytes_match(b.sub(all_sum[STAKE_SUM_LEN - 1], h)), seven)
-    three, two = b.constant(3), b.two()
-    three_valid, crr = [], b.zero()
-    for i in range(STAKE_SUM_LEN):
-        lo, crr = byte_and_carry(b.mul_add(valid_sum[i], three, crr))
-        three_valid.append(lo)
-    three_valid.append(crr)
-    two_all, crr = [], b.zero()
-    for i in range(STAKE_SUM_LEN):
-        lo, crr = byte_and_carry(b.mul_add(all_sum[i], two, crr))
-        two_all.append(lo)
-    two_all.append(crr)
-    res = [None] * len(three_valid)
-    prev = (zero, zero)
-    for i in range(len(three_valid) - 1, -1, -1):
-        is_equal = b.is_equal(three_valid[i], two_all[i])
-        s = upper_bytes_match(b.sub(three_valid[i], two_all[i]))
-        is_negative = b.is_equal(s, seven)
-        b.connect(s, b.select(is_negative, seven, zero))
-        if i == len(three_valid) - 1:
-            res[i] = b.select(is_negative, two_all[i], three_valid[i])
-            prev = (is_equal, is_negative)
-        else:
-            q = b.is_equal(prev[0], prev[1])
-            prev = (b.select(q, prev[0], is_equal), b.select(q, prev[1], is_negative))
-            res[i] = b.select(prev[1], two_all[i], three_valid[i])
+    seven, h = b.constant(7), b.constant(100)
+    b.connect(upper_bytes_match(b, b.sub(valid_sum[STAKE_SUM_LEN - 1], h)), seven)
+    b.connect(upper_bytes_match(b, b.sub(all_sum[STAKE_SUM_LEN - 1], h)), seven)
+    three_valid, two_all = times_small(b, valid_sum, 3), times_small(b, all_sum, 2)
+    res = select_not_smaller(b, three_valid, two_all, len(three_valid))
     for x, y in zip(three_valid, res):
         b.connect(x, y)
     for t in kt + valid_sum:
