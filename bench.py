@@ -418,6 +418,28 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         out[key]["host_ms_per_call"] = {k: round(v, 3) for k, v in host.items()}
         out[key]["host_python_untimed"] = {"first_call_s_circuit_build_upload_program": build_s}
 
+    # ---- 8(f).2: the other circuits of a block proof -- SHA-256 (prove_crypto/sha256.rs:62-83; header / bp_hash / valid_keys
+    # hashes) and the keys / stakes circuit (prove_block_data/keys_stakes.rs:18-243) on the 100-validator fixture
+    from zklc_amd.plonky2 import sha256 as SHA
+    from zklc_amd import keys_stakes as KS
+    c2f = json.load(open(os.path.join(ROOT, "tests", "golden", "ed25519_near_c2_100.json")))
+    vals = [len(e["account_id"]).to_bytes(4, "little") + e["account_id"].encode() + bytes.fromhex(e["validator_tail"]) for e in c2f["entries"]]
+    vkeys = b"".join(bytes([pos]) + vals[pos][-48:-16] for pos, e in enumerate(c2f["entries"]) if len(bytes.fromhex(e["approval"])) == 66)
+    for name, (data_, pw_) in {
+            "sha256_208B_inner_lite": (lambda d_w: (d_w[0], SHA.sha256_witness(d_w[1], bytes(208))))(SHA.sha256_circuit(208)),
+            "keys_stakes_100_validators": (lambda d: (d[0], {**{t: x for ts, v in zip(d[1], vals) for t, x in zip(ts, v)},
+                                                             **dict(zip(d[2], vkeys))}))(KS.keys_stakes_circuit(vkeys, [len(v) for v in vals]))}.items():
+        t_ = time.perf_counter()
+        data_.witness_program(list(pw_))
+        wn_, pn_ = data_.generate_witness_native([pw_])
+        t_w = time.perf_counter() - t_
+        pr_ = data_.prover(fold_ctx, HASH_GL)
+        ms = time_proof(pr_, wn_[0], [int(x) for x in pn_[0]], fold_ctx.stream_ptr(), data_.degree_bits)
+        key = "%s_2p%dx135" % (name, data_.degree_bits)
+        out[key] = describe(data_, pr_, ms, "the reference's circuit (restated), real witness")
+        out[key]["host_python_untimed"] = {"program_compile_and_native_witness_s": t_w}
+        pr_.close()
+
     # ---- one Block_i signature sub-DAG, end to end, on the reference's own fixture (BASELINE configs[1]/[2]):
     # data/validators_ordered.json (100 validators) + data/next_block_header.json: 66 present approvals of one 41-byte message.
     #   a3  batched Ed25519 pre-verification of the present approvals on the GPU (signatures.rs:79)

@@ -238,3 +238,37 @@ def test_prove_approvals_on_the_reference_small_fixture(zctx, approval_prover):
     golden = load_golden("plonky2_near_random_CGZP.json")["common_data"]
     assert wrc.common["gates"] == golden["gates"]      # the wrap circuit has the gate list of the reference's final proofs
     wrap.close()
+
+
+def test_full_block_proof_on_a_mainnet_window(zctx, approval_prover):
+    """`prove_block_bft` (near_bft_finality/src/prove_bft/bft.rs:38-500, the path of bin/prove_random.rs) on the reference's own
+    data set -- NEAR mainnet blocks 121798939..43 of epoch HPi5.., its 100 block producers, Block_0 of the previous epoch and the
+    last block of the one before (tests/golden/block_window_HPi5.json: borsh bytes rebuilt from the JSON views and pinned by the
+    block hashes): 73 Ed25519-circuit proofs and their fold, keys / stakes, seven header-hash chains, bp_hash, equalities,
+    consecutive heights and the recursions that join them.  The final proof is accepted by the verifier restatement and its
+    public inputs are [0, hash(Block_i), hash(Block_n-1(epoch i-2)), hash(Block_0(epoch i-1))]."""
+    import time
+    from conftest import load_golden
+    from zklc_amd.prove_bft import BlockProver
+    w = load_golden("block_window_HPi5.json")
+    hx = bytes.fromhex
+    blocks = []
+    for blk in w["blocks"]:
+        f = {k: hx(blk[k]) for k in ("hash", "prev_hash", "epoch_id", "last_ds_final_hash", "last_final_hash")}
+        f["height"] = blk["height"]
+        f["approvals"] = [hx(a) for a in blk["approvals"]]
+        blocks.append((f, hx(blk["bytes"])))
+    validators = [hx(v) for v in w["validators"]]
+    bp = BlockProver(zctx, approval_prover)
+    t0 = time.time()
+    bi, none = bp.prove_block_bft(hx(w["ep2_last_block"]["bytes"]), hx(w["ep2_last_block"]["hash"]), hx(w["ep1_first_block"]["bytes"]),
+                                  hx(w["ep1_first_block"]["hash"]), blocks, validators)
+    dt = time.time() - t0
+    assert none is None
+    V.verify(json.loads(json.dumps(bi[2])), bi[1], bi[0])
+    want = [0] + list(hx(w["blocks"][4]["hash"])) + list(hx(w["ep2_last_block"]["hash"])) + list(hx(w["ep1_first_block"]["hash"]))
+    assert bi[2]["public_inputs"] == want
+    n_present = sum(1 for a in blocks[3][0]["approvals"] if len(a) == 66)
+    print("full Block_i proof: %.1f s sequential (%d approvals); proof counts %s" % (dt, n_present, bp.counts))
+    bp.hashes.sha.close()
+    bp.prims.close()

@@ -18,3 +18,4 @@ from . import distributed  # noqa: F401
 from . import header_bphash  # noqa: F401
 from . import primitives  # noqa: F401
 from . import keys_stakes  # noqa: F401
+from . import prove_bft  # noqa: F401

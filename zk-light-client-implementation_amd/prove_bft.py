@@ -1,0 +1,176 @@
+"""Host-side mirror of the reference's block-finality DAG (BASELINE configs[2]: the full Block_i proof).
+
+Reference:
+  near_bft_finality/src/prove_bft/block_finality.rs   prove_consecutive_heights_proofs :30-96, prove_block_header :98-198,
+                                                      prove_block_finality :200-650
+  near_bft_finality/src/prove_bft/bft.rs              prove_block_bft :38-500 (5 blocks = a randomly selected block, 6 = epoch blocks)
+Every leaf is one of the proofs this package already produces on the GPU -- SHA-256 chains for header hashes and bp_hash
+(header_bphash.py), the signature fold (signatures.ApprovalProver), keys / stakes (keys_stakes.py), equalities and
+consecutive heights (primitives.py) -- and every inner node is `recursive_proof`.  The order of the recursions, the public
+inputs each one exposes and the byte offsets into them are those of the reference; proofs are (common_data, verifier_only,
+proof) triples.  Block headers are borsh bytes ([version 1][prev_hash 32][inner_lite 208][inner_rest ..][key type 1][sig 64]).
+"""
+from . import signatures as SG
+
+TYPE_BYTE, PK_HASH_BYTES, INNER_LITE_BYTES, BLOCK_HEIGHT_BYTES, SIG_BYTES = 1, 32, 208, 8, 64
+
+
+def pi_bytes(proof, lo, hi=None):
+    pis = proof[2]["public_inputs"]
+    return bytes(int(x) & 0xFF for x in pis[lo:hi])
+
+
+class BlockProver:
+    def __init__(self, ctx, approval_prover=None):
+        from .header_bphash import BlockHashProver
+        from .keys_stakes import KeysStakesProver
+        from .primitives import PrimitiveProver
+        self.approvals = approval_prover or SG.ApprovalProver(ctx)
+        self.recursion = self.approvals.recursion
+        self.hashes = BlockHashProver(ctx)
+        self.hashes.recursion.close()
+        self.hashes.recursion = self.recursion
+        self.keys = KeysStakesProver(ctx, sha=self.hashes.sha, recursion=self.recursion)
+        self.prims = PrimitiveProver(ctx)
+        self.counts = {}
+
+    def _rec(self, first, second=None, pis=None):
+        self.counts["recursive_proof"] = self.counts.get("recursive_proof", 0) + 1
+        rc, proof = self.recursion.recursive_proof(first, second, None if pis is None else [int(x) for x in pis])
+        return (rc.common, rc.verifier_only, proof)
+
+    def _eq(self, a, b):
+        self.counts["prove_eq_array"] = self.counts.get("prove_eq_array", 0) + 1
+        return self.prims.prove_eq_array(a, b)
+
+    # ---- block_finality.rs:30-96
+    def prove_consecutive_heights_proofs(self, proofs):
+        assert len(proofs) >= 3
+        h = [pi_bytes(p, 32, 40) for p in proofs]
+        p1 = self.prims.prove_consecutive_heights(h[0], h[1])
+        p2 = self.prims.prove_consecutive_heights(h[1], h[2])
+        agg = self._rec(p1, p2)
+        if len(proofs) == 4:
+            agg = self._rec(agg, self.prims.prove_consecutive_heights(h[2], h[3]))
+        return agg
+
+    # ---- block_finality.rs:98-198
+    def prove_block_header(self, hash_bytes, block_bytes, height=None, epoch_id=None, prev_hash=None, last_ds_final_hash=None,
+                           last_final_hash=None, bp_hash=None, next_epoch_id=None):
+        pis = bytes(hash_bytes)
+        if height is not None:
+            pis += int(height).to_bytes(8, "little")
+        for part in (epoch_id, prev_hash, last_ds_final_hash, last_final_hash):
+            if part is not None:
+                pis += bytes(part)
+        if bp_hash is not None:
+            assert len(pis) == 32
+            pis += bytes(bp_hash)
+            if next_epoch_id is not None:
+                pis += bytes(next_epoch_id)
+        self.counts["prove_header_hash"] = self.counts.get("prove_header_hash", 0) + 1
+        o = TYPE_BYTE + PK_HASH_BYTES
+        return self.hashes.prove_header_hash(hash_bytes, block_bytes[TYPE_BYTE:o], block_bytes[o:o + INNER_LITE_BYTES],
+                                             block_bytes[o + INNER_LITE_BYTES:len(block_bytes) - TYPE_BYTE - SIG_BYTES], list(pis))
+
+    # ---- block_finality.rs:200-650
+    def prove_block_finality(self, current_block_header_proof, msg_to_sign, next_block_approvals, validators, proofs,
+                             consecutive_heights):
+        cur_hash = pi_bytes(current_block_header_proof, 0, 32)
+        cur_epoch_id = pi_bytes(current_block_header_proof, 40, 72)
+        aggregation = None
+        if msg_to_sign is not None:
+            (rc, sig_proof), valid_keys = self.approvals.prove_approvals(msg_to_sign, next_block_approvals, validators)
+            sig = (rc.common, rc.verifier_only, sig_proof)
+            ks = self.keys.prove_valid_keys_stakes_in_validators_list(valid_keys, pi_bytes(sig, 0), validators)
+            aggregation = self._rec(sig, ks, ks[2]["public_inputs"])
+        assert 3 <= len(proofs) <= 4
+        block_n_1 = self._rec(proofs[0], self._eq(cur_epoch_id, pi_bytes(proofs[0], 0, 32)), proofs[0][2]["public_inputs"][0:32])
+        if validators is not None:
+            bp = self.hashes.prove_bp_hash(pi_bytes(proofs[1], 32, 64), validators)
+            block_0 = self._rec(proofs[1], bp, proofs[1][2]["public_inputs"][0:32])
+        else:
+            block_0 = self._rec(proofs[1], None, proofs[1][2]["public_inputs"][0:32])
+        agg = self._rec(block_n_1, block_0, block_n_1[2]["public_inputs"] + block_0[2]["public_inputs"])
+        aggregation = agg if aggregation is None else self._rec(aggregation, agg, agg[2]["public_inputs"])
+        prev_hash_p = self._eq(pi_bytes(proofs[2], 72, 104), cur_hash)
+        n2 = len(proofs[2][2]["public_inputs"])
+        if consecutive_heights is not None:
+            ds_p = self._eq(pi_bytes(proofs[2], n2 - 64, n2 - 32), cur_hash)
+            inner = self._rec(prev_hash_p, self._rec(ds_p, consecutive_heights))
+        else:
+            inner = self._rec(prev_hash_p)
+        block_i_1 = self._rec(proofs[2], inner)
+        if len(proofs) == 3:
+            aggregation = self._rec(aggregation, block_i_1, aggregation[2]["public_inputs"])
+        else:
+            if consecutive_heights is not None:
+                n3 = len(proofs[3][2]["public_inputs"])
+                block_i_2 = self._rec(proofs[3], self._eq(pi_bytes(proofs[3], n3 - 32), cur_hash))
+            else:
+                block_i_2 = self._rec(proofs[3])
+            aggregation = self._rec(aggregation, self._rec(block_i_1, block_i_2), aggregation[2]["public_inputs"])
+        pis = current_block_header_proof[2]["public_inputs"] + aggregation[2]["public_inputs"]
+        return self._rec(aggregation, current_block_header_proof, pis)
+
+    # ---- bft.rs:38-500
+    def prove_block_bft(self, ep2_last_block_bytes, ep2_last_block_hash, ep1_first_block_bytes, ep1_first_block_hash, blocks,
+                        validators, ep3_last_block_bytes=None, ep3_last_block_hash=None, validators_n_1=None):
+        """blocks: [(fields, header bytes)] in the order [Block_i+4, .., Block_i] (a randomly selected block) or
+        [Block_4, .., Block_0, Block_n-1] (epoch blocks); fields = dict with hash, height, prev_hash, epoch_id,
+        last_ds_final_hash, last_final_hash, approvals.  Returns (proof of Block_i / Block_0, proof of Block_n-1 or None)."""
+        o = TYPE_BYTE + PK_HASH_BYTES + INNER_LITE_BYTES
+
+        def bp_hash_of(b):
+            return b[o - 2 * PK_HASH_BYTES:o - PK_HASH_BYTES]
+        ep2_lb = self.prove_block_header(ep2_last_block_hash, ep2_last_block_bytes, bp_hash=bp_hash_of(ep2_last_block_bytes))
+        q = TYPE_BYTE + PK_HASH_BYTES + BLOCK_HEIGHT_BYTES + PK_HASH_BYTES
+        ep1_fb = self.prove_block_header(ep1_first_block_hash, ep1_first_block_bytes, bp_hash=bp_hash_of(ep1_first_block_bytes),
+                                         next_epoch_id=ep1_first_block_bytes[q:q + PK_HASH_BYTES])
+        n = len(ep1_fb[2]["public_inputs"])
+        neph = self._eq(pi_bytes(ep2_lb, 0, 32), pi_bytes(ep1_fb, n - 32))
+        ep1_fb = self._rec(ep1_fb, neph, ep1_fb[2]["public_inputs"])
+
+        def header(k, *names):
+            f, raw = blocks[k]
+            return self.prove_block_header(f["hash"], raw, **{nm: f[nm] for nm in names})
+        b4 = header(0, "height", "epoch_id", "prev_hash")
+        b3 = header(1, "height", "epoch_id", "prev_hash")
+        b2 = header(2, "height", "epoch_id", "prev_hash", "last_ds_final_hash", "last_final_hash")
+        b2 = self._rec(b2, self.prove_consecutive_heights_proofs([b4, b3, b2]), b2[2]["public_inputs"])
+        b1 = header(3, "height", "epoch_id", "prev_hash", "last_ds_final_hash", "last_final_hash")
+        if len(blocks) == 5:
+            bi0, bn_1_header = header(4, "height", "epoch_id"), None
+        elif len(blocks) == 6:
+            bi0 = header(4, "height", "epoch_id", "prev_hash", "last_ds_final_hash")
+            bn_1_header = header(5, "height", "epoch_id")
+        else:
+            raise ValueError("Invalid blocks.len() %d" % len(blocks))
+        hts = [int.from_bytes(pi_bytes(p, 32, 40), "little") for p in (b2, b1, bi0)]
+        chain = [b2, b1, bi0]
+        if bn_1_header is not None:
+            hts.append(int.from_bytes(pi_bytes(bn_1_header, 32, 40), "little"))
+            chain.append(bn_1_header)
+        # (the reference's test is h1 + 1 == h2 && ... on heights that come in DEscending order: bft.rs:227-263)
+        consecutive = self.prove_consecutive_heights_proofs(chain) if all(hts[k] + 1 == hts[k + 1] for k in range(len(hts) - 1)) else None
+
+        def finality(header_proof, next_block, approvals, vals, proofs):
+            msg = SG.generate_signed_message(int.from_bytes(pi_bytes(header_proof, 32, 40), "little"),
+                                             int.from_bytes(pi_bytes(next_block, 32, 40), "little"), pi_bytes(next_block, 72, 104))
+            return self.prove_block_finality(header_proof, msg, approvals, vals, proofs, consecutive)
+
+        def three_hashes(p, flag):
+            n_ = len(p[2]["public_inputs"])
+            return self._rec(p, None, [flag] + p[2]["public_inputs"][0:32] + p[2]["public_inputs"][n_ - 64:])
+        if len(blocks) == 5:
+            bi = finality(bi0, b1, blocks[3][0]["approvals"], validators, [ep2_lb, ep1_fb, b1, b2])
+            return three_hashes(bi, 0), None
+        b0 = finality(bi0, b1, blocks[3][0]["approvals"], validators, [ep2_lb, ep1_fb, b1, b2])
+        ep3_lb = self.prove_block_header(ep3_last_block_hash, ep3_last_block_bytes)
+        b_n_1 = finality(bn_1_header, b0, blocks[4][0]["approvals"], validators_n_1, [ep3_lb, ep2_lb, b0, b1])
+        return three_hashes(b0, 1), three_hashes(b_n_1, 1)
+
+    def close(self):
+        self.approvals.close()
+        self.hashes.sha.close()
+        self.prims.close()
