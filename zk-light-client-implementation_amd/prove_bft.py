@@ -32,16 +32,23 @@ class BlockProver:
         self.hashes.recursion = self.recursion
         self.keys = KeysStakesProver(ctx, sha=self.hashes.sha, recursion=self.recursion)
         self.prims = PrimitiveProver(ctx)
-        self.counts = {}
+        self.counts, self.seconds = {}, {}
+
+    def _timed(self, what, fn, *a, **kw):
+        import time
+        t0 = time.perf_counter()
+        r = fn(*a, **kw)
+        self.counts[what] = self.counts.get(what, 0) + 1
+        self.seconds[what] = self.seconds.get(what, 0.0) + time.perf_counter() - t0
+        return r
 
     def _rec(self, first, second=None, pis=None):
-        self.counts["recursive_proof"] = self.counts.get("recursive_proof", 0) + 1
-        rc, proof = self.recursion.recursive_proof(first, second, None if pis is None else [int(x) for x in pis])
+        rc, proof = self._timed("recursive_proof", self.recursion.recursive_proof, first, second,
+                                None if pis is None else [int(x) for x in pis])
         return (rc.common, rc.verifier_only, proof)
 
     def _eq(self, a, b):
-        self.counts["prove_eq_array"] = self.counts.get("prove_eq_array", 0) + 1
-        return self.prims.prove_eq_array(a, b)
+        return self._timed("prove_eq_array", self.prims.prove_eq_array, a, b)
 
     # ---- block_finality.rs:30-96
     def prove_consecutive_heights_proofs(self, proofs):
@@ -68,10 +75,10 @@ class BlockProver:
             pis += bytes(bp_hash)
             if next_epoch_id is not None:
                 pis += bytes(next_epoch_id)
-        self.counts["prove_header_hash"] = self.counts.get("prove_header_hash", 0) + 1
         o = TYPE_BYTE + PK_HASH_BYTES
-        return self.hashes.prove_header_hash(hash_bytes, block_bytes[TYPE_BYTE:o], block_bytes[o:o + INNER_LITE_BYTES],
-                                             block_bytes[o + INNER_LITE_BYTES:len(block_bytes) - TYPE_BYTE - SIG_BYTES], list(pis))
+        return self._timed("prove_header_hash", self.hashes.prove_header_hash, hash_bytes, block_bytes[TYPE_BYTE:o],
+                           block_bytes[o:o + INNER_LITE_BYTES],
+                           block_bytes[o + INNER_LITE_BYTES:len(block_bytes) - TYPE_BYTE - SIG_BYTES], list(pis))
 
     # ---- block_finality.rs:200-650
     def prove_block_finality(self, current_block_header_proof, msg_to_sign, next_block_approvals, validators, proofs,
@@ -80,14 +87,16 @@ class BlockProver:
         cur_epoch_id = pi_bytes(current_block_header_proof, 40, 72)
         aggregation = None
         if msg_to_sign is not None:
-            (rc, sig_proof), valid_keys = self.approvals.prove_approvals(msg_to_sign, next_block_approvals, validators)
+            (rc, sig_proof), valid_keys = self._timed("prove_approvals", self.approvals.prove_approvals, msg_to_sign,
+                                                      next_block_approvals, validators)
             sig = (rc.common, rc.verifier_only, sig_proof)
-            ks = self.keys.prove_valid_keys_stakes_in_validators_list(valid_keys, pi_bytes(sig, 0), validators)
+            ks = self._timed("prove_valid_keys_stakes", self.keys.prove_valid_keys_stakes_in_validators_list, valid_keys,
+                             pi_bytes(sig, 0), validators)
             aggregation = self._rec(sig, ks, ks[2]["public_inputs"])
         assert 3 <= len(proofs) <= 4
         block_n_1 = self._rec(proofs[0], self._eq(cur_epoch_id, pi_bytes(proofs[0], 0, 32)), proofs[0][2]["public_inputs"][0:32])
         if validators is not None:
-            bp = self.hashes.prove_bp_hash(pi_bytes(proofs[1], 32, 64), validators)
+            bp = self._timed("prove_bp_hash", self.hashes.prove_bp_hash, pi_bytes(proofs[1], 32, 64), validators)
             block_0 = self._rec(proofs[1], bp, proofs[1][2]["public_inputs"][0:32])
         else:
             block_0 = self._rec(proofs[1], None, proofs[1][2]["public_inputs"][0:32])

@@ -117,7 +117,7 @@ class ApprovalProver:
         return ent
 
     def ed25519_proofs(self, msg, sigs, pks):
-        """one proof per (signature, public key): (common, verifier_only, proof) triples"""
+        """one proof per (signature, public key): (common, verifier_only, proof bytes) triples"""
         from .plonky2 import ed25519_circuit as E
         data, targets, prover, vd = self.ed25519_circuit(len(msg))
         fills = [E.fill_ecdsa_targets(targets, msg, bytes(s), bytes(p)) for s, p in zip(sigs, pks)]
@@ -129,7 +129,7 @@ class ApprovalProver:
         for c0 in range(0, len(fills), chunk):
             wires, pis = data.generate_witness_native(fills[c0:c0 + chunk], threads=self.threads)
             for k in range(len(wires)):
-                out.append((common, vd, prover.prove(wires[k], [int(x) for x in pis[k]])))
+                out.append((common, vd, prover.prove_bytes(wires[k], [int(x) for x in pis[k]])))
         return out
 
     def prove_approvals(self, msg, approvals, validators):
@@ -141,8 +141,8 @@ class ApprovalProver:
         _, pks, sigs = slice_approvals(approvals, validators)
         proofs = self.ed25519_proofs(msg, [s.tobytes() for s in sigs], [p.tobytes() for p in pks])
         agg = proofs[0]
-        for nxt in proofs[1:]:
-            rc, proof = self.recursion.recursive_proof(agg, nxt)
+        for nxt in proofs[1:]:        # proofs travel as `to_bytes` bytes between the steps (signatures.rs:225-230)
+            rc, proof = self.recursion.recursive_proof(agg, nxt, raw=True)
             agg = (rc.common, rc.verifier_only, proof)
         rc, proof = self.recursion.recursive_proof(agg, None, list(hashlib.sha256(valid_keys).digest()))
         return (rc, proof), valid_keys
