@@ -88,6 +88,34 @@ class Target:
         return "Wire(%d,%d)" % (self.row, self.col) if self.idx is None else "Virtual(%d)" % self.idx
 
 
+class TargetRange:
+    """the wires (row, col) .. (row, col + n - 1) without one Python object per wire: the limb / bit cells a gate's generator
+    fills (tens per operation, millions per circuit) are only ever named in bulk"""
+    __slots__ = ("row", "col", "n")
+
+    def __init__(self, row, col, n):
+        self.row, self.col, self.n = row, col, n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [Target(self.row, self.col + j) for j in range(*i.indices(self.n))]
+        if i < 0:
+            i += self.n
+        if not 0 <= i < self.n:
+            raise IndexError(i)
+        return Target(self.row, self.col + i)
+
+    def __iter__(self):
+        return (Target(self.row, self.col + j) for j in range(self.n))
+
+    def keys(self):
+        k0 = (self.row << 8) | self.col
+        return range(k0, k0 + self.n)
+
+
 class CircuitBuilder:
     def __init__(self, config=None):
         self.config = config or standard_recursion_config()
@@ -146,8 +174,8 @@ class CircuitBuilder:
     def add_generator(self, inputs, fn, op=None, params=(), outs=None):
         """fn(values of inputs) -> [(target, value)]; (op, params) name the same computation for the native interpreter
         (csrc/plonky2_witness.cpp), which must emit its outputs in the order fn returns them.  `outs` = the targets fn sets, in
-        that order: when every generator declares them, the interpreter program is compiled without running the Python
-        generators (CircuitData.witness_program)."""
+        that order (Targets and TargetRanges): when every generator declares them, the interpreter program is compiled without
+        running the Python generators (CircuitData.witness_program)."""
         self.generators.append((list(inputs), fn, op, tuple(int(x) for x in params), None if outs is None else list(outs)))
 
     # ---- constants
@@ -284,7 +312,7 @@ class CircuitBuilder:
         for a, w in zip(list(to_add) + [carry_t], ins):
             self.connect(a, w)
         res, carry = Target(row, per * i + na + 1), Target(row, per * i + na + 2)
-        limbs = [Target(row, per * gate.num_ops + 18 * i + j) for j in range(18)]
+        limbs = TargetRange(row, per * gate.num_ops + 18 * i, 18)
 
         def gen(v, res=res, carry=carry, limbs=limbs):
             s = sum(v)
@@ -294,7 +322,7 @@ class CircuitBuilder:
             out += [(limbs[j], (lo >> (2 * j)) & 3) for j in range(16)]
             out += [(limbs[16 + j], (hi >> (2 * j)) & 3) for j in range(2)]
             return out
-        self.add_generator(ins, gen, OP_ADD_MANY, outs=[res, carry] + limbs)
+        self.add_generator(ins, gen, OP_ADD_MANY, outs=[res, carry, limbs])
         return res, carry
 
     def sub_u32(self, x, y, borrow):
@@ -307,7 +335,7 @@ class CircuitBuilder:
         w = [Target(row, 5 * i + k) for k in range(5)]
         for a, t in zip((x, y, borrow), w):
             self.connect(a, t)
-        limbs = [Target(row, 5 * gate.num_ops + 16 * i + j) for j in range(16)]
+        limbs = TargetRange(row, 5 * gate.num_ops + 16 * i, 16)
 
         def gen(v, w=w, limbs=limbs):
             d = v[0] - v[1] - v[2]
@@ -315,7 +343,7 @@ class CircuitBuilder:
             res = d + (bout << 32)
             assert 0 <= res < (1 << 32)
             return [(w[3], res), (w[4], bout)] + [(limbs[j], (res >> (2 * j)) & 3) for j in range(16)]
-        self.add_generator(w[:3], gen, OP_SUB_U32, outs=[w[3], w[4]] + limbs)
+        self.add_generator(w[:3], gen, OP_SUB_U32, outs=[w[3], w[4], limbs])
         return w[3], w[4]
 
     def range_check_u32(self, vals):
@@ -334,7 +362,7 @@ class CircuitBuilder:
                 assert x < (1 << 32), "range_check_u32: value exceeds 32 bits"
                 out += [(Target(row, n + 16 * i + j), (x >> (2 * j)) & 3) for j in range(16)]
             return out
-        self.add_generator(ins, gen, OP_RANGE_CHECK, outs=[Target(row, n + 16 * i + j) for i in range(n) for j in range(16)])
+        self.add_generator(ins, gen, OP_RANGE_CHECK, outs=[TargetRange(row, n, 16 * n)])
 
     def _comparison(self, a, b, num_bits=32):
         """one ComparisonGate row: result = (a <= b)  (crypto/plonky2_u32/src/gates/comparison.rs generator)"""
@@ -472,7 +500,7 @@ class CircuitBuilder:
         row, i = self._u32_slot
         self._u32_slot[1] += 1
         w = [Target(row, 6 * i + k) for k in range(6)]
-        limbs = [Target(row, 6 * gate.num_ops + 32 * i + j) for j in range(32)]
+        limbs = TargetRange(row, 6 * gate.num_ops + 32 * i, 32)
         self.connect(m0, w[0])
         self.connect(m1, w[1])
         self.connect(addend, w[2])
@@ -486,7 +514,7 @@ class CircuitBuilder:
             res = [(w[3], lo), (w[4], hi), (w[5], inv)]
             res += [(limbs[j], (out >> (2 * j)) & 3) for j in range(32)]
             return res
-        self.add_generator(w[:3], gen, OP_U32_MULADD, outs=[w[3], w[4], w[5]] + limbs)
+        self.add_generator(w[:3], gen, OP_U32_MULADD, outs=[w[3], w[4], w[5], limbs])
         return w[3], w[4]
 
     # ---- interleaved ("B32") representation: crypto/plonky2_u32/src/gadgets/interleaved_u32.rs
@@ -499,14 +527,14 @@ class CircuitBuilder:
         self._il_slot[1] += 1
         wx, wi = Target(row, 2 * i), Target(row, 2 * i + 1)
         self.connect(wx, x)
-        bits = [Target(row, 2 * gate.num_ops + 32 * i + j) for j in range(32)]
+        bits = TargetRange(row, 2 * gate.num_ops + 32 * i, 32)
 
         def gen(v, wi=wi, bits=bits):
             xv = v[0]
             assert xv < (1 << 32), "interleave_u32: value exceeds 32 bits"
             bv = [(xv >> (31 - j)) & 1 for j in range(32)]                  # big-endian
             return [(wi, sum(b << (2 * (31 - j)) for j, b in enumerate(bv)))] + list(zip(bits, bv))
-        self.add_generator([wx], gen, OP_INTERLEAVE, outs=[wi] + bits)
+        self.add_generator([wx], gen, OP_INTERLEAVE, outs=[wi, bits])
         return wi
 
     def _uninterleave(self, x, to_b32):
@@ -519,7 +547,7 @@ class CircuitBuilder:
         slot[1] += 1
         wx, we, wo = (Target(row, 3 * i + k) for k in range(3))
         self.connect(wx, x)
-        bits = [Target(row, 3 * gate.num_ops + 64 * i + j) for j in range(64)]
+        bits = TargetRange(row, 3 * gate.num_ops + 64 * i, 64)
 
         def gen(v, we=we, wo=wo, bits=bits, to_b32=to_b32):
             bv = [(v[0] >> (63 - j)) & 1 for j in range(64)]               # big-endian
@@ -527,7 +555,7 @@ class CircuitBuilder:
             ev = sum(bv[2 * j] << (step * (31 - j)) for j in range(32))
             od = sum(bv[2 * j + 1] << (step * (31 - j)) for j in range(32))
             return [(we, ev), (wo, od)] + list(zip(bits, bv))
-        self.add_generator([wx], gen, OP_UNINTERLEAVE, (1 if to_b32 else 0,), outs=[we, wo] + bits)
+        self.add_generator([wx], gen, OP_UNINTERLEAVE, (1 if to_b32 else 0,), outs=[we, wo, bits])
         return we, wo
 
     def uninterleave_to_u32(self, x):
@@ -613,7 +641,7 @@ class CircuitBuilder:
             from .prover import poseidon_gate_rows
             r = poseidon_gate_rows(np.array([v[:12]], dtype=np.uint64), np.array([v[12]], dtype=np.uint64))[0]
             return [(Target(row, c), int(r[c])) for c in range(12, 135) if c != 24]
-        self.add_generator(ins + [sw], gen, OP_POSEIDON, outs=[Target(row, c) for c in range(12, 135) if c != 24])
+        self.add_generator(ins + [sw], gen, OP_POSEIDON, outs=[TargetRange(row, 12, 12), TargetRange(row, 25, 110)])
         return [Target(row, 12 + i) for i in range(12)]
 
     def hash_n_to_hash_no_pad(self, inputs):
@@ -819,11 +847,19 @@ class CircuitData:
         G_ = len(gens)
         assert all(g[2] is not None for g in gens), "generator without a native opcode"
         ins_len = np.fromiter((len(g[0]) for g in gens), dtype=np.int64, count=G_)
-        outs_len = np.fromiter((len(g[4]) for g in gens), dtype=np.int64, count=G_)
+        outs_len = np.fromiter((sum(o.n if type(o) is TargetRange else 1 for o in g[4]) for g in gens), dtype=np.int64, count=G_)
         par_len = np.fromiter((len(g[3]) for g in gens), dtype=np.int64, count=G_)
         ops = np.fromiter((g[2] for g in gens), dtype=np.int64, count=G_)
         ins_k = np.fromiter((t.k for g in gens for t in g[0]), dtype=np.int64, count=int(ins_len.sum()))
-        outs_k = np.fromiter((t.k for g in gens for t in g[4]), dtype=np.int64, count=int(outs_len.sum()))
+        flat = []
+        for g in gens:
+            for o in g[4]:
+                if type(o) is TargetRange:
+                    flat.extend(o.keys())
+                else:
+                    flat.append(o.k)
+        outs_k = np.array(flat, dtype=np.int64)
+        del flat
         params = np.fromiter((x - (1 << 64) if x >= (1 << 63) else x for g in gens for x in g[3]), dtype=np.int64,
                              count=int(par_len.sum()))
         in_k = np.array([t.k for t in in_targets], dtype=np.int64)
