@@ -492,8 +492,13 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
 
     def witness_producer():
         try:
-            for c0 in range(0, n_sig, wchunk):
-                idx = list(range(c0, min(c0 + wchunk, n_sig)))
+            # a small first chunk (one signature per proving stream) so that proving starts after one witness time, not after a
+            # full chunk's
+            bounds = [0, min(n_sig, max(1, nthreads - 1))]
+            while bounds[-1] < n_sig:
+                bounds.append(min(n_sig, bounds[-1] + wchunk))
+            for c0, c1 in zip(bounds, bounds[1:]):
+                idx = list(range(c0, c1))
                 sl = free_slots.get()
                 t_ = time.perf_counter()
                 _, pis_ = ed_data.generate_witness_native([fills[i] for i in idx], out=views[sl][:len(idx)], threads=len(idx))
