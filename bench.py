@@ -491,6 +491,9 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         def __init__(self, recursion):
             self.recursion, self.future = recursion, None
 
+        def valid_keys_early(self, msg_, approvals_, validators_):
+            return self.valid_keys
+
         def prove_approvals(self, msg_, approvals_, validators_):
             assert msg_ == c2_msg
             rc_, raw_, vk_ = self.future.result()
@@ -601,6 +604,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         valid_keys, valid_pos, _, _ = SG.verify_approvals(ctx, c2_msg, approvals, validators)   # a3: the pre-check of signatures.rs:79
         assert len(valid_pos) == n_sig, "fixture approvals must verify"
         t_verify = time.perf_counter() - t0
+        stub.valid_keys = valid_keys
         threads = [threading.Thread(target=witness_producer)]
         threads += [threading.Thread(target=ed_worker, args=(pr,)) for _, pr in workers]
         threads += [threading.Thread(target=fold_worker, args=(valid_keys,)), threading.Thread(target=dag_worker)]

@@ -83,17 +83,18 @@ class BlockProver:
     # ---- block_finality.rs:200-650
     def prove_block_finality(self, current_block_header_proof, msg_to_sign, next_block_approvals, validators, proofs,
                              consecutive_heights):
+        """The nodes are the reference's; the host evaluates the ones that do not depend on the signature aggregate first (the
+        keys / stakes proof needs only valid_keys, which the GPU pre-check yields at once, and sha256(valid_keys)), so that after
+        `prove_approvals` returns only the joining recursions remain."""
+        import hashlib
         cur_hash = pi_bytes(current_block_header_proof, 0, 32)
         cur_epoch_id = pi_bytes(current_block_header_proof, 40, 72)
-        aggregation = None
-        if msg_to_sign is not None:
-            (rc, sig_proof), valid_keys = self._timed("prove_approvals", self.approvals.prove_approvals, msg_to_sign,
-                                                      next_block_approvals, validators)
-            sig = (rc.common, rc.verifier_only, sig_proof)
-            ks = self._timed("prove_valid_keys_stakes", self.keys.prove_valid_keys_stakes_in_validators_list, valid_keys,
-                             pi_bytes(sig, 0), validators)
-            aggregation = self._rec(sig, ks, ks[2]["public_inputs"])
         assert 3 <= len(proofs) <= 4
+        ks = None
+        if msg_to_sign is not None and hasattr(self.approvals, "valid_keys_early"):
+            vk = self.approvals.valid_keys_early(msg_to_sign, next_block_approvals, validators)
+            ks = self._timed("prove_valid_keys_stakes", self.keys.prove_valid_keys_stakes_in_validators_list, vk,
+                             hashlib.sha256(vk).digest(), validators)
         block_n_1 = self._rec(proofs[0], self._eq(cur_epoch_id, pi_bytes(proofs[0], 0, 32)), proofs[0][2]["public_inputs"][0:32])
         if validators is not None:
             bp = self._timed("prove_bp_hash", self.hashes.prove_bp_hash, pi_bytes(proofs[1], 32, 64), validators)
@@ -101,7 +102,6 @@ class BlockProver:
         else:
             block_0 = self._rec(proofs[1], None, proofs[1][2]["public_inputs"][0:32])
         agg = self._rec(block_n_1, block_0, block_n_1[2]["public_inputs"] + block_0[2]["public_inputs"])
-        aggregation = agg if aggregation is None else self._rec(aggregation, agg, agg[2]["public_inputs"])
         prev_hash_p = self._eq(pi_bytes(proofs[2], 72, 104), cur_hash)
         n2 = len(proofs[2][2]["public_inputs"])
         if consecutive_heights is not None:
@@ -109,16 +109,26 @@ class BlockProver:
             inner = self._rec(prev_hash_p, self._rec(ds_p, consecutive_heights))
         else:
             inner = self._rec(prev_hash_p)
-        block_i_1 = self._rec(proofs[2], inner)
-        if len(proofs) == 3:
-            aggregation = self._rec(aggregation, block_i_1, aggregation[2]["public_inputs"])
-        else:
+        tail = self._rec(proofs[2], inner)                                            # Block_i+1
+        if len(proofs) == 4:
             if consecutive_heights is not None:
                 n3 = len(proofs[3][2]["public_inputs"])
                 block_i_2 = self._rec(proofs[3], self._eq(pi_bytes(proofs[3], n3 - 32), cur_hash))
             else:
                 block_i_2 = self._rec(proofs[3])
-            aggregation = self._rec(aggregation, self._rec(block_i_1, block_i_2), aggregation[2]["public_inputs"])
+            tail = self._rec(tail, block_i_2)
+        aggregation = agg
+        if msg_to_sign is not None:
+            (rc, sig_proof), valid_keys = self._timed("prove_approvals", self.approvals.prove_approvals, msg_to_sign,
+                                                      next_block_approvals, validators)
+            sig = (rc.common, rc.verifier_only, sig_proof)
+            if ks is None:
+                ks = self._timed("prove_valid_keys_stakes", self.keys.prove_valid_keys_stakes_in_validators_list, valid_keys,
+                                 pi_bytes(sig, 0), validators)
+            else:
+                assert pi_bytes(sig, 0) == hashlib.sha256(valid_keys).digest()
+            aggregation = self._rec(self._rec(sig, ks, ks[2]["public_inputs"]), agg, agg[2]["public_inputs"])
+        aggregation = self._rec(aggregation, tail, aggregation[2]["public_inputs"])
         pis = current_block_header_proof[2]["public_inputs"] + aggregation[2]["public_inputs"]
         return self._rec(aggregation, current_block_header_proof, pis)
 

@@ -132,6 +132,10 @@ class ApprovalProver:
                 out.append((common, vd, prover.prove_bytes(wires[k], [int(x) for x in pis[k]])))
         return out
 
+    def valid_keys_early(self, msg, approvals, validators):
+        """the `valid_keys` bytes prove_approvals will return: they only need the batched pre-check"""
+        return verify_approvals(self.ctx, msg, approvals, validators, strict=True)[0]
+
     def prove_approvals(self, msg, approvals, validators):
         """-> ((RecursiveCircuit, proof), valid_keys); raises InvalidSignature like the reference's panic (:119-121)"""
         import hashlib
