@@ -450,10 +450,10 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     #       context (= HIP stream) and resident circuit, keep that many proofs in flight
     #   a7  the left fold agg = recursive_proof(agg, sig_i) as soon as signature proof i exists and the closing proof with
     #       sha256(valid_keys) -- one host thread + high-priority stream
-    #   8f  everything else of the DAG on one more thread + stream (zklc_amd.prove_bft.BlockProver): seven header-hash chains
-    #       (three SHA-256 proofs and four recursions each), consecutive heights, equalities, then -- once the signature aggregate
-    #       exists -- keys / stakes, bp_hash and the joining recursions; last, the Poseidon-BN128 wrap of the block proof
-    #       (bin/prove_block.rs:279-287)
+    #   8f  everything else of the DAG on two more threads + streams: keys / stakes (needs only valid_keys from the pre-check) on
+    #       one; on the other (zklc_amd.prove_bft.BlockProver) seven header-hash chains (three SHA-256 proofs and four recursions
+    #       each), consecutive heights, equalities, bp_hash, then -- once the signature aggregate exists -- the joining recursions
+    #       and the Poseidon-BN128 wrap of the block proof (bin/prove_block.rs:279-287)
     from concurrent.futures import Future
     from zklc_amd.plonky2 import serialization as S
     from zklc_amd.prove_bft import BlockProver
@@ -491,8 +491,8 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         def __init__(self, recursion):
             self.recursion, self.future = recursion, None
 
-        def valid_keys_early(self, msg_, approvals_, validators_):
-            return self.valid_keys
+        def keys_stakes_early(self, msg_, approvals_, validators_):
+            return self.ks_future.result()
 
         def prove_approvals(self, msg_, approvals_, validators_):
             assert msg_ == c2_msg
@@ -501,6 +501,9 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
 
         def close(self):
             self.recursion.close()
+    from zklc_amd.keys_stakes import KeysStakesProver
+    ks_ctx = zklc_amd.Context(torch.cuda.current_device())
+    ks_prover = KeysStakesProver(ks_ctx)          # keys / stakes needs only valid_keys: its own thread + stream from the start
     dag_ctx = zklc_amd.Context(torch.cuda.current_device(), high_priority=True)
     stub = PipelinedApprovals(RecursionProver(dag_ctx, HASH_GL))
     bprover = BlockProver(dag_ctx, stub)
@@ -518,13 +521,14 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         st["errors"], st["tw"] = [], [0.0]
         st["fold_host"] = {"inputs": 0.0, "witness": 0.0, "prove": 0.0}
         st["result"] = {}
-        stub.future = Future()
+        stub.future, stub.ks_future = Future(), Future()
         bprover.counts, bprover.seconds = {}, {}
 
     def fail(e):
         st["errors"].append(e)
-        if not stub.future.done():
-            stub.future.set_exception(e)
+        for fut in (stub.future, stub.ks_future):
+            if not fut.done():
+                fut.set_exception(e)
         for ev in st["ed_done"]:
             ev.set()
         for _ in range(nthreads):
@@ -598,16 +602,25 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         except Exception as e:  # pragma: no cover
             fail(e)
 
+    def ks_worker(valid_keys):
+        try:
+            t_ = time.perf_counter()
+            stub.ks_future.set_result(ks_prover.prove_valid_keys_stakes_in_validators_list(
+                valid_keys, hashlib.sha256(valid_keys).digest(), validators))
+            st["result"]["keys_stakes_s"] = time.perf_counter() - t_
+        except Exception as e:  # pragma: no cover
+            fail(e)
+
     def prove_one_block():
         reset()
         t0 = time.perf_counter()
         valid_keys, valid_pos, _, _ = SG.verify_approvals(ctx, c2_msg, approvals, validators)   # a3: the pre-check of signatures.rs:79
         assert len(valid_pos) == n_sig, "fixture approvals must verify"
         t_verify = time.perf_counter() - t0
-        stub.valid_keys = valid_keys
         threads = [threading.Thread(target=witness_producer)]
         threads += [threading.Thread(target=ed_worker, args=(pr,)) for _, pr in workers]
-        threads += [threading.Thread(target=fold_worker, args=(valid_keys,)), threading.Thread(target=dag_worker)]
+        threads += [threading.Thread(target=fold_worker, args=(valid_keys,)), threading.Thread(target=dag_worker),
+                    threading.Thread(target=ks_worker, args=(valid_keys,))]
         for th in threads:
             th.start()
         for th in threads:
@@ -634,11 +647,11 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                                 "header-hash chains, bp_hash, heights, equalities, %d joining recursions, the BN128 wrap; every rank "
                                 "proves its own block" % (n_sig, n_sig, bprover.counts.get("recursive_proof", 0)),
                       "value": world / block_s, "unit": "proofs/s", "seconds_per_block": block_s,
-                      "seconds_until_signature_aggregate": sig_s, "streams": nthreads + 1,
+                      "seconds_until_signature_aggregate": sig_s, "streams": nthreads + 2,
                       "approvals": n_sig, "witness_chunk": wchunk, "witness_cpu_seconds_total": tw[0], "preverify_ms": t_verify * 1e3,
                       "fold_thread_seconds": {k: round(v / 1e3, 3) for k, v in fold_host.items()},
                       "dag_thread_seconds": {k: round(v, 3) for k, v in bprover.seconds.items()},
-                      "dag_thread_counts": dict(bprover.counts),
+                      "dag_thread_counts": dict(bprover.counts), "keys_stakes_thread_seconds": result.get("keys_stakes_s"),
                       "wrap_proof_bytes": len(result["wrap"][1]),
                       "first_block_s_incl_circuit_construction": t_setup,
                       "cpu_baseline": None,
@@ -657,6 +670,8 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     rpw_block.close()
     bprover.close()
     dag_ctx.close()
+    ks_prover.close()
+    ks_ctx.close()
     return out
 
 

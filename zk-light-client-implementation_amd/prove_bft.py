@@ -91,7 +91,8 @@ class BlockProver:
         cur_epoch_id = pi_bytes(current_block_header_proof, 40, 72)
         assert 3 <= len(proofs) <= 4
         ks = None
-        if msg_to_sign is not None and hasattr(self.approvals, "valid_keys_early"):
+        ks_elsewhere = msg_to_sign is not None and hasattr(self.approvals, "keys_stakes_early")   # proven by another thread
+        if msg_to_sign is not None and not ks_elsewhere and hasattr(self.approvals, "valid_keys_early"):
             vk = self.approvals.valid_keys_early(msg_to_sign, next_block_approvals, validators)
             ks = self._timed("prove_valid_keys_stakes", self.keys.prove_valid_keys_stakes_in_validators_list, vk,
                              hashlib.sha256(vk).digest(), validators)
@@ -118,6 +119,8 @@ class BlockProver:
                 block_i_2 = self._rec(proofs[3])
             tail = self._rec(tail, block_i_2)
         aggregation = agg
+        if ks_elsewhere:
+            ks = self._timed("wait_keys_stakes", self.approvals.keys_stakes_early, msg_to_sign, next_block_approvals, validators)
         if msg_to_sign is not None:
             (rc, sig_proof), valid_keys = self._timed("prove_approvals", self.approvals.prove_approvals, msg_to_sign,
                                                       next_block_approvals, validators)
