@@ -24,7 +24,7 @@ import hashlib
 import random
 
 from . import sha512
-from .builder import P as GLP, OP_NN_ADD, OP_NN_SUB, OP_NN_MUL, OP_NN_INV, OP_DIV_REM, OP_DECOMPRESS
+from .builder import OP_NN_ADD, OP_NN_SUB, OP_NN_MUL, OP_NN_INV, OP_DIV_REM, OP_DECOMPRESS
 
 P25519 = 2**255 - 19
 L25519 = 2**252 + 27742317777372353535851937790883648493
