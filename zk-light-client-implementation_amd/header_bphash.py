@@ -17,12 +17,12 @@ def vec_u32_to_u8(words):
 
 
 class BlockHashProver:
-    def __init__(self, ctx):
+    def __init__(self, ctx, sha=None, recursion=None):
         from .plonky2 import HASH_GL
         from .plonky2.recursion import RecursionProver
         from .plonky2.sha256 import Sha256Prover
-        self.sha = Sha256Prover(ctx, HASH_GL)
-        self.recursion = RecursionProver(ctx, HASH_GL)
+        self.sha = sha or Sha256Prover(ctx, HASH_GL)
+        self.recursion = recursion or RecursionProver(ctx, HASH_GL)
 
     def _sha(self, msg, digest):
         (common, vd), proof = self.sha.sha256_proof_u32(msg, digest)
