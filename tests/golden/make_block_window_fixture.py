@@ -72,26 +72,49 @@ def block(path):
             "approvals": [("00" if a is None else (b"\1" + sig(a)).hex()) for a in j["approvals"]]}
 
 
-def main():
-    vals = json.load(open(os.path.join(E, EPOCH_I, "validators.json")))["result"]
-    validators = []
-    for e in vals:
+def validators_of(epoch):
+    out = []
+    for e in json.load(open(os.path.join(E, epoch, "validators.json")))["result"]:
         assert e["validator_stake_struct_version"] == "V1" and e["public_key"].startswith("ed25519:")
         acc = e["account_id"].encode()
-        validators.append(b"\0" + len(acc).to_bytes(4, "little") + acc + b"\0" + b58d(e["public_key"][8:], 32)
-                          + int(e["stake"]).to_bytes(16, "little"))
-    ep1 = block(os.path.join(E, EPOCH_I1, "block-0.json"))
-    ep2 = block(os.path.join(E, EPOCH_I2, "block-last.json"))
-    assert hashlib.sha256(len(validators).to_bytes(4, "little") + b"".join(validators)).hexdigest() == ep1["bp_hash"]
-    blocks = [block(os.path.join(E, EPOCH_I, "random-%d.json" % k)) for k in (4, 3, 2, 1, 0)]      # set_blocks order
-    assert all(blocks[k]["prev_hash"] == blocks[k + 1]["hash"] for k in range(4)) and blocks[4]["epoch_id"] == ep2["hash"]
-    out = {"source": "data/epochs/{%s,%s,%s} of the reference (NEAR mainnet, heights %d..%d)" % (EPOCH_I[:6], EPOCH_I1[:6],
-                                                                                           EPOCH_I2[:6], blocks[4]["height"],
-                                                                                           blocks[0]["height"]),
-           "ep1_first_block": ep1, "ep2_last_block": ep2, "blocks": blocks, "validators": [v.hex() for v in validators]}
-    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "block_window_HPi5.json")
+        out.append(b"\0" + len(acc).to_bytes(4, "little") + acc + b"\0" + b58d(e["public_key"][8:], 32) + int(e["stake"]).to_bytes(16, "little"))
+    return out
+
+
+def bp_hash(validators):
+    return hashlib.sha256(len(validators).to_bytes(4, "little") + b"".join(validators)).hexdigest()
+
+
+def dump(name, out):
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
     json.dump(out, open(dst, "w"), separators=(",", ":"))
     print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
+def main():
+    # a randomly selected block: bin/prove_random.rs:57-62
+    validators = validators_of(EPOCH_I)
+    ep1 = block(os.path.join(E, EPOCH_I1, "block-0.json"))
+    ep2 = block(os.path.join(E, EPOCH_I2, "block-last.json"))
+    assert bp_hash(validators) == ep1["bp_hash"]
+    blocks = [block(os.path.join(E, EPOCH_I, "random-%d.json" % k)) for k in (4, 3, 2, 1, 0)]      # set_blocks order
+    assert all(blocks[k]["prev_hash"] == blocks[k + 1]["hash"] for k in range(4)) and blocks[4]["epoch_id"] == ep2["hash"]
+    dump("block_window_HPi5.json",
+         {"source": "data/epochs/{%s,%s,%s} of the reference (NEAR mainnet, heights %d..%d)" % (EPOCH_I[:6], EPOCH_I1[:6], EPOCH_I2[:6],
+                                                                                           blocks[4]["height"], blocks[0]["height"]),
+          "ep1_first_block": ep1, "ep2_last_block": ep2, "blocks": blocks, "validators": [v.hex() for v in validators]})
+    # the epoch blocks Block_0(epoch i) and Block_n-1(epoch i-1): bin/prove_epoch.rs:222-232 (epoch i = CRTZ.., i-1 = HPi5.., ...)
+    ei, ei1, ei2, ei3 = "CRTZ7cQd77rvfS57Y7M36P1vLhran9HyQFEpTLxHRf9t", EPOCH_I, EPOCH_I1, EPOCH_I2
+    vals, vals_n_1 = validators_of(ei), validators_of(ei1)
+    e1, e2, e3 = (block(os.path.join(E, ei1, "block-0.json")), block(os.path.join(E, ei2, "block-last.json")),
+                  block(os.path.join(E, ei3, "block-last.json")))
+    blks = [block(os.path.join(E, ei, "block-%d.json" % k)) for k in (4, 3, 2, 1, 0)] + [block(os.path.join(E, ei1, "block-last.json"))]
+    assert bp_hash(vals) == e1["bp_hash"] and all(blks[k]["prev_hash"] == blks[k + 1]["hash"] for k in range(5))
+    dump("block_window_epoch_CRTZ.json",
+         {"source": "data/epochs/{%s,%s,%s,%s} of the reference (NEAR mainnet, heights %d..%d)" % (ei[:6], ei1[:6], ei2[:6], ei3[:6],
+                                                                                              blks[5]["height"], blks[0]["height"]),
+          "ep1_first_block": e1, "ep2_last_block": e2, "ep3_last_block": e3, "blocks": blks,
+          "validators": [v.hex() for v in vals], "validators_n_1": [v.hex() for v in vals_n_1]})
 
 
 if __name__ == "__main__":

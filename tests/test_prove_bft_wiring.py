@@ -161,3 +161,27 @@ def test_header_hash_chain_wiring():
     assert bh.prove_header_hash(f["hash"], raw[1:33], lite, rest, public_inputs=[1, 2])[2]["public_inputs"] == [1, 2]
     with pytest.raises(AssertionError):
         bh.prove_header_hash(f["prev_hash"], raw[1:33], lite, rest)
+
+
+def test_dag_wiring_epoch_blocks():
+    """the 6-block branch of prove_block_bft (bft.rs:334-496, the path of bin/prove_epoch.rs:222-232) on the reference's epoch data:
+    Block_0 of epoch CRTZ.. and Block_n-1 of epoch HPi5.., each with its own validator set and epoch-ancestor blocks"""
+    w = load_golden("block_window_epoch_CRTZ.json")
+    hx = bytes.fromhex
+    blocks = []
+    for blk in w["blocks"]:
+        f = {k: hx(blk[k]) for k in ("hash", "prev_hash", "epoch_id", "last_ds_final_hash", "last_final_hash")}
+        f["height"] = blk["height"]
+        f["approvals"] = [hx(a) for a in blk["approvals"]]
+        blocks.append((f, hx(blk["bytes"])))
+    ap = FakeApprovals()
+    bp = BlockProver(None, parts=(ap, FakeHashes(), FakeKeys(), FakePrims()))
+    b0, bn_1 = bp.prove_block_bft(hx(w["ep2_last_block"]["bytes"]), hx(w["ep2_last_block"]["hash"]), hx(w["ep1_first_block"]["bytes"]),
+                                  hx(w["ep1_first_block"]["hash"]), blocks, [hx(v) for v in w["validators"]],
+                                  ep3_last_block_bytes=hx(w["ep3_last_block"]["bytes"]), ep3_last_block_hash=hx(w["ep3_last_block"]["hash"]),
+                                  validators_n_1=[hx(v) for v in w["validators_n_1"]])
+    assert b0[2]["public_inputs"] == [1] + list(hx(w["blocks"][4]["hash"])) + list(hx(w["ep2_last_block"]["hash"])) + \
+        list(hx(w["ep1_first_block"]["hash"]))
+    assert bn_1[2]["public_inputs"] == [1] + list(hx(w["blocks"][5]["hash"])) + list(hx(w["ep3_last_block"]["hash"])) + \
+        list(hx(w["ep2_last_block"]["hash"]))
+    assert len(ap.msgs) == 2 and bp.counts["prove_header_hash"] == 9 and bp.counts["prove_valid_keys_stakes"] == 2
