@@ -194,6 +194,8 @@ uint32_t zklc_plonky2_last_timings(zklc_plonky2_circuit *c, double *out_ms, uint
 /* PoseidonGate witness rows (host function, no GPU): inputs n x 12, swap n (0/1, NULL = all 0) -> rows n x 135
  * in the wire layout of gnark-plonky2-verifier/plonk/gates/poseidon_gate.go:27-82 */
 int32_t zklc_poseidon_gl_gate_rows(const uint64_t *inputs, const uint64_t *swap, uint32_t n, uint64_t *rows);
+/* out[i] = a[i] * b[i] in the Goldilocks field (host function; canonical inputs): the circuit builder's sigma values */
+void zklc_gl_mul_vec(const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n);
 /* Poseidon-Goldilocks parameters (gnark-plonky2-verifier/poseidon/goldilocks_constants.go): all round constants (30 x 12),
  * the optimised partial-round constants (first layer 12, one per round 22), MDS circulant + diagonal.  Used by the host
  * circuit builder to restate PoseidonGate's constraints in-circuit (recursive verifier). */

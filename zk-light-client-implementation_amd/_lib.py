@@ -75,6 +75,7 @@ _SIGS = {
     "zklc_poseidon_gl_gate_rows": (ctypes.c_int32, [_u8p, _u8p, ctypes.c_uint32, _u8p]),
     "zklc_plonky2_witness_release": (None, []),
     "zklc_poseidon_gl_constants": (None, [_u8p, _u8p, _u8p, _u8p, _u8p]),
+    "zklc_gl_mul_vec": (None, [_u8p, _u8p, _u8p, ctypes.c_uint64]),
     "zklc_plonky2_witness_run": (ctypes.c_int32, [_u8p, ctypes.c_uint64, _u8p, ctypes.c_uint32, _u8p, ctypes.c_uint32, _u8p,
                                                   ctypes.c_uint32, _u8p, _u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _u8p,
                                                   _u8p, ctypes.c_uint32, _u8p, _u8p, ctypes.c_char_p, ctypes.c_uint32]),

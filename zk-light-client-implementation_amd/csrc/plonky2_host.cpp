@@ -51,6 +51,11 @@ uint64_t zklc_challenger::challenge() {
 
 // One PoseidonGate row per input state: wires 0..12 inputs, 12..24 outputs, 24 swap, 25..29 deltas,
 // 29..65 / 65..87 / 87..135 the S-box inputs (gnark-plonky2-verifier/plonk/gates/poseidon_gate.go:27-82).
+// elementwise Goldilocks products of canonical values (circuit preprocessing on the host: sigma values k_is[col] * w^row)
+extern "C" void zklc_gl_mul_vec(const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) out[i] = gl_mul(a[i], b[i]);
+}
+
 extern "C" void zklc_poseidon_gl_constants(uint64_t *rc360, uint64_t *fp_first12, uint64_t *fp_rc22, uint64_t *mds_circ12, uint64_t *mds_diag12) {
     for (int i = 0; i < 360; i++) rc360[i] = PGL_RC[i];
     for (int i = 0; i < 12; i++) fp_first12[i] = PGL_FP_FIRST[i];

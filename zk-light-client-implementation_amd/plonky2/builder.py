@@ -780,7 +780,10 @@ class CircuitData:
         # sigma_j(w^i) = k_is[col'] * w^(row'): one field multiplication per cell
         sub_arr = np.array(sub, dtype=np.uint64)
         k_arr = np.array(self.k_is, dtype=np.uint64)
-        sig = gl_mul_np(k_arr[sig_col], sub_arr[sig_row])
+        from .. import _lib
+        ka, sa = np.ascontiguousarray(k_arr[sig_col]), np.ascontiguousarray(sub_arr[sig_row])
+        sig = np.empty_like(ka)
+        _lib.load().zklc_gl_mul_vec(ka.ctypes.data, sa.ctypes.data, sig.ctypes.data, ka.size)
         self.sigmas = sig
         self.fri_arity_bits = fri_reduction_arity_bits(cfg, self.degree_bits)
         self.num_public_inputs = num_public_inputs
