@@ -81,3 +81,37 @@ def test_msm_sharded_world2_matches_single():
     for rank, out, inf, bitmap in res:
         assert inf == winf and out == want.tolist()
         assert bitmap == [int(i % 4 != 3) for i in range(10)]
+
+
+def _proof_worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib
+    D = importlib.import_module("zk-light-client-implementation_amd.distributed")
+    calls = []
+
+    def prove_one(i):          # stands in for one Ed25519-circuit proof: ragged lengths, content tied to the index
+        calls.append(i)
+        return bytes([(7 * i + k) & 0xFF for k in range(100 + 13 * (i % 5))])
+    out = D.prove_signatures_sharded(prove_one, n)
+    q.put((rank, calls, [p.hex() for p in out], D.gather_bytes([]) == [[] for _ in range(world)]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [7, 2, 1])
+def test_signature_proofs_sharded_over_two_ranks(n):
+    """signature i -> rank i mod world, all-gather of the (ragged) proof bytes, every rank ends with the n proofs in
+    signature order -- what the left fold consumes"""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_proof_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+    want = [bytes([(7 * i + k) & 0xFF for k in range(100 + 13 * (i % 5))]).hex() for i in range(n)]
+    for rank, calls, out, empty_ok in res:
+        assert calls == list(range(rank, n, world)) and out == want and empty_ok

@@ -38,3 +38,55 @@ def msm_sharded(local_msm, combine_msm, points_shard, scalars_shard, group=None,
     ones = np.zeros((world, 4), dtype=np.uint64)
     ones[:, 0] = 1
     return combine_msm(pts, ones)
+
+
+def gather_bytes(chunks, group=None, device=None):
+    """ALL-GATHER of variable-length byte strings: every rank contributes a list of `bytes` and gets the list of all ranks'
+    lists (rank order).  Two collectives: the lengths, then the zero-padded payloads (RCCL has no ragged gather; a signature proof
+    is ~190 KB, so a padded all_gather of a few MB per rank is far below what xGMI moves in a millisecond)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return [list(chunks)]
+    lens = torch.tensor([len(chunks)] + [len(c) for c in chunks], dtype=torch.int64, device=device)
+    n_max = torch.tensor([lens.numel()], dtype=torch.int64, device=device)
+    dist.all_reduce(n_max, op=dist.ReduceOp.MAX, group=group)
+    pad = torch.zeros(int(n_max), dtype=torch.int64, device=device)
+    pad[:lens.numel()] = lens
+    all_lens = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(all_lens, pad, group=group)
+    all_lens = [t.cpu().tolist() for t in all_lens]
+    total = max(sum(t[1:1 + t[0]]) for t in all_lens)
+    buf = torch.zeros(max(total, 1), dtype=torch.uint8, device=device)
+    blob = b"".join(chunks)
+    if blob:
+        buf[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(buf.device)
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    out = []
+    for t, b in zip(all_lens, bufs):
+        raw, off, items = b.cpu().numpy().tobytes(), 0, []
+        for ln in t[1:1 + t[0]]:
+            items.append(raw[off:off + ln])
+            off += ln
+        out.append(items)
+    return out
+
+
+def prove_signatures_sharded(prove_one, n, group=None, device=None):
+    """One block's signature proofs over the GPUs of a node: signature i is proven by rank i mod world
+    (`prove_one(i) -> bytes`, no data dependence between signatures: signatures.rs:70-123), the proofs are all-gathered, and every
+    rank returns the n proofs in signature order -- the order the left fold of signatures.rs:97-105 consumes them in, so the
+    aggregate is the one a single GPU would produce."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    mine = [prove_one(i) for i in range(rank, n, world)]
+    parts = gather_bytes(mine, group=group, device=device)
+    out = [None] * n
+    for r, items in enumerate(parts):
+        for k, p in enumerate(items):
+            out[r + k * world] = p
+    assert all(p is not None for p in out)
+    return out
