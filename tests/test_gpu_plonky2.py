@@ -210,9 +210,11 @@ def test_prove_approvals_on_the_reference_small_fixture(zctx, approval_prover):
     seen = []
     orig = rec.recursive_proof
 
-    def checked(first, second=None, public_inputs=None):
-        rc, proof = orig(first, second, public_inputs)
-        V.verify(json.loads(json.dumps(proof)), rc.verifier_only, rc.common)
+    def checked(first, second=None, public_inputs=None, **kw):
+        # prove_approvals hands proofs over as `to_bytes` bytes between fold steps (raw=True): check what it really passes on
+        rc, proof = orig(first, second, public_inputs, **kw)
+        as_json = S.proof_from_bytes(proof, rc.common, HASH_GL) if isinstance(proof, (bytes, bytearray)) else proof
+        V.verify(json.loads(json.dumps(as_json)), rc.verifier_only, rc.common)
         seen.append((rc.data.n, len(rc.common["gates"]), rc.prover.last_timings()["total"]))
         return rc, proof
     rec.recursive_proof = checked
