@@ -645,6 +645,17 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     block = st["result"]["block"]
     want = [0] + list(hx(win["blocks"][4]["hash"])) + list(hx(win["ep2_last_block"]["hash"])) + list(hx(win["ep1_first_block"]["hash"]))
     assert block[2]["public_inputs"] == want, "block proof public inputs"
+    # checker role, untimed: the last two proofs of the DAG -- the Block_i proof and its Poseidon-BN128 wrap -- are the only ones no
+    # later recursion witness checks, so the verifier restatement (pinned by the reference's golden proofs) checks them here
+    # (prove_crypto/recursion.rs:53,81 verify every inner proof natively; bin/prove_block.rs:279-287 is the wrap)
+    from oracle import plonky2_verifier as V
+    t_v = time.perf_counter()
+    V.verify(json.loads(json.dumps(block[2])), block[1], block[0])
+    wrc, wraw = st["result"]["wrap"]
+    wrap_json = S.proof_from_bytes(wraw, wrc.common, HASH_BN128)
+    V.verify(json.loads(json.dumps(wrap_json)), wrc.verifier_only, wrc.common)
+    assert wrap_json["public_inputs"] == want, "wrap proof public inputs"
+    t_v = time.perf_counter() - t_v
     tw, fold_host, result = st["tw"], st["fold_host"], st["result"]
     out["block_i"] = {"metric": "full Block_i BFT-finality proofs/s (prove_block_bft on NEAR mainnet blocks 121798939..43, 100 validators, %d "
                                 "approvals), end to end from the header / approval / validator bytes: GPU pre-verification, native witness "
@@ -658,6 +669,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                       "dag_thread_seconds": {k: round(v, 3) for k, v in bprover.seconds.items()},
                       "dag_thread_counts": dict(bprover.counts), "keys_stakes_thread_seconds": result.get("keys_stakes_s"),
                       "wrap_proof_bytes": len(result["wrap"][1]),
+                      "final_proof_verified": True, "final_proof_verify_s_untimed": t_v,
                       "first_block_s_incl_circuit_construction": t_setup,
                       "cpu_baseline": None,
                       "note": "every proof is a proof of the reference's own circuit (restated) on the reference's own mainnet data; "
@@ -820,6 +832,7 @@ def main():
                                                         "kernel time of a block proof", kernel_ms=mk["ms"],
                                  note="measured live by the `merkle` stage (HIP events on the launch stream): 2^20 leaves x 234 columns; "
                                       + mk["roofline"]["note"]),
+                "final_proof_verified": blk["final_proof_verified"],
                 "block_i": blk, "stages": dict(stages, ed25519_verify=verify),
             }
             if "cpu_baseline" in edp:
