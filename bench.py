@@ -598,7 +598,8 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
             bi, _ = bprover.prove_block_bft(hx(win["ep2_last_block"]["bytes"]), hx(win["ep2_last_block"]["hash"]),
                                             hx(win["ep1_first_block"]["bytes"]), hx(win["ep1_first_block"]["hash"]), win_blocks, validators)
             st["result"]["block"] = bi
-            st["result"]["wrap"] = rpw_block.recursive_proof(bi, raw=True)
+            # bin/prove_block.rs:279-287: recursive_proof::<F, Cbn128, C, D>((..bi..), None, Some(&bi_proof.public_inputs))
+            st["result"]["wrap"] = rpw_block.recursive_proof(bi, None, list(bi[2]["public_inputs"]), raw=True)
         except Exception as e:  # pragma: no cover
             fail(e)
 
