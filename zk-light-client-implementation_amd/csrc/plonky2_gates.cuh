@@ -75,6 +75,23 @@ struct p2_vars {
     ZKLC_M gl2 wa(u32 j) const { return gl2_make(w(j), w(j + 1)); }
 };
 
+#if defined(__HIPCC__)
+// The same accessors over a tile staged in LDS by the fused quotient kernel (plonky2_prover.hip): column j of the tile holds
+// the values of wire (or constant) j at the 64 LDE points of the workgroup, so lane l reads tile[j * 64 + l] -- one
+// conflict-free ds_read_b64 per access instead of a global load per gate launch.
+typedef __attribute__((address_space(3))) const u64 p2_lds_u64;
+struct p2_vars_lds {
+    p2_lds_u64 *wires;   // [num_wires][64]
+    p2_lds_u64 *consts;  // [num_constants][64]
+    u32 lane, nsel;
+    u64 pih[4];
+    ZKLC_M u64 w(u32 j) const { return wires[j * 64 + lane]; }
+    ZKLC_M u64 c(u32 j) const { return consts[(nsel + j) * 64 + lane]; }
+    ZKLC_M u64 sel(u32 j) const { return consts[j * 64 + lane]; }
+    ZKLC_M gl2 wa(u32 j) const { return gl2_make(w(j), w(j + 1)); }
+};
+#endif
+
 // prod_{k < base} (x - k); the result is LOOSE (any u64 congruent to it: what p2_consumer::emit multiplies by alpha^k).
 // The two-bit limbs of the u32 gates dominate the constraint count of the Ed25519 circuit: x (x-1)(x-2)(x-3) = y (y + 2) with
 // y = x (x - 3) takes two multiplications instead of three.
@@ -95,15 +112,18 @@ ZKLC_D u64 p2_mul4_loose(u64 a) {
 // Horner step of sum_j limb_j 4^j: loose accumulator, canonical limb
 ZKLC_D u64 p2_horner4(u64 acc, u64 limb) { return gl_add_lc(p2_mul4_loose(acc), limb); }
 
-ZKLC_D void p2_eval_constant(const p2_vars &v, u32 n, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_constant(const V &v, u32 n, p2_consumer &out) {
     for (u32 i = 0; i < n; i++) out.emit(gl_sub(v.c(i), v.w(i)));
 }
 
-ZKLC_D void p2_eval_public_input(const p2_vars &v, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_public_input(const V &v, p2_consumer &out) {
     for (u32 i = 0; i < 4; i++) out.emit(gl_sub(v.w(i), v.pih[i]));
 }
 
-ZKLC_D void p2_eval_arithmetic(const p2_vars &v, u32 num_ops, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_arithmetic(const V &v, u32 num_ops, p2_consumer &out) {
     u64 c0 = v.c(0), c1 = v.c(1);
     for (u32 i = 0; i < num_ops; i++) {
         u64 m0 = v.w(4 * i), m1 = v.w(4 * i + 1), a = v.w(4 * i + 2), o = v.w(4 * i + 3);
@@ -111,7 +131,8 @@ ZKLC_D void p2_eval_arithmetic(const p2_vars &v, u32 num_ops, p2_consumer &out) 
     }
 }
 
-ZKLC_D void p2_eval_arithmetic_ext(const p2_vars &v, u32 num_ops, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_arithmetic_ext(const V &v, u32 num_ops, p2_consumer &out) {
     u64 c0 = v.c(0), c1 = v.c(1);
     for (u32 i = 0; i < num_ops; i++) {
         gl2 m0 = v.wa(8 * i), m1 = v.wa(8 * i + 2), a = v.wa(8 * i + 4), o = v.wa(8 * i + 6);
@@ -120,7 +141,8 @@ ZKLC_D void p2_eval_arithmetic_ext(const p2_vars &v, u32 num_ops, p2_consumer &o
     }
 }
 
-ZKLC_D void p2_eval_mul_ext(const p2_vars &v, u32 num_ops, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_mul_ext(const V &v, u32 num_ops, p2_consumer &out) {
     u64 c0 = v.c(0);
     for (u32 i = 0; i < num_ops; i++) {
         gl2 m0 = v.wa(6 * i), m1 = v.wa(6 * i + 2), o = v.wa(6 * i + 4);
@@ -128,7 +150,8 @@ ZKLC_D void p2_eval_mul_ext(const p2_vars &v, u32 num_ops, p2_consumer &out) {
     }
 }
 
-ZKLC_D void p2_eval_base_sum(const p2_vars &v, u32 num_limbs, u32 base, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_base_sum(const V &v, u32 num_limbs, u32 base, p2_consumer &out) {
     u64 acc = 0;
     if (base == 2)
         for (u32 i = num_limbs; i-- > 0;) acc = gl_add(gl_add(acc, acc), v.w(1 + i));
@@ -142,7 +165,8 @@ ZKLC_D void p2_eval_base_sum(const p2_vars &v, u32 num_limbs, u32 base, p2_consu
 }
 
 // poseidon_gate.go:84-181
-ZKLC_D void p2_eval_poseidon(const p2_vars &v, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_poseidon(const V &v, p2_consumer &out) {
     u64 swap = v.w(24);
     out.emit(gl_mul(swap, gl_sub(swap, 1)));
     u64 s[12];
@@ -224,7 +248,8 @@ ZKLC_D void p2_eval_poseidon(const p2_vars &v, p2_consumer &out) {
     for (int i = 0; i < 12; i++) out.emit(gl_sub(s[i], v.w(12 + i)));
 }
 
-ZKLC_D void p2_eval_poseidon_mds(const p2_vars &v, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_poseidon_mds(const V &v, p2_consumer &out) {
     const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     for (u32 r = 0; r < 12; r++) {
         gl2 acc = gl2_make(0, 0);
@@ -234,7 +259,8 @@ ZKLC_D void p2_eval_poseidon_mds(const p2_vars &v, p2_consumer &out) {
     }
 }
 
-ZKLC_D void p2_eval_random_access(const p2_vars &v, u32 bits, u32 copies, u32 extra, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_random_access(const V &v, u32 bits, u32 copies, u32 extra, p2_consumer &out) {
     const u32 vs = 1u << bits;
     const u32 routed = (2 + vs) * copies + extra;
     for (u32 cp = 0; cp < copies; cp++) {
@@ -261,7 +287,8 @@ ZKLC_D void p2_eval_random_access(const p2_vars &v, u32 bits, u32 copies, u32 ex
     for (u32 i = 0; i < extra; i++) out.emit(gl_sub(v.c(i), v.w((2 + vs) * copies + i)));
 }
 
-ZKLC_D void p2_eval_reducing(const p2_vars &v, u32 n, bool ext, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_reducing(const V &v, u32 n, bool ext, p2_consumer &out) {
     gl2 alpha = v.wa(2), acc = v.wa(4);
     const u32 start_accs = 6 + (ext ? 2 * n : n);
     for (u32 i = 0; i < n; i++) {
@@ -272,7 +299,8 @@ ZKLC_D void p2_eval_reducing(const p2_vars &v, u32 n, bool ext, p2_consumer &out
     }
 }
 
-ZKLC_D void p2_eval_exponentiation(const p2_vars &v, u32 n, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_exponentiation(const V &v, u32 n, p2_consumer &out) {
     u64 base = v.w(0);
     u64 prev_inter = 0;
     for (u32 i = 0; i < n; i++) {
@@ -287,7 +315,8 @@ ZKLC_D void p2_eval_exponentiation(const p2_vars &v, u32 n, p2_consumer &out) {
 }
 
 // coset_interpolation_gate.go:152-226; extra = [barycentric weights (2^bits) | subgroup points w^i (2^bits)]
-ZKLC_D void p2_coset_partial(const p2_vars &v, const u64 *extra, u32 np, u32 s, u32 e, gl2 point, gl2 &ev, gl2 &prod) {
+template <class V>
+ZKLC_D void p2_coset_partial(const V &v, const u64 *extra, u32 np, u32 s, u32 e, gl2 point, gl2 &ev, gl2 &prod) {
     for (u32 i = s; i < e; i++) {
         gl2 term = gl2_sub(point, gl2_make(extra[np + i], 0));
         gl2 wv = gl2_scale(v.wa(1 + 2 * i), extra[i]);
@@ -295,7 +324,8 @@ ZKLC_D void p2_coset_partial(const p2_vars &v, const u64 *extra, u32 np, u32 s, 
         prod = gl2_mul(prod, term);
     }
 }
-ZKLC_D void p2_eval_coset_interpolation(const p2_vars &v, u32 bits, u32 degree, const u64 *extra, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_coset_interpolation(const V &v, u32 bits, u32 degree, const u64 *extra, p2_consumer &out) {
     const u32 np = 1u << bits;
     const u32 n_inter = (np - 2) / (degree - 1);
     const u32 start_pt = 1 + 2 * np, start_val = start_pt + 2, start_inter = start_val + 2;
@@ -318,7 +348,8 @@ ZKLC_D void p2_eval_coset_interpolation(const p2_vars &v, u32 bits, u32 degree, 
 }
 
 // crypto/plonky2_u32/src/gates/arithmetic_u32.rs:110-165
-ZKLC_D void p2_eval_u32_arithmetic(const p2_vars &v, u32 num_ops, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_u32_arithmetic(const V &v, u32 num_ops, p2_consumer &out) {
     for (u32 i = 0; i < num_ops; i++) {
         u64 m0 = v.w(6 * i), m1 = v.w(6 * i + 1), add = v.w(6 * i + 2), lo = v.w(6 * i + 3), hi = v.w(6 * i + 4),
             inv = v.w(6 * i + 5);
@@ -342,7 +373,8 @@ ZKLC_D void p2_eval_u32_arithmetic(const p2_vars &v, u32 num_ops, p2_consumer &o
 }
 
 // add_many_u32.rs: per op (num_addends + 3) routed wires, then 16 + 2 two-bit limbs
-ZKLC_D void p2_eval_u32_add_many(const p2_vars &v, u32 num_addends, u32 num_ops, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_u32_add_many(const V &v, u32 num_addends, u32 num_ops, p2_consumer &out) {
     const u32 per = num_addends + 3;
     for (u32 i = 0; i < num_ops; i++) {
         u64 sum = v.w(per * i + num_addends);  // carry in
@@ -364,7 +396,8 @@ ZKLC_D void p2_eval_u32_add_many(const p2_vars &v, u32 num_addends, u32 num_ops,
 }
 
 // subtraction_u32.rs: per op (x, y, borrow_in, result, borrow_out), then 16 two-bit limbs of result
-ZKLC_D void p2_eval_u32_subtraction(const p2_vars &v, u32 num_ops, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_u32_subtraction(const V &v, u32 num_ops, p2_consumer &out) {
     for (u32 i = 0; i < num_ops; i++) {
         u64 x = v.w(5 * i), y = v.w(5 * i + 1), bin = v.w(5 * i + 2), res = v.w(5 * i + 3), bout = v.w(5 * i + 4);
         u64 initial = gl_sub(gl_sub(x, y), bin);
@@ -381,7 +414,8 @@ ZKLC_D void p2_eval_u32_subtraction(const p2_vars &v, u32 num_ops, p2_consumer &
 }
 
 // range_check_u32.rs: n input limbs, each with 16 two-bit aux limbs
-ZKLC_D void p2_eval_u32_range_check(const p2_vars &v, u32 n, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_u32_range_check(const V &v, u32 n, p2_consumer &out) {
     for (u32 i = 0; i < n; i++) {
         u64 sum = 0;
         for (u32 j = 16; j-- > 0;) sum = p2_horner4(sum, v.w(n + 16 * i + j));
@@ -391,7 +425,8 @@ ZKLC_D void p2_eval_u32_range_check(const p2_vars &v, u32 n, p2_consumer &out) {
 }
 
 // comparison.rs:106-190
-ZKLC_D void p2_eval_comparison(const p2_vars &v, u32 num_bits, u32 num_chunks, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_comparison(const V &v, u32 num_bits, u32 num_chunks, p2_consumer &out) {
     const u32 chunk_bits = (num_bits + num_chunks - 1) / num_chunks;
     const u32 chunk_size = 1u << chunk_bits;
     u64 c1 = 0, c2 = 0;
@@ -436,7 +471,8 @@ ZKLC_D void p2_eval_comparison(const p2_vars &v, u32 num_bits, u32 num_chunks, p
 
 // interleave_u32.rs:103-139: per op (x, x_interleaved) routed, then 32 big-endian bits; x = sum bits 2^(31-j),
 // x_interleaved = sum bits 4^(31-j) (the bits of x spread over the even positions of a 64-bit word)
-ZKLC_D void p2_eval_u32_interleave(const p2_vars &v, u32 num_ops, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_u32_interleave(const V &v, u32 num_ops, p2_consumer &out) {
     for (u32 i = 0; i < num_ops; i++) {
         u64 x = 0, xi = 0;
         for (u32 j = 0; j < 32; j++) {
@@ -451,7 +487,8 @@ ZKLC_D void p2_eval_u32_interleave(const p2_vars &v, u32 num_ops, p2_consumer &o
 }
 // uninterleave_to_u32.rs:112-159 / uninterleave_to_b32.rs: per op (x_interleaved, evens, odds) routed, then 64 big-endian bits;
 // evens / odds collect bits 2j / 2j+1 with weights 2^(31-j) (to_u32) or 4^(31-j) (to_b32: the halves stay interleaved)
-ZKLC_D void p2_eval_uninterleave(const p2_vars &v, u32 num_ops, bool to_b32, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_uninterleave(const V &v, u32 num_ops, bool to_b32, p2_consumer &out) {
     for (u32 i = 0; i < num_ops; i++) {
         u64 x = 0, ev = 0, od = 0;
         for (u32 j = 0; j < 32; j++) {
@@ -472,7 +509,8 @@ ZKLC_D void p2_eval_uninterleave(const p2_vars &v, u32 num_ops, bool to_b32, p2_
     }
 }
 
-ZKLC_D void p2_eval_gate(const p2_gate &g, const p2_vars &v, const u64 *extra, p2_consumer &out) {
+template <class V>
+ZKLC_D void p2_eval_gate(const p2_gate &g, const V &v, const u64 *extra, p2_consumer &out) {
     switch (g.type) {
         case P2_NOOP: break;
         case P2_CONSTANT: p2_eval_constant(v, g.p[0], out); break;

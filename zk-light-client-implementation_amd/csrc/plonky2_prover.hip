@@ -12,7 +12,10 @@
 // directly and a wave of 64 consecutive points reads 512 contiguous bytes of every column.  FRI oracles are arrays of
 // extension elements (2 x u64), i.e. row-major leaves of 2 * arity words.  The Fiat-Shamir transcript (a few hundred
 // Poseidon permutations) runs on the host between kernels (plonky2_host.cpp).
+#include <algorithm>
 #include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include <new>
 #include <vector>
 #include <string.h>
@@ -164,6 +167,8 @@ struct p2_quotient_args {
     p2_challenges ch;
     const u64 *apow[P2_MAX_CH];     // powers of the alphas, one table per challenge
     u64 *out;                       // [nch][N]
+    const u64 *xs, *l0;             // per LDE point (bit-reversed order): x = g w^bitrev(p) and L_0(x) = (x^n - 1) / (n (x - 1))
+    u32 num_wires;
 };
 
 // vanishing_poly.rs `eval_vanishing_poly_base_batch` at the point stored at position p, divided by Z_H.
@@ -175,10 +180,9 @@ __global__ void __launch_bounds__(P2_THREADS) p2_quotient_base_kernel(p2_quotien
     size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     u64 i = __brevll((u64)p) >> (64 - a.lde_bits);  // natural index on the coset
-    u64 x = gl_mul(GL_GENERATOR, gl_pow(a.w_lde, i));
+    u64 x = a.xs[p];
     const u32 coset = (u32)i & ((1u << a.rate_bits) - 1);
-    // L_0(x) = (x^n - 1) / (n (x - 1))
-    u64 l0 = gl_mul(a.zh[coset], gl_inv(gl_mul(a.n_field, gl_sub(x, 1))));
+    u64 l0 = a.l0[p];
     u64 i_next = (i + (1ULL << a.rate_bits)) & (N - 1);
     size_t p_next = (size_t)(__brevll(i_next) >> (64 - a.lde_bits));
 
@@ -249,6 +253,136 @@ static p2_gate_kernel_fn p2_gate_kernel_of(u32 type) {
         P2_CASE(P2_U32_INTERLEAVE) P2_CASE(P2_UNINTERLEAVE_TO_U32) P2_CASE(P2_UNINTERLEAVE_TO_B32)
 #undef P2_CASE
         default: return nullptr;   // P2_NOOP: no constraints
+    }
+}
+
+// The fused form.  The per-gate launches above read the wire matrix once per gate type (~16x the algorithmic bytes for the 20
+// gate types of the Ed25519 circuit); here a workgroup stages the constants and wires of 64 consecutive LDE points in LDS once
+// ([column][64 points]: a lane's access is one conflict-free ds_read_b64) and its waves share the tile: every wave evaluates
+// its own sub-list of jobs (a job = one gate of the list, or the L_0 / partial-product terms) for the same 64 points, the
+// per-wave sums are added through LDS.  The job lists are balanced on the host from the measured cost of each gate
+// (p2_plan_quotient).  Same field values as the per-gate form (the sum over gates commutes), so the proof bytes do not change.
+#define P2_FQ_MAX_WAVES 8
+#define P2_FQ_MAX_JOBS 40
+#define P2_JOB_BASE 0xFFFFu
+struct p2_fused_plan {
+    u32 nwaves;
+    u32 njobs[P2_FQ_MAX_WAVES];
+    uint16_t jobs[P2_FQ_MAX_WAVES][P2_FQ_MAX_JOBS];
+};
+
+__global__ void __launch_bounds__(64 * P2_FQ_MAX_WAVES) p2_quotient_fused_kernel(p2_quotient_args a, p2_fused_plan plan) {
+    extern __shared__ u64 p2_tile[];   // [num_constants + num_wires][64], then [nwaves][P2_MAX_CH][64] partial sums
+    const size_t N = (size_t)1 << a.lde_bits;
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t p = (size_t)blockIdx.x * 64 + lane;
+    const u32 ncols = a.num_constants + a.num_wires;
+    {   // stage the tile: wave w takes columns w, w + nwaves, ...; eight loads in flight per lane
+        u32 j = wave;
+        for (; j + 7 * plan.nwaves < ncols; j += 8 * plan.nwaves) {
+            u64 t[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                u32 jj = j + q * plan.nwaves;
+                const u64 *src = jj < a.num_constants ? a.cs + (size_t)jj * N : a.wires + (size_t)(jj - a.num_constants) * N;
+                t[q] = src[p];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) p2_tile[(size_t)(j + q * plan.nwaves) * 64 + lane] = t[q];
+        }
+        for (; j < ncols; j += plan.nwaves) {
+            const u64 *src = j < a.num_constants ? a.cs + (size_t)j * N : a.wires + (size_t)(j - a.num_constants) * N;
+            p2_tile[(size_t)j * 64 + lane] = src[p];
+        }
+    }
+    __syncthreads();
+    p2_vars_lds v;
+    v.consts = (p2_lds_u64 *)p2_tile;
+    v.wires = v.consts + (size_t)a.num_constants * 64;
+    v.lane = lane;
+    v.nsel = a.nsel;
+    for (int k = 0; k < 4; k++) v.pih[k] = a.pih[k];
+    u64 sum[P2_MAX_CH] = {0, 0};
+    p2_consumer out;
+    out.nch = a.nch;
+    for (int c = 0; c < P2_MAX_CH; c++) out.apow[c] = a.apow[c];
+    const u32 njobs = plan.njobs[wave];
+    for (u32 jb = 0; jb < njobs; jb++) {
+        const u32 g = plan.jobs[wave][jb];
+        if (g == P2_JOB_BASE) {
+            u64 i = __brevll((u64)p) >> (64 - a.lde_bits);
+            u64 x = a.xs[p], l0 = a.l0[p];
+            u64 i_next = (i + (1ULL << a.rate_bits)) & (N - 1);
+            size_t p_next = (size_t)(__brevll(i_next) >> (64 - a.lde_bits));
+            out.reset(0);
+            for (u32 c = 0; c < a.nch; c++) out.emit(gl_mul(l0, gl_sub(a.zs[(size_t)c * N + p], 1)));
+            const u32 nchunks = a.npp + 1;
+            for (u32 c = 0; c < a.nch; c++) {
+                u64 beta = a.ch.beta[c], gamma = a.ch.gamma[c];
+                u64 prev = a.zs[(size_t)c * N + p];
+                for (u32 k = 0; k < nchunks; k++) {
+                    u64 np = 1, dp = 1;
+                    u32 end = (k + 1) * a.qdf < a.routed ? (k + 1) * a.qdf : a.routed;
+                    for (u32 j = k * a.qdf; j < end; j++) {
+                        u64 w = gl_add(v.w(j), gamma);
+                        np = gl_mul(np, gl_add(w, gl_mul(beta, gl_mul(a.k_is[j], x))));
+                        dp = gl_mul(dp, gl_add(w, gl_mul(beta, a.cs[(size_t)(a.num_constants + j) * N + p])));
+                    }
+                    u64 next = k + 1 < nchunks ? a.zs[(size_t)(a.nch + c * a.npp + k) * N + p] : a.zs[(size_t)c * N + p_next];
+                    out.emit(gl_sub(gl_mul(prev, np), gl_mul(next, dp)));
+                    prev = next;
+                }
+            }
+            for (u32 c = 0; c < a.nch; c++) sum[c] = gl_add(sum[c], out.result((int)c));
+            continue;
+        }
+        p2_gate gate = a.gates[g];
+        out.reset(a.nch + a.nch * (a.npp + 1));
+        p2_eval_gate(gate, v, a.extra, out);
+        u64 f = p2_filter(g, gate.group_start, gate.group_end, v.sel(gate.selector_index), a.nsel > 1);
+        for (u32 c = 0; c < a.nch; c++) sum[c] = gl_add(sum[c], gl_mul(f, out.result((int)c)));
+    }
+    u64 *part = p2_tile + (size_t)ncols * 64;
+    for (u32 c = 0; c < a.nch; c++) part[((size_t)wave * P2_MAX_CH + c) * 64 + lane] = sum[c];
+    __syncthreads();
+    if (wave == 0) {
+        u64 i = __brevll((u64)p) >> (64 - a.lde_bits);
+        const u32 coset = (u32)i & ((1u << a.rate_bits) - 1);
+        for (u32 c = 0; c < a.nch; c++) {
+            u64 t = sum[c];
+            for (u32 w = 1; w < plan.nwaves; w++) t = gl_add(t, part[((size_t)w * P2_MAX_CH + c) * 64 + lane]);
+            a.out[(size_t)c * N + p] = gl_mul(t, a.zh_inv[coset]);
+        }
+    }
+}
+
+// x = g w^bitrev(p) and L_0(x) for every LDE point (circuit constants): the L_0 denominators n (x - 1) are inverted with one
+// field inversion per 256 points (Montgomery's trick inside a workgroup's scan would be overkill: one lane = 4 points)
+__global__ void __launch_bounds__(256) p2_point_tables_kernel(u64 *xs, u64 *l0, u32 lde_bits, u32 rate_bits, u64 w_lde, u64 n_field,
+                                                               p2_quotient_args zhsrc) {
+    const size_t N = (size_t)1 << lde_bits;
+    size_t p0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (p0 >= N) return;
+    u64 x[4], d[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        u64 i = __brevll((u64)(p0 + q)) >> (64 - lde_bits);
+        x[q] = gl_mul(GL_GENERATOR, gl_pow(w_lde, i));
+        d[q] = gl_mul(n_field, gl_sub(x[q], 1));
+    }
+    u64 p01 = gl_mul(d[0], d[1]), p012 = gl_mul(p01, d[2]), inv = gl_inv(gl_mul(p012, d[3]));
+    u64 i3 = gl_mul(inv, p012);
+    inv = gl_mul(inv, d[3]);
+    u64 i2 = gl_mul(inv, p01);
+    inv = gl_mul(inv, d[2]);
+    u64 i1 = gl_mul(inv, d[0]), i0 = gl_mul(inv, d[1]);
+    u64 di[4] = {i0, i1, i2, i3};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        u64 i = __brevll((u64)(p0 + q)) >> (64 - lde_bits);
+        xs[p0 + q] = x[q];
+        l0[p0 + q] = gl_mul(zhsrc.zh[(u32)i & ((1u << rate_bits) - 1)], di[q]);
     }
 }
 
@@ -465,6 +599,10 @@ struct zklc_plonky2_circuit {
     u64 *d_rp = nullptr, *d_excl = nullptr, *d_totals = nullptr, *d_grand = nullptr;
     u64 *d_qv = nullptr;              // quotient values [nch][N]
     u64 *d_apow = nullptr;            // powers of the alphas for the quotient kernel
+    u64 *d_xs = nullptr, *d_l0 = nullptr;   // per LDE point: x and L_0(x) (p2_point_tables_kernel)
+    p2_fused_plan plan = {};          // job lists of the fused quotient kernel; plan.nwaves == 0: per-gate launches
+    size_t fused_lds = 0;
+    std::vector<double> gate_ms;      // calibration: per-gate kernel time (the last entry is the base kernel)
     gl2 *d_zpow = nullptr, *d_open = nullptr, *d_open_partial = nullptr;
     gl2 *d_fri[9] = {};               // FRI oracles (extension values), [0] has N elements
     u64 *d_fri_tree[8] = {};
@@ -551,6 +689,110 @@ static int32_t p2_hash_no_pad(zklc_plonky2_circuit *c, hipStream_t st, const std
     return ZKLC_OK;
 }
 
+static void p2_quotient_static_args(const zklc_plonky2_circuit *c, p2_quotient_args &a) {
+    const zklc_plonky2_params &P = c->P;
+    a.cs = c->cs.lde;
+    a.wires = c->wires.lde;
+    a.zs = c->zs.lde;
+    a.gates = c->d_gates;
+    a.extra = c->d_extra;
+    a.k_is = c->d_kis;
+    a.lde_bits = c->lde_bits;
+    a.degree_bits = P.degree_bits;
+    a.rate_bits = P.rate_bits;
+    a.num_constants = P.num_constants;
+    a.nsel = P.num_selectors;
+    a.routed = P.num_routed_wires;
+    a.nch = P.num_challenges;
+    a.npp = P.num_partial_products;
+    a.qdf = P.quotient_degree_factor;
+    a.num_gates = P.num_gates;
+    a.num_wires = P.num_wires;
+    a.w_lde = h_root(c->lde_bits);
+    u64 gn = h_pow(GL_GENERATOR, c->n), w_r = h_root(P.rate_bits);
+    for (u32 k = 0; k < (1u << P.rate_bits); k++) {
+        a.zh[k] = h_sub(h_mul(gn, h_pow(w_r, k)), 1);
+        a.zh_inv[k] = h_inv(a.zh[k]);
+    }
+    a.n_field = c->n;
+    a.xs = c->d_xs;
+    a.l0 = c->d_l0;
+    a.out = c->d_qv;
+}
+
+// Measures every gate's (and the base terms') kernel once on the circuit's own buffers and splits the jobs over the waves of
+// the fused kernel: longest job first onto the least loaded wave.  ZKLC_P2_QUOTIENT=pergate keeps the per-gate launches,
+// ZKLC_P2_FQ_WAVES overrides the number of waves per workgroup (default: 8 when only one workgroup's tile fits a CU's LDS).
+static int32_t p2_plan_quotient(zklc_plonky2_circuit *c, hipStream_t st) {
+    zklc_ctx *ctx = c->ctx;
+    const zklc_plonky2_params &P = c->P;
+    const u32 N = c->N;
+    c->plan.nwaves = 0;
+    // measured on the Ed25519 circuit (profiles/r02_quotient_ab.txt): per-gate launches 15.4 ms of kernels, fused 30 ms with 8
+    // waves per workgroup, 51 ms with 4 -- the 120 KB tile leaves 1-2 waves per SIMD and the evaluators (long dependent chains
+    // of multiply-reduce) need 6-8 to reach the VALU issue rate.  The fused form therefore stays opt-in.
+    const char *mode = getenv("ZKLC_P2_QUOTIENT");
+    if (!mode || strcmp(mode, "fused")) return ZKLC_OK;
+    const size_t tile = (size_t)(P.num_constants + P.num_wires) * 64 * 8;
+    if (N < 64 || P.num_gates + 1 > P2_FQ_MAX_WAVES * P2_FQ_MAX_JOBS) return ZKLC_OK;
+    u32 nw = tile * 2 + 2 * 4 * P2_MAX_CH * 512 <= 160 * 1024 ? 4 : 8;
+    if (const char *e = getenv("ZKLC_P2_FQ_WAVES")) nw = (u32)atoi(e);
+    if (nw < 1 || nw > P2_FQ_MAX_WAVES) return ZKLC_ERR_INVALID_ARG;
+    c->fused_lds = tile + (size_t)nw * P2_MAX_CH * 64 * 8;
+    if (c->fused_lds > 160 * 1024) return ZKLC_OK;      // the tile does not fit: per-gate launches
+    ZKLC_HIP(ctx, hipFuncSetAttribute((const void *)p2_quotient_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)c->fused_lds));
+    p2_quotient_args a = {};
+    p2_quotient_static_args(c, a);
+    for (u32 k = 0; k < P2_MAX_CH; k++) a.apow[k] = c->d_apow;
+    hipEvent_t e0, e1;
+    ZKLC_HIP(ctx, hipEventCreate(&e0));
+    ZKLC_HIP(ctx, hipEventCreate(&e1));
+    c->gate_ms.assign(P.num_gates + 1, 0.0);
+    for (u32 g = 0; g <= P.num_gates; g++) {
+        p2_gate_kernel_fn fn = g < P.num_gates ? p2_gate_kernel_of(c->gates[g].type) : nullptr;
+        if (g < P.num_gates && !fn) continue;
+        for (int rep = 0; rep < 2; rep++) {
+            ZKLC_HIP(ctx, hipEventRecord(e0, st));
+            if (fn)
+                hipLaunchKernelGGL(fn, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a, g);
+            else
+                hipLaunchKernelGGL(p2_quotient_base_kernel, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a);
+            ZKLC_HIP(ctx, hipEventRecord(e1, st));
+            ZKLC_HIP(ctx, hipEventSynchronize(e1));
+            float ms = 0;
+            ZKLC_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+            if (rep == 0 || ms < c->gate_ms[g]) c->gate_ms[g] = ms;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    std::vector<u32> order;
+    for (u32 g = 0; g <= P.num_gates; g++)
+        if (g == P.num_gates || p2_gate_kernel_of(c->gates[g].type)) order.push_back(g);
+    std::sort(order.begin(), order.end(), [&](u32 x, u32 y) { return c->gate_ms[x] > c->gate_ms[y]; });
+    double load[P2_FQ_MAX_WAVES] = {};
+    p2_fused_plan plan = {};
+    for (u32 g : order) {
+        u32 best = 0;
+        for (u32 w = 1; w < nw; w++)
+            if (load[w] < load[best]) best = w;
+        if (plan.njobs[best] >= P2_FQ_MAX_JOBS) return ZKLC_OK;
+        plan.jobs[best][plan.njobs[best]++] = g == P.num_gates ? (uint16_t)P2_JOB_BASE : (uint16_t)g;
+        load[best] += c->gate_ms[g];
+    }
+    plan.nwaves = nw;
+    c->plan = plan;
+    if (getenv("ZKLC_P2_DEBUG")) {
+        fprintf(stderr, "[zklc] fused quotient: %u waves, LDS %zu B; per-gate calibration (ms):", nw, c->fused_lds);
+        for (u32 g = 0; g <= P.num_gates; g++) fprintf(stderr, " %u:%.3f", g < P.num_gates ? c->gates[g].type : 99u, c->gate_ms[g]);
+        fprintf(stderr, "\n[zklc] wave loads (ms):");
+        for (u32 w = 0; w < nw; w++) fprintf(stderr, " %.3f", load[w]);
+        fprintf(stderr, "\n");
+    }
+    return ZKLC_OK;
+}
+
 extern "C" void zklc_plonky2_circuit_destroy(zklc_plonky2_circuit *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -625,6 +867,8 @@ static int32_t p2_create(zklc_ctx *ctx, const zklc_plonky2_params *params, const
     P2_ALLOC(c, c->d_grand, 8);
     P2_ALLOC(c, c->d_apow, (size_t)nch_ * (nch_ + nch_ * (P.num_partial_products + 1) + P.num_gate_constraints + 1) * 8);
     P2_ALLOC(c, c->d_zpow, (size_t)n * sizeof(gl2));
+    P2_ALLOC(c, c->d_xs, (size_t)N * 8);
+    P2_ALLOC(c, c->d_l0, (size_t)N * 8);
     u32 total_polys = c->cs.width + c->wires.width + c->zs.width + c->quot.width + nch;
     P2_ALLOC(c, c->d_open, (size_t)total_polys * sizeof(gl2));
     P2_ALLOC(c, c->d_open_partial, (size_t)total_polys * P2_EVAL_SPLIT * sizeof(gl2));
@@ -647,6 +891,14 @@ static int32_t p2_create(zklc_ctx *ctx, const zklc_plonky2_params *params, const
     ZKLC_HIP(ctx, hipMemcpyAsync(c->cs.coeffs + (size_t)P.num_constants * n, sigmas, sbytes, hipMemcpyHostToDevice, st));
     ZKLC_HIP(ctx, hipMemcpyAsync(c->d_sigma_vals, sigmas, sbytes, hipMemcpyHostToDevice, st));
     P2_RC(p2_commit_values(c, st, c->cs, c->cap_bytes));
+    {
+        p2_quotient_args a = {};
+        p2_quotient_static_args(c, a);
+        hipLaunchKernelGGL(p2_point_tables_kernel, dim3((N / 4 + 255) / 256 ? (N / 4 + 255) / 256 : 1), dim3(256), 0, st, c->d_xs, c->d_l0,
+                           c->lde_bits, P.rate_bits, a.w_lde, a.n_field, a);
+        ZKLC_HIP(ctx, hipGetLastError());
+        P2_RC(p2_plan_quotient(c, st));
+    }
 
     // circuit digest = hash_no_pad(cap as field elements || hash_pad([]) || degree_bits)  (plonky2 circuit_builder.rs `build`)
     auto hash_to_vec = [&](const uint8_t *h, std::vector<u64> &out) {
@@ -835,29 +1087,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
     // ---- quotient
     {
         p2_quotient_args a = {};
-        a.cs = c->cs.lde;
-        a.wires = c->wires.lde;
-        a.zs = c->zs.lde;
-        a.gates = c->d_gates;
-        a.extra = c->d_extra;
-        a.k_is = c->d_kis;
-        a.lde_bits = c->lde_bits;
-        a.degree_bits = P.degree_bits;
-        a.rate_bits = P.rate_bits;
-        a.num_constants = P.num_constants;
-        a.nsel = P.num_selectors;
-        a.routed = P.num_routed_wires;
-        a.nch = nch;
-        a.npp = npp;
-        a.qdf = P.quotient_degree_factor;
-        a.num_gates = P.num_gates;
-        a.w_lde = h_root(c->lde_bits);
-        u64 gn = h_pow(GL_GENERATOR, n), w_r = h_root(P.rate_bits);
-        for (u32 k = 0; k < (1u << P.rate_bits); k++) {
-            a.zh[k] = h_sub(h_mul(gn, h_pow(w_r, k)), 1);
-            a.zh_inv[k] = h_inv(a.zh[k]);
-        }
-        a.n_field = n;
+        p2_quotient_static_args(c, a);
         for (int k = 0; k < 4; k++) a.pih[k] = pih[k];
         a.ch = chal;
         {
@@ -875,11 +1105,14 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
             for (u32 k = 0; k < nch; k++) a.apow[k] = c->d_apow + (size_t)k * n_pow;
             for (u32 k = nch; k < P2_MAX_CH; k++) a.apow[k] = c->d_apow;
         }
-        a.out = c->d_qv;
-        hipLaunchKernelGGL(p2_quotient_base_kernel, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a);
-        for (u32 g = 0; g < P.num_gates; g++) {
-            p2_gate_kernel_fn fn = p2_gate_kernel_of(c->gates[g].type);
-            if (fn) hipLaunchKernelGGL(fn, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a, g);
+        if (c->plan.nwaves) {
+            hipLaunchKernelGGL(p2_quotient_fused_kernel, dim3(N / 64), dim3(64 * c->plan.nwaves), c->fused_lds, st, a, c->plan);
+        } else {
+            hipLaunchKernelGGL(p2_quotient_base_kernel, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a);
+            for (u32 g = 0; g < P.num_gates; g++) {
+                p2_gate_kernel_fn fn = p2_gate_kernel_of(c->gates[g].type);
+                if (fn) hipLaunchKernelGGL(fn, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a, g);
+            }
         }
         ZKLC_HIP(ctx, hipGetLastError());
         // values on g<w_N> (bit-reversed) -> coefficients: inverse DIT, then undo the coset shift
