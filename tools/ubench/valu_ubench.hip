@@ -92,6 +92,29 @@ DEFINE_KERNEL(k_lshrrev_b64, DECL64, OP8_LSHR64, SINK64)
                  : "vcc");
 DEFINE_KERNEL(k_addco_nop_addc_pairs, DECL32, OP8_ADDC, SINK32)
 
+// carry-flag forms used by the hand-scheduled Poseidon statements (tools/gen_poseidon_asm.py): VOP3 with an SGPR-pair carry
+// against the VOP2 + VCC encodings
+#define OP8_RAW(TXT, CLOB...)                                                                                     \
+    asm volatile(TXT(0) TXT(1) TXT(2) TXT(3) TXT(4) TXT(5) TXT(6) TXT(7)                                           \
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)               \
+                 : "v"(b), "v"(c)                                                                                 \
+                 : CLOB);
+#define T_ADDCO_E64(i) "v_add_co_u32_e64 %" #i ", s[10:11], %" #i ", %8\n\t"
+#define T_ADDCO_E32(i) "v_add_co_u32_e32 %" #i ", vcc, %" #i ", %8\n\t"
+#define T_ADDC_E64(i) "v_addc_co_u32_e64 %" #i ", s[10:11], %" #i ", %8, s[12:13]\n\t"
+#define T_SUBB_E64(i) "v_subb_co_u32_e64 %" #i ", s[10:11], %" #i ", 0, s[12:13]\n\t"
+#define T_CND_E64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[12:13]\n\t"
+#define T_CND_E32(i) "v_cndmask_b32_e32 %" #i ", %" #i ", %8, vcc\n\t"
+#define T_MOV_E32(i) "v_mov_b32_e32 %" #i ", %8\n\t"
+#define T_MAD_CARRY(i) "v_mad_u64_u32 %" #i ", s[10:11], %8, %9, %" #i "\n\t"
+DEFINE_KERNEL(k_addco_e64, DECL32, OP8_RAW(T_ADDCO_E64, "s10", "s11"), SINK32)
+DEFINE_KERNEL(k_addco_e32, DECL32, OP8_RAW(T_ADDCO_E32, "vcc"), SINK32)
+DEFINE_KERNEL(k_addc_e64, DECL32, OP8_RAW(T_ADDC_E64, "s10", "s11"), SINK32)
+DEFINE_KERNEL(k_subb_e64, DECL32, OP8_RAW(T_SUBB_E64, "s10", "s11"), SINK32)
+DEFINE_KERNEL(k_cnd_e64, DECL32, OP8_RAW(T_CND_E64, "s10"), SINK32)
+DEFINE_KERNEL(k_cnd_e32, DECL32, OP8_RAW(T_CND_E32, "s10"), SINK32)
+DEFINE_KERNEL(k_mov_e32, DECL32, OP8_RAW(T_MOV_E32, "s10"), SINK32)
+
 #define DECLF64                                                                                                  \
     double a0 = 1.0 + threadIdx.x * 1e-9, a1 = a0 + 1e-3, a2 = a0 + 2e-3, a3 = a0 + 3e-3, a4 = a0 + 4e-3,     \
            a5 = a0 + 5e-3, a6 = a0 + 6e-3, a7 = a0 + 7e-3, b = 1.0 + seed * 1e-12, c = seed * 1e-13
@@ -145,6 +168,10 @@ int main() {
         {"v_mul_hi_u32", k_mul_hi_u32, 32},    {"v_mad_u64_u32", k_mad_u64_u32, 32},
         {"v_lshl_add_u64", k_lshl_add_u64, 32}, {"v_lshrrev_b64", k_lshrrev_b64, 32},
         {"add_co;s_nop1;addc (per pair)", k_addco_nop_addc_pairs, 16},
+        {"v_add_co_u32_e64 (sgpr carry out)", k_addco_e64, 32}, {"v_add_co_u32_e32 (vcc)", k_addco_e32, 32},
+        {"v_addc_co_u32_e64 (sgpr in/out)", k_addc_e64, 32}, {"v_subb_co_u32_e64", k_subb_e64, 32},
+        {"v_cndmask_b32_e64 (sgpr)", k_cnd_e64, 32}, {"v_cndmask_b32_e32 (vcc)", k_cnd_e32, 32},
+        {"v_mov_b32_e32", k_mov_e32, 32},
         {"v_fma_f64", k_fma_f64, 32},          {"v_mul_f64", k_mul_f64, 32},
         {"v_add_f64", k_add_f64, 32},
     };
