@@ -30,7 +30,8 @@ P = 2**64 - 2**32 + 1
 M32 = 0xFFFFFFFF
 MDS_C = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
 
-VB, NT = 64, 44          # fixed temporary VGPRs v[64:107]
+VB, NT = 48, 60          # fixed temporary VGPRs v[48:107]
+LB = 32                  # s[32:33] table pointer, s34 round counter of the looped statement
 SB = 36                  # constants s[36:83]
 FB, NF = 84, 9           # flag pairs s[84:85] .. s[100:101]; flag index NF = vcc
 
@@ -124,12 +125,12 @@ def mds_row_stream(r, lo, hi_, out, base, rc, fl, fd):
     return ins
 
 
-def dot_streams(xs, ks, base, flags, fd, yterm=None):
+def dot_streams(xs, ks, base, flags, fd, yterm=None, needconst=True):
     """sum_j x_j k_j as four column accumulators (64 bits + a carry counter each).  xs: [(x0, x1)] registers, ks: [(k0, k1)]
     SGPRs.  Returns the four streams; temporaries T(base .. base+11).  yterm = (y, 25, event): adds 25 y once `event` is up"""
     C0, C1a, C1b, C2 = T(base), T(base + 2), T(base + 4), T(base + 6)
     n0, n1a, n1b, n2 = T(base + 8), T(base + 9), T(base + 10), T(base + 11)
-    st = [[("mov", n, 0), ("needconst",)] for n in (n0, n1a, n1b, n2)]
+    st = [[("mov", n, 0)] + ([("needconst",)] if needconst else []) for n in (n0, n1a, n1b, n2)]
     for j, ((x0, x1), (k0, k1)) in enumerate(zip(xs, ks)):
         for s_, (acc, cnt, xa, kb) in enumerate(((C0, n0, x0, k0), (C1a, n1a, x0, k1), (C1b, n1b, x1, k0), (C2, n2, x1, k1))):
             st[s_].append(("mad", acc, flags[s_], xa, kb, acc if j else None))
@@ -298,7 +299,7 @@ def simulate(prog, regs, consts=None):
         elif op == "sload":
             _, base, n, off = ins
             for k in range(n):
-                R["s%d" % (int(base[1:]) + k)] = consts[off // 4 + k]
+                R["s%d" % (int(base[1:]) + k)] = consts[off // 4 + k]      # `consts` starts at the statement's table pointer
         elif op in ("nop", "waitcnt"):
             pass
         else:
@@ -364,19 +365,30 @@ def check_constant_bus(prog):
         assert len(sg) <= 1, ("constant bus", ins)
 
 
-CLOBBERS = ["v%d" % (VB + i) for i in range(NT)] + ["s%d" % i for i in range(SB, FB + 2 * NF)] + ["vcc"]
+CLOBBERS = ["v%d" % (VB + i) for i in range(NT)] + ["s%d" % i for i in range(LB, FB + 2 * NF)] + ["vcc", "scc"]
 
 
-def statement(name, prog, inouts, ins_ops, outs=(), ptr=False, comment=""):
+def statement(name, prog, inouts, ins_ops, outs=(), ptr=False, comment="", loop=None, pre=()):
     """C++ text of one inline function holding one asm statement.  inouts / ins_ops / outs: operand register names "%k" are
-    assigned here in this order: outs ("=&v"), inouts ("+v"), inputs ("v"), then the table pointer ("s")."""
+    assigned here in this order: outs ("=&v"), inouts ("+v"), inputs ("v"), then the table pointer ("s").
+    loop = (rounds, stride_bytes): `prog` is the body of a loop over table rows; the pointer lives in s[LB:LB+1], the
+    counter in s(LB+2); `pre`: instructions before the loop (they use the pointer operand's copy as well)."""
     names = list(outs) + list(inouts) + list(ins_ops)
     idx = {n: "%%%d" % k for k, n in enumerate(names)}
     ptr_op = "%%%d" % len(names)
 
     def tr(ins):
         return tuple(idx.get(x, x) if isinstance(x, str) else x for x in ins)
-    lines = [emit(tr(i), ptr_op) for i in prog]
+    if loop:
+        lp = "s[%d:%d]" % (LB, LB + 1)
+        lines = ["s_mov_b64 %s, %s" % (lp, ptr_op), "s_movk_i32 s%d, %d" % (LB + 2, loop[0])]
+        lines += [emit(tr(i), lp) for i in pre]
+        lines.append("pgl_loop_%=:")
+        lines += [emit(tr(i), lp) for i in prog]
+        lines += ["s_add_u32 s%d, s%d, %d" % (LB, LB, loop[1]), "s_addc_u32 s%d, s%d, 0" % (LB + 1, LB + 1),
+                  "s_sub_u32 s%d, s%d, 1" % (LB + 2, LB + 2), "s_cmp_lg_u32 s%d, 0" % (LB + 2), "s_cbranch_scc1 pgl_loop_%="]
+    else:
+        lines = [emit(tr(i), ptr_op) for i in prog]
     params = ["u32 &%s" % n for n in list(outs) + list(inouts)] + ["u32 %s" % n for n in ins_ops] + (["const u32 *tab"] if ptr else [])
     c = ["// %s" % comment if comment else "", "ZKLC_D void %s(%s) {" % (name, ", ".join(params)), "    asm volatile("]
     for ln in lines:
@@ -441,6 +453,63 @@ def build_partial():
     return prog, list(s0) + [r for x in sj for r in x], nops
 
 
+def build_fullround():
+    """one full round in place: twelve S-boxes (three streams of four; results in temporaries), then the MDS layer + the next
+    constant layer written back to the state operands (three streams of four rows).  The 48 dwords of constants are fetched
+    at the top and arrive behind the S-boxes.  Table row: {lo, 0, hi, 0} x 12"""
+    fd = F(0)
+    xs = [("x%dl" % i, "x%dh" % i) for i in range(12)]
+    Y = [(T(2 * i), T(2 * i + 1)) for i in range(12)]
+    streams = []
+    for k in range(3):
+        st = []
+        for i in range(k, 12, 3):
+            st += sbox_stream(xs[i], 24 + 12 * k, F(1 + k), fd, out=Y[i])
+            st.append(("signal", "sb%d" % i))
+        streams.append(st)
+    lo, hi_ = [y[0] for y in Y], [y[1] for y in Y]
+    for m in range(3):
+        st = [("wait", "sb%d" % i) for i in range(12)]
+        for r in range(m, 12, 3):
+            st += mds_row_stream(r, lo, hi_, xs[r], 24 + 12 * m, (K(4 * r), K(4 * r + 2)), F(1 + m), fd)
+        streams.append(st)
+    prologue = [("sload", K(0), 16, 0), ("sload", K(16), 16, 64), ("sload", K(32), 16, 128)]
+    prog, nops = schedule(streams, prologue)
+    return prog, [r for x in xs for r in x], nops
+
+
+def build_partial_loop():
+    """the body of the loop over the 22 fast partial rounds (one asm statement, pointer and counter in SGPRs):
+    y = s0^7 + rc; s0' = 25 y + sum_j w_j s_j; s_j += y v_j.  Table row (48 dwords): w (k0, k1) x 11 | 2 pad | v (v0, v1) x 11 |
+    rc lo, hi.  The w block of the NEXT row is fetched as soon as the dot products have read this row's, the v block at the
+    top of the body (first used ~200 slots later), so no load latency is exposed."""
+    fd = F(0)
+    s0 = ("q0l", "q0h")
+    sj = [("q%dl" % j, "q%dh" % j) for j in range(1, 12)]
+    Y = (T(12), T(13))
+    DB = 14
+    sbox = sbox_stream(s0, 0, F(1), fd, out=Y)
+    f = T(10)
+    sbox += [("needconst",), ("mov", f, K(47)), ("add_co", Y[0], F(1), Y[0], K(46)), ("addc", Y[1], F(1), Y[1], f, F(1)),
+             ("cnd", f, 0, -1, F(1)), ("add_co", Y[0], F(1), Y[0], f), ("addc", Y[1], fd, Y[1], 0, F(1)), ("signal", "y")]
+    ks = [(K(2 * j), K(2 * j + 1)) for j in range(11)]
+    dots = dot_streams(sj, ks, DB, [F(2), F(3), F(4), F(5)], fd, yterm=(Y, 25, "y"), needconst=False)
+    for k, d in enumerate(dots):
+        d.append(("signal", "dot%d" % k))
+    rds = ["rd%d_%d" % (DB, q) for q in range(4)]
+    prefetch = [("wait", e) for e in rds] + [("sload", K(0), 8, 192), ("sload", K(8), 16, 192 + 32)]
+    fold = fold_stream(DB, s0, T(26), F(2), fd, ["dot0", "dot1", "dot2", "dot3"])
+    usc = [((T(4), T(6), T(8)), T(10), F(1)), ((T(28), T(30), T(32)), T(34), F(6)), ((T(36), T(38), T(40)), T(42), F(7))]
+    ups = [[], [], []]
+    for j in range(11):
+        sc, fj, fl = usc[j % 3]
+        ups[j % 3] += update_stream(Y, (K(24 + 2 * j), K(25 + 2 * j)), sj[j], sc, fj, fl, fd, ["y"] + rds)
+    pre = [("sload", K(0), 8, 0), ("sload", K(8), 16, 32)]
+    top = [("waitcnt",), ("sload", K(24), 8, 96), ("sload", K(32), 16, 128)]
+    prog, nops = schedule([sbox] + dots + [prefetch, fold] + ups, top)
+    return pre, prog, list(s0) + [r for x in sj for r in x], nops
+
+
 def build_init2(n_out):
     """n_out (1 or 2) outputs of the 11 x 11 initial matrix of the fast partial rounds: t_d = sum_{r=1..11} s_r init[r-1][d-1].
     Table row per output (24 dwords): (k0, k1) x 11 | 2 pad"""
@@ -471,50 +540,39 @@ def get64(R, pair):
 
 def selftest(consts, tables):
     rng = random.Random(2024)
-    # S-boxes
-    prog, ops, _ = build_sbox3()
+    # full rounds (every layer of constants)
+    prog, ops, _ = build_fullround()
     check_hazards(prog)
     check_constant_bus(prog)
-    for _ in range(300):
-        xs = [rnd64(rng) for _ in range(3)]
-        regs = {}
-        for i, x in enumerate(xs):
-            regs["x%dl" % i], regs["x%dh" % i] = x & M32, x >> 32
-        R = simulate(prog, regs)
-        for i, x in enumerate(xs):
-            assert get64(R, ("x%dl" % i, "x%dh" % i)) % P == pow(x, 7, P), "sbox"
-    # MDS rows with the constants of one layer
-    rc_tab = tables["rc"]
-    for layer in (0, 3, 7):
-        for pair in range(6):
-            prog, outs, ins, _ = build_mds2([2 * pair, 2 * pair + 1])
-            check_hazards(prog)
-            check_constant_bus(prog)
-            for _ in range(40):
-                s = [rnd64(rng) for _ in range(12)]
-                regs = {}
-                for i, x in enumerate(s):
-                    regs["l%d" % i], regs["h%d" % i] = x & M32, x >> 32
-                R = simulate(prog, regs, rc_tab[48 * layer:48 * layer + 48])
-                for k, r in enumerate((2 * pair, 2 * pair + 1)):
-                    want = sum(MDS_C[i] * s[(i + r) % 12] for i in range(12)) + (8 * s[0] if r == 0 else 0) + consts["next"][layer][r]
-                    assert get64(R, ("o%dl" % k, "o%dh" % k)) % P == want % P, "mds"
-    # partial rounds
-    prog, ops, _ = build_partial()
-    check_hazards(prog)
-    check_constant_bus(prog)
-    for rnd in range(22):
-        for _ in range(12):
-            s = [rnd64(rng) for _ in range(12)]
+    for layer in range(8):
+        for _ in range(25):
+            st = [rnd64(rng) for _ in range(12)]
             regs = {}
-            for i, x in enumerate(s):
-                regs["q%dl" % i], regs["q%dh" % i] = x & M32, x >> 32
-            R = simulate(prog, regs, tables["partial"][48 * rnd:48 * rnd + 48])
-            y = (pow(s[0], 7, P) + consts["fp_rc"][rnd]) % P
-            d = (25 * y + sum(consts["w"][rnd][j - 1] * s[j] for j in range(1, 12))) % P
-            assert get64(R, ("q0l", "q0h")) % P == d, "partial s0"
-            for j in range(1, 12):
-                assert get64(R, ("q%dl" % j, "q%dh" % j)) % P == (s[j] + y * consts["v"][rnd][j - 1]) % P, "partial sj"
+            for i, x in enumerate(st):
+                regs["x%dl" % i], regs["x%dh" % i] = x & M32, x >> 32
+            R = simulate(prog, regs, tables["rc"][48 * layer:48 * layer + 48])
+            y = [pow(x, 7, P) for x in st]
+            for r in range(12):
+                want = sum(MDS_C[i] * y[(i + r) % 12] for i in range(12)) + (8 * y[0] if r == 0 else 0) + consts["next"][layer][r]
+                assert get64(R, ("x%dl" % r, "x%dh" % r)) % P == want % P, "full round"
+    # the 22 partial rounds as the loop runs them (the w block of row i + 1 is fetched inside iteration i)
+    pre, body, ops, _ = build_partial_loop()
+    check_hazards(body + body)
+    check_constant_bus(body)
+    for _ in range(12):
+        st = [rnd64(rng) for _ in range(12)]
+        regs = {}
+        for i, x in enumerate(st):
+            regs["q%dl" % i], regs["q%dh" % i] = x & M32, x >> 32
+        R = simulate(pre, regs, tables["partial"])
+        cur = list(st)
+        for rnd in range(22):
+            R = simulate(body, R, tables["partial"][48 * rnd:])
+            y = (pow(cur[0], 7, P) + consts["fp_rc"][rnd]) % P
+            d = (25 * y + sum(consts["w"][rnd][j - 1] * cur[j] for j in range(1, 12))) % P
+            cur = [d] + [(cur[j] + y * consts["v"][rnd][j - 1]) % P for j in range(1, 12)]
+            for j in range(12):
+                assert get64(R, ("q%dl" % j, "q%dh" % j)) % P == cur[j], "partial round %d word %d" % (rnd, j)
     # initial matrix
     for d0 in range(0, 11, 2):
         n_out = min(2, 11 - d0)
@@ -550,12 +608,13 @@ def load_constants():
         row = []
         for x in consts["w"][r]:
             row += [x & M32, x >> 32]
-        row += [consts["fp_rc"][r] & M32, consts["fp_rc"][r] >> 32]
+        row += [0, 0]
         for x in consts["v"][r]:
             row += [x & M32, x >> 32]
-        row += [0, 0]
+        row += [consts["fp_rc"][r] & M32, consts["fp_rc"][r] >> 32]
         assert len(row) == 48
         t_part += row
+    t_part += [0] * 48            # the loop's last iteration prefetches one row past the end
     t_init = []
     for d in range(11):
         row = []
@@ -584,29 +643,26 @@ def main():
     parts = ["// GENERATED by tools/gen_poseidon_asm.py -- do not edit.  Hand-scheduled gfx950 statements of the Poseidon-Goldilocks",
              "// permutation (see the generator for the derivation, the hazard rule and the simulator that checks every list).",
              "// Tables: PGL_ASM_RC[layer][row] = {lo, 0, hi, 0} of the constant added after the MDS of full round `layer`;",
-             "// PGL_ASM_PARTIAL[round] = w_hat pairs | rc | v pairs | pad (48 dwords); PGL_ASM_INIT[d] = column d of the initial",
+             "// PGL_ASM_PARTIAL[round] = w_hat pairs | pad | v pairs | rc (48 dwords, + one padding row); PGL_ASM_INIT[d] = column d of the initial",
              "// matrix as (lo, hi) pairs | pad (24 dwords).",
              c_table("PGL_ASM_RC", tables["rc"]), c_table("PGL_ASM_PARTIAL", tables["partial"]), c_table("PGL_ASM_INIT", tables["init"]),
              "#if defined(__HIP_DEVICE_COMPILE__)"]
     stats = []
-    prog, ops, nops = build_sbox3()
-    stats.append(("sbox3", len(prog), nops))
-    parts.append(statement("pgl_asm_sbox3", prog, ops, [], comment="x <- x^7 for three state words"))
-    for pair in range(6):
-        prog, outs, ins, nops = build_mds2([2 * pair, 2 * pair + 1])
-        stats.append(("mds rows %d,%d" % (2 * pair, 2 * pair + 1), len(prog), nops))
-        parts.append(statement("pgl_asm_mds_rows_%d" % pair, prog, [], ins, outs=outs, ptr=True,
-                               comment="MDS rows %d, %d + the next constant layer (tab: 48 dwords of PGL_ASM_RC)" % (2 * pair, 2 * pair + 1)))
-    prog, ops, nops = build_partial()
+    prog, ops, nops = build_fullround()
+    stats.append(("full round", len(prog), nops))
+    parts.append(statement("pgl_asm_full_round", prog, ops, [], ptr=True,
+                           comment="one full round in place: x^7 on the twelve words, MDS, next constant layer (tab: 48 dwords of PGL_ASM_RC)"))
+    pre, prog, ops, nops = build_partial_loop()
     stats.append(("partial round", len(prog), nops))
-    parts.append(statement("pgl_asm_partial_round", prog, ops, [], ptr=True, comment="one fast partial round (tab: 48 dwords of PGL_ASM_PARTIAL)"))
+    parts.append(statement("pgl_asm_partial_rounds", prog, ops, [], ptr=True, loop=(22, 192), pre=pre,
+                           comment="the 22 fast partial rounds (tab: PGL_ASM_PARTIAL)"))
     for n_out in (2, 1):
         prog, outs, ins, nops = build_init2(n_out)
         stats.append(("init x%d" % n_out, len(prog), nops))
         parts.append(statement("pgl_asm_init%d" % n_out, prog, [], ins, outs=outs, ptr=True,
                                comment="%d output(s) of the initial matrix of the fast partial rounds (tab: %d dwords of PGL_ASM_INIT)" % (n_out, 24 * n_out)))
     parts.append("#endif")
-    total = 8 * (4 * stats[0][1] + sum(s[1] for s in stats[1:7])) + 22 * stats[7][1] + 5 * stats[8][1] + stats[9][1]
+    total = 8 * stats[0][1] + 22 * stats[1][1] + 5 * stats[2][1] + stats[3][1]
     parts.insert(5, "// instructions per statement (of which s_nop): " + "; ".join("%s %d (%d)" % s for s in stats)
                  + "; permutation ~%d + constant layers / canonicalisation" % total)
     open(os.path.join(ROOT, "zk-light-client-implementation_amd", "csrc", "poseidon_gl_asm.inc"), "w").write("\n".join(parts) + "\n")
