@@ -217,6 +217,29 @@ int32_t zklc_plonky2_witness_run(const uint32_t *code, uint64_t code_len, const 
 /* the interpreter keeps its per-thread state (value arrays, one per slot) cached across calls; this frees the cache */
 void zklc_plonky2_witness_release(void);
 
+/* Witness generation ON THE GPU: the same program, levelled by data dependence and executed by the device for a
+ * batch of up to 64 witnesses -- one lane per (instruction, witness), slot values stored as val[slot][witness]
+ * (csrc/plonky2_witness_dev.hip).  The wire matrices are written in HBM in the prover's layout (what zklc_plonky2_prove_dev
+ * takes), so the 490 MB per Ed25519 signature never cross PCIe and no host core is on the per-signature path.
+ * Replaces the generators that run inside `CircuitData::prove` at near_bft_finality/src/prove_crypto/ed25519.rs:60,100 and
+ * recursion.rs:95 (crypto/plonky2_ed25519/src/gadgets/nonnative.rs:447-705, gadgets/curve.rs:327-370, ...).
+ * program_create copies and schedules the program once per circuit (arguments as for zklc_plonky2_witness_run);
+ * run_dev: input_values host n_witnesses x n_inputs; d_wires DEVICE n_witnesses x num_wires x n_rows (only the circuit's wire
+ * cells are written: zero-fill the buffer once); pi_out / status / err_out (optional, 200 bytes per witness) are host arrays,
+ * valid on return (the call synchronises `stream`).  status[i] != 0: witness i does not exist (invalid signature, ...). */
+typedef struct zklc_witness_program zklc_witness_program;
+int32_t zklc_plonky2_witness_program_create(zklc_ctx *ctx, const uint32_t *code, uint64_t code_len, const int64_t *params,
+                                            uint64_t n_params, uint32_t n_slots, const uint32_t *input_slots, uint32_t n_inputs,
+                                            const uint32_t *wire_slot, const uint32_t *wire_index, uint64_t n_wire_entries,
+                                            uint32_t num_wires, uint32_t n_rows, const uint32_t *pi_slots, uint32_t n_pi,
+                                            zklc_witness_program **out);
+void zklc_plonky2_witness_program_destroy(zklc_witness_program *p);
+/* instructions, dependence levels, and the kernel launches a batch of n_witnesses takes (runs of small levels share a launch) */
+int32_t zklc_plonky2_witness_program_info(zklc_witness_program *p, uint32_t n_witnesses, uint64_t *n_instr, uint32_t *n_levels,
+                                          uint32_t *n_launches);
+int32_t zklc_plonky2_witness_run_dev(zklc_ctx *ctx, void *stream, zklc_witness_program *p, const uint64_t *input_values,
+                                     uint32_t n_witnesses, uint64_t *d_wires, uint64_t *pi_out, int32_t *status, char *err_out);
+
 /* ---- (c) BN254 ---------------------------------------------------------------
  * G1 multi-scalar multiplication sum_i scalars[i] * points[i].
  * Replaces gnark-crypto `bn254.G1Affine.MultiExp` (un-vendored; gnark-plonky2-verifier/go.mod:9)

@@ -76,6 +76,14 @@ _SIGS = {
     "zklc_plonky2_witness_release": (None, []),
     "zklc_poseidon_gl_constants": (None, [_u8p, _u8p, _u8p, _u8p, _u8p]),
     "zklc_gl_mul_vec": (None, [_u8p, _u8p, _u8p, ctypes.c_uint64]),
+    "zklc_plonky2_witness_program_create": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, _u8p, ctypes.c_uint64, ctypes.c_uint32,
+                                                             _u8p, ctypes.c_uint32, _u8p, _u8p, ctypes.c_uint64, ctypes.c_uint32,
+                                                             ctypes.c_uint32, _u8p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]),
+    "zklc_plonky2_witness_program_destroy": (None, [ctypes.c_void_p]),
+    "zklc_plonky2_witness_program_info": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64),
+                                                           ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
+    "zklc_plonky2_witness_run_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint32,
+                                                      ctypes.c_void_p, _u8p, _u8p, ctypes.c_char_p]),
     "zklc_plonky2_witness_run": (ctypes.c_int32, [_u8p, ctypes.c_uint64, _u8p, ctypes.c_uint32, _u8p, ctypes.c_uint32, _u8p,
                                                   ctypes.c_uint32, _u8p, _u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _u8p,
                                                   _u8p, ctypes.c_uint32, _u8p, _u8p, ctypes.c_char_p, ctypes.c_uint32]),

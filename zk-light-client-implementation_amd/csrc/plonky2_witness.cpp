@@ -62,6 +62,11 @@ struct Runner {
             }
             return r->set(os[k++], v % GLP, pc);
         }
+        // out-of-order outputs (PoseidonGate rows): by index; the instruction then counts as complete
+        bool out_at(u32 idx, u64 v) {
+            k = no;
+            return idx < no ? r->set(os[idx], v % GLP, pc) : r->fail("output index out of range", pc);
+        }
         bool fail(int code) { return r->fail(wit_strerror(code), pc); }
     };
 
@@ -84,7 +89,7 @@ struct Runner {
             for (u32 i = 0; i < ni; i++)
                 if (epoch[is[i]] != cur) return fail("input not available", pc);
             IO io = {this, is, os, no, 0, pc};
-            if (!wit_exec(op, pr, np, ni, no, io)) return false;
+            if (!wit_exec<true>(op, pr, np, ni, no, io)) return false;
             if (io.k != no) return fail("output count mismatch", pc);
         }
         return true;

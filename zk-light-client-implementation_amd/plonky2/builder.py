@@ -978,6 +978,12 @@ class CircuitData:
                 raise AssertionError("witness %d: %s" % (i, err.raw[200 * i:200 * i + 200].split(b"\0")[0].decode()))
         return wires, pis[:, :npi]
 
+    def device_witness(self, ctx):
+        """the witness program resident on `ctx`'s GPU (zklc_plonky2_witness_program_create): `DeviceWitness.run` generates a
+        batch of witnesses straight into HBM (csrc/plonky2_witness_dev.hip)"""
+        assert self._program is not None, "call witness_program(example_inputs) first"
+        return DeviceWitness(ctx, self)
+
     def prover(self, ctx, hasher=0):
         """upload + preprocess the circuit on `ctx`'s GPU (zklc_plonky2_circuit_create)"""
         from .prover import Prover
@@ -1063,3 +1069,62 @@ class CircuitData:
                     wires[k & 255, k >> 8] = vals[r]
         pis = [vals[find(t)] for t in b.public_inputs]
         return wires, pis
+
+
+class DeviceWitness:
+    """A circuit's generator program on one GPU: witnesses are produced in HBM in the prover's layout, up to 64 per call.
+    The reference runs these generators on the CPU inside `CircuitData::prove` (prove_crypto/ed25519.rs:60,100)."""
+
+    def __init__(self, ctx, data):
+        import ctypes
+        from .. import _lib
+        self.ctx, self.data, self._lib = ctx, data, _lib.load()
+        pr = data._program
+        self.n_inputs, self.n_pi = len(pr["input_slots"]), len(pr["pi_slots"])
+        self.num_wires, self.n_rows = data.config["num_wires"], data.n
+        h = ctypes.c_void_p()
+        rc = self._lib.zklc_plonky2_witness_program_create(
+            ctx._h, pr["code"].ctypes.data, len(pr["code"]), pr["params"].ctypes.data, len(pr["params"]), pr["n_slots"],
+            pr["input_slots"].ctypes.data, self.n_inputs, pr["wire_slot"].ctypes.data, pr["wire_index"].ctypes.data, len(pr["wire_slot"]),
+            self.num_wires, self.n_rows, pr["pi_slots"].ctypes.data, self.n_pi, ctypes.byref(h))
+        ctx._check(rc)
+        self._h = h
+
+    def info(self, n_witnesses=1):
+        import ctypes
+        a, b, c = ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_uint32()
+        self.ctx._check(self._lib.zklc_plonky2_witness_program_info(self._h, n_witnesses, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"instructions": a.value, "levels": b.value, "launches": c.value}
+
+    def input_matrix(self, inputs_list):
+        pr = self.data._program
+        return np.array([[int(w[t]) for t in pr["input_targets"]] for w in inputs_list], dtype=np.uint64).reshape(len(inputs_list), -1)
+
+    def run(self, d_wires_ptr, inputs_list=None, input_values=None, stream=None):
+        """d_wires_ptr: device address of a ZERO-INITIALISED uint64 [k, num_wires, n] buffer (reusable: the same cells are written
+        every time).  Returns the public inputs uint64 [k, n_pi]; raises AssertionError if a witness does not exist."""
+        import ctypes
+        vals = self.input_matrix(inputs_list) if input_values is None else np.ascontiguousarray(input_values, dtype=np.uint64).reshape(-1, self.n_inputs)
+        k = vals.shape[0]
+        assert 1 <= k <= 64 and vals.shape[1] == self.n_inputs
+        pis = np.zeros((k, max(self.n_pi, 1)), dtype=np.uint64)
+        status = np.zeros(k, dtype=np.int32)
+        err = ctypes.create_string_buffer(200 * k)
+        rc = self._lib.zklc_plonky2_witness_run_dev(self.ctx._h, stream, self._h, vals.ctypes.data, k, d_wires_ptr, pis.ctypes.data,
+                                                    status.ctypes.data, err)
+        self.ctx._check(rc)
+        for i in range(k):
+            if status[i]:
+                raise AssertionError("witness %d: %s" % (i, err.raw[200 * i:200 * i + 200].split(b"\0")[0].decode()))
+        return pis[:, :self.n_pi]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.zklc_plonky2_witness_program_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
