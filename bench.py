@@ -474,16 +474,28 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     fills = [E.fill_ecdsa_targets(ed_targets, c2_msg, sg, pk_) for sg, pk_ in present]
     workers = [(ctx, ed_prover)] + [(c_, ed_data.prover(c_, HASH_GL)) for c_ in
                                     (zklc_amd.Context(torch.cuda.current_device()) for _ in range(nthreads - 2))]
-    # host threads of this rank's witness producer; two pinned buffers of wchunk x 490 MB each: smaller chunks when several ranks
-    # share the host
-    wchunk = max(1, min(12 if world == 1 else 6, host_cores() // max(1, world) - nthreads))
     nbuf = 2
     nw_, n_rows = ed_data.config["num_wires"], ed_data.n
-    pinned = [torch.zeros((wchunk, nw_, n_rows), dtype=torch.int64).pin_memory() for _ in range(nbuf)]
-    views = [p_.numpy().view(np.uint64) for p_ in pinned]
-    for _, pr in workers:       # warm every Ed25519 prover once (also pages the pinned buffers in)
-        data_w, pis_w = ed_data.generate_witness_native(fills[:1], out=views[0][:1])
-        pr.prove_host_ptr(views[0][0].ctypes.data, [int(x) for x in pis_w[0]])
+    dev_wit = not args.host_witness
+    if dev_wit:
+        # a5 on the GPU (csrc/plonky2_witness_dev.hip): the generator program runs on the device for a batch of signatures, the
+        # wire matrices (490 MB each) are written in HBM where zklc_plonky2_prove_dev reads them -- no host threads, no PCIe
+        wchunk = max(1, min(64, args.witness_batch))
+        wit_ctx = zklc_amd.Context(torch.cuda.current_device())
+        dwit = ed_data.device_witness(wit_ctx)
+        d_bufs = [torch.zeros((wchunk, nw_, n_rows), dtype=torch.int64, device=dev) for _ in range(nbuf)]
+        pis_w = dwit.run(d_bufs[0].data_ptr(), fills[:1], stream=wit_ctx.stream_ptr())
+        for c_, pr in workers:
+            pr.prove_dev(d_bufs[0][0].data_ptr(), [int(x) for x in pis_w[0]], stream=c_.stream_ptr())
+    else:
+        # host threads of this rank's witness producer; two pinned buffers of wchunk x 490 MB each: smaller chunks when several
+        # ranks share the host
+        wchunk = max(1, min(12 if world == 1 else 6, host_cores() // max(1, world) - nthreads))
+        pinned = [torch.zeros((wchunk, nw_, n_rows), dtype=torch.int64).pin_memory() for _ in range(nbuf)]
+        views = [p_.numpy().view(np.uint64) for p_ in pinned]
+        for _, pr in workers:       # warm every Ed25519 prover once (also pages the pinned buffers in)
+            data_w, pis_w = ed_data.generate_witness_native(fills[:1], out=views[0][:1])
+            pr.prove_host_ptr(views[0][0].ctypes.data, [int(x) for x in pis_w[0]])
     barrier()
     class PipelinedApprovals:
         """what BlockProver calls for `prove_approvals`: the result of the pipeline below instead of a sequential loop"""
@@ -545,7 +557,10 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                 idx = list(range(c0, c1))
                 sl = st["free_slots"].get()
                 t_ = time.perf_counter()
-                _, pis_ = ed_data.generate_witness_native([fills[i] for i in idx], out=views[sl][:len(idx)], threads=len(idx))
+                if dev_wit:
+                    pis_ = dwit.run(d_bufs[sl].data_ptr(), [fills[i] for i in idx], stream=wit_ctx.stream_ptr())
+                else:
+                    _, pis_ = ed_data.generate_witness_native([fills[i] for i in idx], out=views[sl][:len(idx)], threads=len(idx))
                 st["tw"][0] += time.perf_counter() - t_
                 with lock:
                     st["slot_left"][sl] = len(idx)
@@ -556,14 +571,17 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         except Exception as e:  # pragma: no cover
             fail(e)
 
-    def ed_worker(pr):
+    def ed_worker(c_, pr):
         try:
             while True:
                 item = st["ready"].get()
                 if item is None:
                     return
                 i, sl, k, pis_ = item
-                st["ed_proofs"][i] = pr.prove_host_ptr(views[sl][k].ctypes.data, pis_)
+                if dev_wit:
+                    st["ed_proofs"][i] = pr.prove_dev(d_bufs[sl][k].data_ptr(), pis_, stream=c_.stream_ptr())
+                else:
+                    st["ed_proofs"][i] = pr.prove_host_ptr(views[sl][k].ctypes.data, pis_)
                 st["ed_done"][i].set()
                 with lock:
                     st["slot_left"][sl] -= 1
@@ -619,7 +637,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         assert len(valid_pos) == n_sig, "fixture approvals must verify"
         t_verify = time.perf_counter() - t0
         threads = [threading.Thread(target=witness_producer)]
-        threads += [threading.Thread(target=ed_worker, args=(pr,)) for _, pr in workers]
+        threads += [threading.Thread(target=ed_worker, args=(c_, pr)) for c_, pr in workers]
         threads += [threading.Thread(target=fold_worker, args=(valid_keys,)), threading.Thread(target=dag_worker),
                     threading.Thread(target=ks_worker, args=(valid_keys,))]
         for th in threads:
@@ -659,13 +677,14 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     t_v = time.perf_counter() - t_v
     tw, fold_host, result = st["tw"], st["fold_host"], st["result"]
     out["block_i"] = {"metric": "full Block_i BFT-finality proofs/s (prove_block_bft on NEAR mainnet blocks 121798939..43, 100 validators, %d "
-                                "approvals), end to end from the header / approval / validator bytes: GPU pre-verification, native witness "
-                                "generation, %d Ed25519-circuit proofs, their left fold and closing proof, keys / stakes, seven SHA-256 "
+                                "approvals), end to end from the header / approval / validator bytes: GPU pre-verification, witness "
+                                "generation on the GPU, %d Ed25519-circuit proofs, their left fold and closing proof, keys / stakes, seven SHA-256 "
                                 "header-hash chains, bp_hash, heights, equalities, %d joining recursions, the BN128 wrap; every rank "
                                 "proves its own block" % (n_sig, n_sig, bprover.counts.get("recursive_proof", 0)),
                       "value": world / block_s, "unit": "proofs/s", "seconds_per_block": block_s, "blocks_timed": max(1, args.steps),
                       "seconds_until_signature_aggregate": sig_s, "streams": nthreads + 2,
-                      "approvals": n_sig, "witness_chunk": wchunk, "witness_cpu_seconds_total": tw[0], "preverify_ms": t_verify * 1e3,
+                      "approvals": n_sig, "witness_on": "gpu" if dev_wit else "host", "witness_batch": wchunk,
+                      "witness_producer_seconds_total": tw[0], "preverify_ms": t_verify * 1e3,
                       "fold_thread_seconds": {k: round(v / 1e3, 3) for k, v in fold_host.items()},
                       "dag_thread_seconds": {k: round(v, 3) for k, v in bprover.seconds.items()},
                       "dag_thread_counts": dict(bprover.counts), "keys_stakes_thread_seconds": result.get("keys_stakes_s"),
@@ -674,7 +693,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                       "first_block_s_incl_circuit_construction": t_setup,
                       "cpu_baseline": None,
                       "note": "every proof is a proof of the reference's own circuit (restated) on the reference's own mainnet data; "
-                              "witness generation is inside the timed region (host threads, overlapped); circuits are built and "
+                              "witness generation is inside the timed region (on the GPU by default, overlapped with proving); circuits are built and "
                               "uploaded by an untimed first block and reused (the reference rebuilds every circuit on every call); "
                               "dag_thread_seconds includes the wait for the signature aggregate inside prove_approvals; the "
                               "reference CPU prover cannot be built here (no Rust toolchain) and publishes no time for this step"}
@@ -682,6 +701,10 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         pr.close()
         if c_ is not ctx:
             c_.close()
+    if dev_wit:
+        dwit.close()
+        wit_ctx.close()
+        del d_bufs
     rp.close()
     rpw.close()
     fold_ctx.close()
@@ -708,6 +731,8 @@ def main():
     ap.add_argument("--no-prove", action="store_true", help="skip the plonky2 proof stage")
     ap.add_argument("--no-bn254-extras", action="store_true", help="skip the G2 MSM / Fr NTT / pairing stage")
     ap.add_argument("--prove-streams", type=int, default=4, help="proofs in flight per GPU in the Block_i stage")
+    ap.add_argument("--host-witness", action="store_true", help="Ed25519-circuit witnesses from the host interpreter (threads + PCIe) instead of the GPU")
+    ap.add_argument("--witness-batch", type=int, default=32, help="signatures per device witness batch (<= 64; 0.7 GB of HBM each)")
     args = ap.parse_args()
 
     import torch

@@ -1110,6 +1110,8 @@ class DeviceWitness:
         pis = np.zeros((k, max(self.n_pi, 1)), dtype=np.uint64)
         status = np.zeros(k, dtype=np.int32)
         err = ctypes.create_string_buffer(200 * k)
+        if stream is None:
+            stream = self.ctx.stream_ptr()
         rc = self._lib.zklc_plonky2_witness_run_dev(self.ctx._h, stream, self._h, vals.ctypes.data, k, d_wires_ptr, pis.ctypes.data,
                                                     status.ctypes.data, err)
         self.ctx._check(rc)

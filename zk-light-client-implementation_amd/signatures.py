@@ -93,11 +93,13 @@ class ApprovalProver:
     sha256(valid_keys))` (:125-139).  Everything after the pre-check is plonky2 proving on the GPU
     (zklc_amd.plonky2.Prover); witnesses come from the native interpreter (csrc/plonky2_witness.cpp)."""
 
-    def __init__(self, ctx, witness_threads=None):
+    def __init__(self, ctx, witness_threads=None, device_witness=True, witness_batch=8):
         from .plonky2 import HASH_GL
         from .plonky2.recursion import RecursionProver
         self.ctx = ctx
         self.threads = witness_threads
+        self.device_witness, self.witness_batch = device_witness, max(1, min(64, witness_batch))
+        self._dwit, self._dbuf = {}, None
         self._ed = {}                       # message length in bits -> (CircuitData, targets, Prover, verifier_only)
         self.recursion = RecursionProver(ctx, HASH_GL, threads=witness_threads)
 
@@ -117,7 +119,8 @@ class ApprovalProver:
         return ent
 
     def ed25519_proofs(self, msg, sigs, pks):
-        """one proof per (signature, public key): (common, verifier_only, proof bytes) triples"""
+        """one proof per (signature, public key): (common, verifier_only, proof bytes) triples.  The witnesses are generated on
+        the GPU in batches (csrc/plonky2_witness_dev.hip) and proven from HBM; `device_witness=False` uses the host interpreter"""
         from .plonky2 import ed25519_circuit as E
         data, targets, prover, vd = self.ed25519_circuit(len(msg))
         fills = [E.fill_ecdsa_targets(targets, msg, bytes(s), bytes(p)) for s, p in zip(sigs, pks)]
@@ -125,6 +128,19 @@ class ApprovalProver:
             self.ed25519_circuit(len(msg), example=fills[0])
         common = data.common_data()
         out = []
+        if self.device_witness and fills:
+            import torch
+            dw = self._dwit.get(len(msg))
+            if dw is None:
+                dw = self._dwit[len(msg)] = data.device_witness(self.ctx)
+            chunk = min(len(fills), self.witness_batch)
+            if self._dbuf is None or self._dbuf.shape[0] < chunk or self._dbuf.shape[1:] != (dw.num_wires, dw.n_rows):
+                self._dbuf = torch.zeros((chunk, dw.num_wires, dw.n_rows), dtype=torch.int64, device="cuda:%d" % self.ctx.device_id)
+            for c0 in range(0, len(fills), chunk):
+                pis = dw.run(self._dbuf.data_ptr(), fills[c0:c0 + chunk], stream=self.ctx.stream_ptr())
+                for k in range(len(pis)):
+                    out.append((common, vd, prover.prove_dev(self._dbuf[k].data_ptr(), [int(x) for x in pis[k]], stream=self.ctx.stream_ptr())))
+            return out
         chunk = max(1, self.threads or 4)
         for c0 in range(0, len(fills), chunk):
             wires, pis = data.generate_witness_native(fills[c0:c0 + chunk], threads=self.threads)
@@ -152,6 +168,9 @@ class ApprovalProver:
         return (rc, proof), valid_keys
 
     def close(self):
+        for dw in self._dwit.values():
+            dw.close()
+        self._dwit, self._dbuf = {}, None
         for _, _, prover, _ in self._ed.values():
             prover.close()
         self._ed = {}
