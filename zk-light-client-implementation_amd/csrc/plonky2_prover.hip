@@ -659,7 +659,7 @@ static int32_t p2_commit_coeffs(zklc_plonky2_circuit *c, hipStream_t st, p2_batc
     cap.resize((size_t)32 << cap_h);
     ZKLC_HIP(ctx, hipMemcpyAsync(cap.data(), p2_tree_level(b.tree, c->lde_bits, c->lde_bits - cap_h), cap.size(),
                                  hipMemcpyDeviceToHost, st));
-    ZKLC_HIP(ctx, hipStreamSynchronize(st));
+    ZKLC_HIP(ctx, zklc_stream_wait(st));
     return ZKLC_OK;
 }
 // values on the subgroup (natural order, in b.coeffs) -> coefficients in place, then commit
@@ -685,7 +685,7 @@ static int32_t p2_hash_no_pad(zklc_plonky2_circuit *c, hipStream_t st, const std
     ZKLC_HIP(ctx, hipMemcpyAsync(dv + 8, v.data(), v.size() * 8, hipMemcpyHostToDevice, st));
     P2_RC(zklc_bn254_merkle_commit_strided(ctx, st, dv + 8, 1, 0, 0, (u32)v.size(), 0, dv));
     ZKLC_HIP(ctx, hipMemcpyAsync(out32, dv, 32, hipMemcpyDeviceToHost, st));
-    ZKLC_HIP(ctx, hipStreamSynchronize(st));
+    ZKLC_HIP(ctx, zklc_stream_wait(st));
     return ZKLC_OK;
 }
 
@@ -1101,7 +1101,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
                 }
             }
             ZKLC_HIP(ctx, hipMemcpyAsync(c->d_apow, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st));
-            ZKLC_HIP(ctx, hipStreamSynchronize(st));   // `tab` is a stack-lifetime source
+            ZKLC_HIP(ctx, zklc_stream_wait(st));   // `tab` is a stack-lifetime source
             for (u32 k = 0; k < nch; k++) a.apow[k] = c->d_apow + (size_t)k * n_pow;
             for (u32 k = nch; k < P2_MAX_CH; k++) a.apow[k] = c->d_apow;
         }
@@ -1147,7 +1147,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
                            c->d_open);
         ZKLC_HIP(ctx, hipGetLastError());
         ZKLC_HIP(ctx, hipMemcpyAsync(open.data(), c->d_open, (size_t)n_open * sizeof(gl2), hipMemcpyDeviceToHost, st));
-        ZKLC_HIP(ctx, hipStreamSynchronize(st));
+        ZKLC_HIP(ctx, zklc_stream_wait(st));
     }
     // transcript order = FriOpenings: batch at zeta (constants, sigmas, wires, zs, partial products, quotient), then zs_next
     for (u32 i = 0; i < n_open; i++) {
@@ -1198,7 +1198,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
             fri_caps[r].resize((size_t)32 << cap_h);
             ZKLC_HIP(ctx, hipMemcpyAsync(fri_caps[r].data(), p2_tree_level(c->d_fri_tree[r], leaves_bits, leaves_bits - cap_h),
                                          fri_caps[r].size(), hipMemcpyDeviceToHost, st));
-            ZKLC_HIP(ctx, hipStreamSynchronize(st));
+            ZKLC_HIP(ctx, zklc_stream_wait(st));
             p2_observe_cap(ch, fri_caps[r], hasher);
             fri_betas[r].a = ch.challenge();
             fri_betas[r].b = ch.challenge();
@@ -1218,7 +1218,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
     }
     std::vector<gl2> final_poly((size_t)1 << final_bits);
     ZKLC_HIP(ctx, hipMemcpyAsync(final_poly.data(), c->d_final, final_poly.size() * sizeof(gl2), hipMemcpyDeviceToHost, st));
-    ZKLC_HIP(ctx, hipStreamSynchronize(st));
+    ZKLC_HIP(ctx, zklc_stream_wait(st));
     const u32 final_len = 1u << (final_bits - P.rate_bits);
     for (size_t i = final_len; i < final_poly.size(); i++)
         if (final_poly[i].a || final_poly[i].b) {
@@ -1248,7 +1248,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
             hipLaunchKernelGGL(p2_pow_kernel, dim3((unsigned)(batch / P2_THREADS)), dim3(P2_THREADS), 0, st, a);
             ZKLC_HIP(ctx, hipGetLastError());
             ZKLC_HIP(ctx, hipMemcpyAsync(&found, c->d_found, 8, hipMemcpyDeviceToHost, st));
-            ZKLC_HIP(ctx, hipStreamSynchronize(st));
+            ZKLC_HIP(ctx, zklc_stream_wait(st));
             if (found != ~0ULL) break;
             if (base > (1ULL << 50)) return ZKLC_ERR_INVALID_ARG;
         }
@@ -1307,7 +1307,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
                            c->d_gather_out);
         ZKLC_HIP(ctx, hipGetLastError());
         ZKLC_HIP(ctx, hipMemcpyAsync(qwords.data(), c->d_gather_out, qwords.size() * 8, hipMemcpyDeviceToHost, st));
-        ZKLC_HIP(ctx, hipStreamSynchronize(st));
+        ZKLC_HIP(ctx, zklc_stream_wait(st));
     }
 
     // ---- serialise

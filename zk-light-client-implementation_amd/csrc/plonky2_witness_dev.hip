@@ -303,7 +303,7 @@ static int32_t wit_create(zklc_ctx *ctx, zklc_witness_program *p, const uint32_t
     ZKLC_HIP(ctx, hipMemcpyAsync(p->d_wire_slot, wire_slot, n_wire_entries * 4, hipMemcpyHostToDevice, st));
     ZKLC_HIP(ctx, hipMemcpyAsync(p->d_wire_index, wire_index, n_wire_entries * 4, hipMemcpyHostToDevice, st));
     ZKLC_HIP(ctx, hipMemcpyAsync(p->d_pi_slots, pi_slots, (size_t)n_pi * 4, hipMemcpyHostToDevice, st));
-    ZKLC_HIP(ctx, hipStreamSynchronize(st));   // the sources are the caller's (and this function's) host buffers
+    ZKLC_HIP(ctx, zklc_stream_wait(st));   // the sources are the caller's (and this function's) host buffers
     return ZKLC_OK;
 }
 
@@ -367,7 +367,7 @@ static int32_t wit_padded(zklc_witness_program *p, u32 k, hipStream_t st) {
     WIT_ALLOC(p, P.d_level_start, P.level_start.size() * 4);
     ZKLC_HIP(ctx, hipMemcpyAsync(P.d_sched, out.data(), out.size() * sizeof(wit_sched), hipMemcpyHostToDevice, st));
     ZKLC_HIP(ctx, hipMemcpyAsync(P.d_level_start, P.level_start.data(), P.level_start.size() * 4, hipMemcpyHostToDevice, st));
-    ZKLC_HIP(ctx, hipStreamSynchronize(st));
+    ZKLC_HIP(ctx, zklc_stream_wait(st));
     return ZKLC_OK;
 }
 
@@ -426,7 +426,7 @@ extern "C" int32_t zklc_plonky2_witness_run_dev(zklc_ctx *ctx, void *stream, zkl
         // (re)allocate the batch buffers for W witnesses
         for (void **q : {(void **)&p->d_val, (void **)&p->d_inputs, (void **)&p->d_pis, (void **)&p->d_err})
             if (*q) {
-                ZKLC_HIP(ctx, hipStreamSynchronize(st));
+                ZKLC_HIP(ctx, zklc_stream_wait(st));
                 ZKLC_HIP(ctx, hipFree(*q));
                 p->allocs.erase(std::remove(p->allocs.begin(), p->allocs.end(), *q), p->allocs.end());
                 *q = nullptr;
@@ -478,7 +478,7 @@ extern "C" int32_t zklc_plonky2_witness_run_dev(zklc_ctx *ctx, void *stream, zkl
     unsigned long long errs[64];
     if (p->n_pi) ZKLC_HIP(ctx, hipMemcpyAsync(pi_out, p->d_pis, (size_t)p->n_pi * W * 8, hipMemcpyDeviceToHost, st));
     ZKLC_HIP(ctx, hipMemcpyAsync(errs, p->d_err, 64 * 8, hipMemcpyDeviceToHost, st));
-    ZKLC_HIP(ctx, hipStreamSynchronize(st));
+    ZKLC_HIP(ctx, zklc_stream_wait(st));
     if (d_trace) {
         // debugging aid: the slowest levels of the stepping kernel with their opcode mix (ticks of the 100 MHz wall clock)
         std::vector<unsigned long long> tr(p->n_levels + 1);

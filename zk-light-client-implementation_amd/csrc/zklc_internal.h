@@ -43,6 +43,27 @@ struct zklc_ctx {
         }                                                             \
     } while (0)
 
+// hipStreamSynchronize spins on the host by default; a proof synchronises ~10 times and a rank keeps several proving threads
+// (and a node several ranks) in flight, so the waits go through an event created with hipEventBlockingSync: the thread sleeps
+// until the stream reaches the event
+inline hipError_t zklc_stream_wait(hipStream_t st) {
+    static thread_local hipEvent_t ev = nullptr;
+    static thread_local int ev_dev = -1;
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!ev || ev_dev != dev) {
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;
+        e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        ev_dev = dev;
+    }
+    e = hipEventRecord(ev, st);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(ev);
+}
+
 // returns a device buffer of at least `bytes` in slot `slot`
 int32_t zklc_stage(zklc_ctx *ctx, int slot, size_t bytes, void **out);
 // *_dev entry points launch on exactly the hipStream_t they are given (NULL = the legacy default stream)

@@ -90,3 +90,81 @@ def prove_signatures_sharded(prove_one, n, group=None, device=None):
             out[r + k * world] = p
     assert all(p is not None for p in out)
     return out
+
+
+# ---------------------------------------------------------------------------------- one block over the GPUs of a node
+def _comm_device(device):
+    """tensors of a collective live on the GPU with RCCL and on the host with gloo"""
+    import torch.distributed as dist
+    return device if dist.get_backend() == "nccl" else None
+
+
+def send_obj(obj, dst, group=None, device=None):
+    """point-to-point transfer of a picklable object (a proof triple is ~150-200 KB): length, then the bytes"""
+    import pickle
+    import torch
+    import torch.distributed as dist
+    dev = _comm_device(device)
+    raw = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+    dist.send(torch.tensor([len(raw)], dtype=torch.int64, device=dev), dst, group=group)
+    dist.send(torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev) if dev is not None
+              else torch.frombuffer(bytearray(raw), dtype=torch.uint8), dst, group=group)
+
+
+def recv_obj(src, group=None, device=None):
+    import pickle
+    import torch
+    import torch.distributed as dist
+    dev = _comm_device(device)
+    n = torch.zeros(1, dtype=torch.int64, device=dev)
+    dist.recv(n, src, group=group)
+    buf = torch.zeros(int(n[0]), dtype=torch.uint8, device=dev)
+    dist.recv(buf, src, group=group)
+    return pickle.loads(buf.cpu().numpy().tobytes())
+
+
+def tree_fold(local, combine, group=None, device=None):
+    """Binary-tree aggregation of the ranks' partial aggregates (the opt-in replacement of the serial left fold of
+    signatures.rs:97-105 across GPUs).  Rank r holds `local` = the aggregate of ITS contiguous run of signature proofs (None if it
+    has none); at step s = 1, 2, 4, .. rank r with r % 2s == s sends its aggregate to rank r - s, which combines
+    (lower-rank aggregate first: the leaves stay in signature order) with `combine(a, b)` = one `recursive_proof(a, b)`.
+    log2(world) exchanges of one proof each over xGMI point-to-point links; rank 0 returns the block's aggregate, the others None."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    step = 1
+    while step < world:
+        if rank % (2 * step) == step:
+            send_obj(local, rank - step, group, device)
+            return None
+        if rank % (2 * step) == 0 and rank + step < world:
+            other = recv_obj(rank + step, group, device)
+            if local is None:
+                local = other
+            elif other is not None:
+                local = combine(local, other)
+        step *= 2
+    return local
+
+
+def gather_objects(obj, dst=0, group=None, device=None):
+    """every rank's object on rank `dst` (list in rank order; None elsewhere): the header / keys-stakes proofs made by the other
+    ranks travel to the rank that joins the DAG"""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world == 1:
+        return [obj]
+    if rank == dst:
+        return [obj if r == dst else recv_obj(r, group, device) for r in range(world)]
+    send_obj(obj, dst, group, device)
+    return None
+
+
+def assign_jobs(names, world, skip_rank0_first=True):
+    """header proofs -> ranks, round robin starting from the LAST rank so that rank 0 (which also joins the DAG and wraps) gets a
+    job only when there are more jobs than other ranks"""
+    out = {}
+    for k, name in enumerate(names):
+        out[name] = (world - 1 - k) % world if skip_rank0_first else k % world
+    return out

@@ -57,27 +57,40 @@ class KeysStakesProver:
         self.ctx = ctx
         self.sha = sha or Sha256Prover(ctx, HASH_GL)
         self.recursion = recursion or RecursionProver(ctx, HASH_GL)
+        # the circuit depends on WHICH validators signed (keys_stakes.rs:73-75) and on the lengths of the validator records, not on
+        # the key or stake bytes: the last few shapes stay resident (the reference rebuilds the circuit on every call)
+        self._cache, self.cache_size, self.cache_hits = [], 4, 0
 
     def prove_valid_keys_stakes_in_validators_list(self, valid_keys, valid_keys_hash, validators):
         """-> (common, verifier_only, proof) of the aggregated proof (keys_stakes.rs:244-265); public inputs = valid_keys bytes
         then the 17 bytes of the valid stake sum.  Raises AssertionError when the stake condition or the hash does not hold."""
         from .plonky2 import HASH_GL
         valid_keys = bytes(valid_keys)
-        data, vt, kt = keys_stakes_circuit(valid_keys, [len(v) for v in validators])
+        shape = (tuple(valid_keys[0::PK_HASH_BYTES + 1]), tuple(len(v) for v in validators))
+        ent = next((e for e in self._cache if e[0] == shape), None)
+        if ent is None:
+            data, vt, kt = keys_stakes_circuit(valid_keys, [len(v) for v in validators])
+            ent = (shape, data, vt, kt, data.prover(self.ctx, HASH_GL))
+            self._cache.append(ent)
+            if len(self._cache) > self.cache_size:
+                self._cache.pop(0)[4].close()
+        else:
+            self.cache_hits += 1
+        _, data, vt, kt, prover = ent
         pw = {t: x for ts, v in zip(vt, validators) for t, x in zip(ts, bytes(v))}
         pw.update(zip(kt, valid_keys))
-        data.witness_program(list(pw))
+        if data._program is None:
+            data.witness_program(list(pw))
         wires, pis = data.generate_witness_native([pw])
-        prover = data.prover(self.ctx, HASH_GL)
-        try:
-            ks = (data.common_data(), prover.verifier_data(), prover.prove(wires[0], [int(x) for x in pis[0]]))
-        finally:
-            prover.close()
+        ks = (data.common_data(), prover.verifier_data(), prover.prove(wires[0], [int(x) for x in pis[0]]))
         keys = bytes(int(x) & 0xFF for x in ks[2]["public_inputs"][:len(valid_keys)])
         (hc, hv), hp = self.sha.sha256_proof_u32(keys, valid_keys_hash)
         rc, proof = self.recursion.recursive_proof(ks, (hc, hv, hp), ks[2]["public_inputs"])
         return rc.common, rc.verifier_only, proof
 
     def close(self):
+        for e in self._cache:
+            e[4].close()
+        self._cache = []
         self.sha.close()
         self.recursion.close()

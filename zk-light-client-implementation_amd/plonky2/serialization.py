@@ -174,8 +174,9 @@ def write_proof_files(directory, common, verifier_only, proof, hasher, prefix=""
     """The files near_bft_finality/src/bin/prove_block.rs:320-458 writes next to a proof (`<prefix>proof.bin`, `<prefix>proof.json`,
     `<prefix>common_data.json`, `<prefix>verifier_data.json`; prefix "b0_" / "bn_" for the epoch blocks, "" otherwise) and, when the
     proof has the 33+ public inputs of a block proof, `<prefix>hash.json` = hex of public inputs 1..33 (:305-311,441-443).
-    `proof` is the JSON form or the `to_bytes` bytes.  `verifier_data.bin` (VerifierCircuitData::to_bytes with plonky2's gate
-    serializer) is not produced: nothing on this path reads it back (gnark reads the JSON files)."""
+    `proof` is the JSON form or the `to_bytes` bytes.  `<prefix>verifier_data.bin` (VerifierCircuitData::to_bytes with plonky2's
+    default gate serializer, zklc_amd/formats.py) is written when every gate of the circuit is in that serializer, which is the
+    case for the wrap proofs the reference writes."""
     import json
     import os
     os.makedirs(directory, exist_ok=True)
@@ -188,6 +189,14 @@ def write_proof_files(directory, common, verifier_only, proof, hasher, prefix=""
     for name, obj in (("proof.json", pj), ("common_data.json", common), ("verifier_data.json", verifier_only)):
         with open(os.path.join(directory, prefix + name), "w") as f:
             json.dump(obj, f, indent=2)
+    from .. import formats
+    try:
+        vbin = formats.verifier_data_to_bytes(verifier_only, common, hasher)
+    except ValueError:
+        vbin = None          # a gate outside plonky2's DefaultGateSerializer (the u32 gates of the inner circuits)
+    if vbin is not None:
+        with open(os.path.join(directory, prefix + "verifier_data.bin"), "wb") as f:
+            f.write(vbin)
     pis = pj["public_inputs"]
     if len(pis) >= 33 and all(int(x) < 256 for x in pis[1:33]):
         with open(os.path.join(directory, prefix + "hash.json"), "w") as f:

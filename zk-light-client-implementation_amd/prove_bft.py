@@ -141,39 +141,69 @@ class BlockProver:
         pis = current_block_header_proof[2]["public_inputs"] + aggregation[2]["public_inputs"]
         return self._rec(aggregation, current_block_header_proof, pis)
 
-    # ---- bft.rs:38-500
-    def prove_block_bft(self, ep2_last_block_bytes, ep2_last_block_hash, ep1_first_block_bytes, ep1_first_block_hash, blocks,
-                        validators, ep3_last_block_bytes=None, ep3_last_block_hash=None, validators_n_1=None):
-        """blocks: [(fields, header bytes)] in the order [Block_i+4, .., Block_i] (a randomly selected block) or
-        [Block_4, .., Block_0, Block_n-1] (epoch blocks); fields = dict with hash, height, prev_hash, epoch_id,
-        last_ds_final_hash, last_final_hash, approvals.  Returns (proof of Block_i / Block_0, proof of Block_n-1 or None)."""
+    # ---- the block-header proofs of prove_block_bft (bft.rs:64-205): independent leaves of the DAG
+    def header_jobs(self, ep2_last_block_bytes, ep2_last_block_hash, ep1_first_block_bytes, ep1_first_block_hash, blocks,
+                    ep3_last_block_bytes=None, ep3_last_block_hash=None):
+        """{name: (hash_bytes, block_bytes, keyword arguments of prove_block_header)} in the order the reference proves them.
+        The sharded driver (zklc_amd.distributed) hands each job to a rank; prove_block_bft takes the results back through
+        `header_proofs`."""
         o = TYPE_BYTE + PK_HASH_BYTES + INNER_LITE_BYTES
 
         def bp_hash_of(b):
             return b[o - 2 * PK_HASH_BYTES:o - PK_HASH_BYTES]
-        ep2_lb = self.prove_block_header(ep2_last_block_hash, ep2_last_block_bytes, bp_hash=bp_hash_of(ep2_last_block_bytes))
         q = TYPE_BYTE + PK_HASH_BYTES + BLOCK_HEIGHT_BYTES + PK_HASH_BYTES
-        ep1_fb = self.prove_block_header(ep1_first_block_hash, ep1_first_block_bytes, bp_hash=bp_hash_of(ep1_first_block_bytes),
-                                         next_epoch_id=ep1_first_block_bytes[q:q + PK_HASH_BYTES])
+        jobs = {"ep2_lb": (ep2_last_block_hash, ep2_last_block_bytes, {"bp_hash": bp_hash_of(ep2_last_block_bytes)}),
+                "ep1_fb": (ep1_first_block_hash, ep1_first_block_bytes, {"bp_hash": bp_hash_of(ep1_first_block_bytes),
+                                                                         "next_epoch_id": ep1_first_block_bytes[q:q + PK_HASH_BYTES]})}
+
+        def header(name, k, *names):
+            f, raw = blocks[k]
+            jobs[name] = (f["hash"], raw, {nm: f[nm] for nm in names})
+        header("b4", 0, "height", "epoch_id", "prev_hash")
+        header("b3", 1, "height", "epoch_id", "prev_hash")
+        header("b2", 2, "height", "epoch_id", "prev_hash", "last_ds_final_hash", "last_final_hash")
+        header("b1", 3, "height", "epoch_id", "prev_hash", "last_ds_final_hash", "last_final_hash")
+        if len(blocks) == 5:
+            header("bi0", 4, "height", "epoch_id")
+        elif len(blocks) == 6:
+            header("bi0", 4, "height", "epoch_id", "prev_hash", "last_ds_final_hash")
+            header("bn_1", 5, "height", "epoch_id")
+            if ep3_last_block_bytes is not None:
+                jobs["ep3_lb"] = (ep3_last_block_hash, ep3_last_block_bytes, {})
+        else:
+            raise ValueError("Invalid blocks.len() %d" % len(blocks))
+        return jobs
+
+    def prove_header_job(self, job):
+        return self.prove_block_header(job[0], job[1], **job[2])
+
+    # ---- bft.rs:38-500
+    def prove_block_bft(self, ep2_last_block_bytes, ep2_last_block_hash, ep1_first_block_bytes, ep1_first_block_hash, blocks,
+                        validators, ep3_last_block_bytes=None, ep3_last_block_hash=None, validators_n_1=None, header_proofs=None):
+        """blocks: [(fields, header bytes)] in the order [Block_i+4, .., Block_i] (a randomly selected block) or
+        [Block_4, .., Block_0, Block_n-1] (epoch blocks); fields = dict with hash, height, prev_hash, epoch_id,
+        last_ds_final_hash, last_final_hash, approvals.  Returns (proof of Block_i / Block_0, proof of Block_n-1 or None).
+        header_proofs: {name: proof} or a callable name -> proof for header proofs made elsewhere (header_jobs)."""
+        jobs = self.header_jobs(ep2_last_block_bytes, ep2_last_block_hash, ep1_first_block_bytes, ep1_first_block_hash, blocks,
+                                ep3_last_block_bytes, ep3_last_block_hash)
+
+        def hp(name):
+            got = None
+            if callable(header_proofs):
+                got = header_proofs(name)
+            elif header_proofs is not None:
+                got = header_proofs.get(name)
+            return got if got is not None else self.prove_header_job(jobs[name])
+        ep2_lb = hp("ep2_lb")
+        ep1_fb = hp("ep1_fb")
         n = len(ep1_fb[2]["public_inputs"])
         neph = self._eq(pi_bytes(ep2_lb, 0, 32), pi_bytes(ep1_fb, n - 32))
         ep1_fb = self._rec(ep1_fb, neph, ep1_fb[2]["public_inputs"])
-
-        def header(k, *names):
-            f, raw = blocks[k]
-            return self.prove_block_header(f["hash"], raw, **{nm: f[nm] for nm in names})
-        b4 = header(0, "height", "epoch_id", "prev_hash")
-        b3 = header(1, "height", "epoch_id", "prev_hash")
-        b2 = header(2, "height", "epoch_id", "prev_hash", "last_ds_final_hash", "last_final_hash")
+        b4, b3, b2 = hp("b4"), hp("b3"), hp("b2")
         b2 = self._rec(b2, self.prove_consecutive_heights_proofs([b4, b3, b2]), b2[2]["public_inputs"])
-        b1 = header(3, "height", "epoch_id", "prev_hash", "last_ds_final_hash", "last_final_hash")
-        if len(blocks) == 5:
-            bi0, bn_1_header = header(4, "height", "epoch_id"), None
-        elif len(blocks) == 6:
-            bi0 = header(4, "height", "epoch_id", "prev_hash", "last_ds_final_hash")
-            bn_1_header = header(5, "height", "epoch_id")
-        else:
-            raise ValueError("Invalid blocks.len() %d" % len(blocks))
+        b1 = hp("b1")
+        bi0 = hp("bi0")
+        bn_1_header = hp("bn_1") if len(blocks) == 6 else None
         hts = [int.from_bytes(pi_bytes(p, 32, 40), "little") for p in (b2, b1, bi0)]
         chain = [b2, b1, bi0]
         if bn_1_header is not None:
@@ -194,7 +224,7 @@ class BlockProver:
             bi = finality(bi0, b1, blocks[3][0]["approvals"], validators, [ep2_lb, ep1_fb, b1, b2])
             return three_hashes(bi, 0), None
         b0 = finality(bi0, b1, blocks[3][0]["approvals"], validators, [ep2_lb, ep1_fb, b1, b2])
-        ep3_lb = self.prove_block_header(ep3_last_block_hash, ep3_last_block_bytes)
+        ep3_lb = hp("ep3_lb")
         b_n_1 = finality(bn_1_header, b0, blocks[4][0]["approvals"], validators_n_1, [ep3_lb, ep2_lb, b0, b1])
         return three_hashes(b0, 1), three_hashes(b_n_1, 1)
 
