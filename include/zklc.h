@@ -287,7 +287,13 @@ uint64_t zklc_bn254_fr_ntt_workspace_bytes(uint32_t log_n);
 int32_t zklc_bn254_fr_ntt_dev(zklc_ctx *ctx, void *stream, uint64_t *d_data, uint32_t log_n, uint32_t flags, uint32_t coset,
                               void *d_workspace, uint64_t workspace_bytes);
 
+/* d_a[i] = (d_a[i] * d_b[i] - d_c[i]) * scale over Fr (device arrays of n elements, gnark layout; scale: 4 u64, host): the
+ * pointwise step of the quotient polynomial in `groth16.Prove` (gnark backend/groth16/bn254/prove.go `computeH`, un-vendored),
+ * between the three coset FFTs and the coset inverse FFT; scale = 1 / (5^n - 1). */
+int32_t zklc_bn254_fr_mul_sub_scale_dev(zklc_ctx *ctx, void *stream, uint64_t *d_a, const uint64_t *d_b, const uint64_t *d_c,
+                                        const uint64_t *scale, uint64_t n);
+
 #ifdef __cplusplus
 }
 #endif
-#endif
+#endif /* ZKLC_H */

@@ -61,6 +61,8 @@ _SIGS = {
     "zklc_bn254_fr_ntt_workspace_bytes": (ctypes.c_uint64, [ctypes.c_uint32]),
     "zklc_bn254_fr_ntt_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
                                                _u8p, ctypes.c_uint64]),
+    "zklc_bn254_fr_mul_sub_scale_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                         _u8p, ctypes.c_uint64]),
     "zklc_plonky2_circuit_create": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint32, _u8p,
                                                      _u8p, _u8p, ctypes.POINTER(ctypes.c_void_p)]),
     "zklc_plonky2_circuit_destroy": (None, [ctypes.c_void_p]),

@@ -114,6 +114,33 @@ __global__ void frn_store_kernel(const i32 *__restrict__ work, u64 *__restrict__
     for (int k = 0; k < 4; k++) o[k] = (u64)w[2 * k] | ((u64)w[2 * k + 1] << 32);
 }
 
+// a[i] = (a[i] * b[i] - c[i]) * scale: the quotient step of groth16 computeH between the coset FFTs and the coset inverse FFT
+// (gnark backend/groth16/bn254/prove.go `computeH`: scale = 1 / (g^n - 1), the inverse of the vanishing polynomial on the coset)
+__global__ void __launch_bounds__(256) frn_mul_sub_scale_kernel(u64 *__restrict__ a, const u64 *__restrict__ b, const u64 *__restrict__ c,
+                                                                 const u64 s0, const u64 s1, const u64 s2, const u64 s3, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 sw[4] = {s0, s1, s2, s3};
+    fr x = fr_mul(frn_load_gnark(a + i * 4), frn_load_gnark(b + i * 4));
+    x = fr_mul(fr_sub(x, frn_load_gnark(c + i * 4)), frn_load_gnark(sw));
+    u32 w[8];
+    fr_to_gnark(w, x);
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[i * 4 + k] = (u64)w[2 * k] | ((u64)w[2 * k + 1] << 32);
+}
+
+extern "C" int32_t zklc_bn254_fr_mul_sub_scale_dev(zklc_ctx *ctx, void *stream, uint64_t *d_a, const uint64_t *d_b, const uint64_t *d_c,
+                                                   const uint64_t *scale, uint64_t n) {
+    if (!ctx || !d_a || !d_b || !d_c || !scale) return ZKLC_ERR_INVALID_ARG;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = zklc_pick_stream(ctx, stream);
+    if (n)
+        hipLaunchKernelGGL(frn_mul_sub_scale_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_a, d_b, d_c, scale[0], scale[1], scale[2],
+                           scale[3], n);
+    ZKLC_HIP(ctx, hipGetLastError());
+    return ZKLC_OK;
+}
+
 extern "C" uint64_t zklc_bn254_fr_ntt_workspace_bytes(uint32_t log_n) { return ((uint64_t)40 << log_n) + ((uint64_t)20 << log_n) + 512; }
 
 extern "C" int32_t zklc_bn254_fr_ntt_dev(zklc_ctx *ctx, void *stream, uint64_t *d_data, uint32_t log_n, uint32_t flags, uint32_t coset,

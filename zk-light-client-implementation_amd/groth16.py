@@ -1,0 +1,175 @@
+"""`groth16.Prove` of the wrap step on the GPU: the assembly above the MSM / NTT kernels.
+
+Reference: gnark-plonky2-verifier/cmd/web-api.go:77 (`groth16.Prove(r1cs, pk, witness)`), :84 (`groth16.Verify`), :90-98 (the 256
+proof bytes); gnark v0.9.1 backend/groth16/bn254/prove.go is un-vendored (go.mod:8).  What it computes, and what runs where:
+
+  host    a, b, c = (A w, B w, C w) per constraint (the solved witness is the caller's: gnark's solver is the Go side)
+  GPU     computeH: 3 inverse NTTs, 3 coset NTTs, (a b - c) / (5^n - 1) pointwise, 1 coset inverse NTT  (zklc_bn254_fr_ntt_dev,
+          zklc_bn254_fr_mul_sub_scale_dev) -- data stays in HBM between the seven transforms
+  GPU     Ar  = alpha + sum_i w_i A_i + r delta                       one G1 MSM (alpha, delta appended as points)
+          Bs  = beta  + sum_i w_i B_i + s delta                       one G2 MSM
+          Bs1 = beta1 + sum_i w_i B1_i + s delta1                     one G1 MSM
+          Krs = sum_priv w_i K_i + sum_j h_j Z_j + s Ar + r Bs1 - r s delta1      one G1 MSM (Ar, Bs1 appended)
+  host    the eight coordinates out of Montgomery form -> the uint256[8] / 256-byte / compressed encodings (zklc_amd/formats.py)
+The proving key arrives as affine points in gnark-crypto's memory layout (what a cgo shim hands over) and stays
+resident on the device.  No CPU fallback: every transform and MSM is a kernel launch through the C ABI.
+"""
+import numpy as np
+
+R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+P = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+_M64 = (1 << 64) - 1
+
+
+def fr_to_mont_words(x):
+    m = (x % R) * (1 << 256) % R
+    return [(m >> (64 * i)) & _M64 for i in range(4)]
+
+
+def fr_to_regular_words(x):
+    x %= R
+    return [(x >> (64 * i)) & _M64 for i in range(4)]
+
+
+def fp_from_mont_words(w):
+    m = sum(int(w[i]) << (64 * i) for i in range(4))
+    return m * pow(1 << 256, P - 2, P) % P
+
+
+def fp_to_mont_words(x):
+    m = (x % P) * (1 << 256) % P
+    return [(m >> (64 * i)) & _M64 for i in range(4)]
+
+
+def g1_words(pt):
+    """affine point (x, y) or None (infinity) -> 8 u64 in gnark's layout"""
+    return [0] * 8 if pt is None else fp_to_mont_words(pt[0]) + fp_to_mont_words(pt[1])
+
+
+def g2_words(pt):
+    """((x0, x1), (y0, y1)) or None -> 16 u64: X.A0, X.A1, Y.A0, Y.A1"""
+    if pt is None:
+        return [0] * 16
+    (x0, x1), (y0, y1) = pt
+    return fp_to_mont_words(x0) + fp_to_mont_words(x1) + fp_to_mont_words(y0) + fp_to_mont_words(y1)
+
+
+class Groth16Prover:
+    """One proving key resident on one GPU.  pk: dict with n (domain size), n_public, point lists A, B1, K, Z (G1), B2 (G2) and
+    alpha1, beta1, delta1 (G1), beta2, delta2 (G2) as affine integer tuples (None = infinity) or as uint64 arrays in gnark's
+    layout under the same keys with the suffix `_words`."""
+
+    def __init__(self, ctx, pk):
+        import torch
+        self.ctx, self.torch = ctx, torch
+        self.dev = torch.device("cuda", ctx.device_id)
+        self.n, self.n_public = int(pk["n"]), int(pk["n_public"])
+        self.log_n = self.n.bit_length() - 1
+        assert 1 << self.log_n == self.n
+
+        def pts(name, conv, width):
+            if name + "_words" in pk:
+                a = np.ascontiguousarray(pk[name + "_words"], dtype=np.uint64).reshape(-1, width)
+            else:
+                v = pk[name]
+                a = np.array([conv(p) for p in (v if isinstance(v, list) else [v])], dtype=np.uint64).reshape(-1, width)
+            return a
+        A, B1, K, Z = pts("A", g1_words, 8), pts("B1", g1_words, 8), pts("K", g1_words, 8), pts("Z", g1_words, 8)
+        B2 = pts("B2", g2_words, 16)
+        al, be1, de1 = pts("alpha1", g1_words, 8), pts("beta1", g1_words, 8), pts("delta1", g1_words, 8)
+        be2, de2 = pts("beta2", g2_words, 16), pts("delta2", g2_words, 16)
+        self.n_wires = A.shape[0]
+        assert B1.shape[0] == B2.shape[0] == self.n_wires and K.shape[0] == self.n_wires - 1 - self.n_public and Z.shape[0] == self.n - 1
+        up = lambda a: torch.from_numpy(a.view(np.int64)).to(self.dev)
+        # MSM operand layouts: the fixed points first, the per-proof extras (alpha / beta, delta, Ar, Bs1) in the tail
+        self.d_A = up(np.concatenate([A, al, de1]))
+        self.d_B1 = up(np.concatenate([B1, be1, de1]))
+        self.d_B2 = up(np.concatenate([B2, be2, de2]))
+        self.d_KZ = up(np.concatenate([K, Z, np.zeros((2, 8), np.uint64), de1]))
+        lib = ctx._lib
+        self.ws1 = torch.empty(int(lib.zklc_bn254_g1_msm_workspace_bytes(max(self.d_A.shape[0], self.d_KZ.shape[0]))), dtype=torch.uint8, device=self.dev)
+        self.ws2 = torch.empty(int(lib.zklc_bn254_g2_msm_workspace_bytes(self.d_B2.shape[0])), dtype=torch.uint8, device=self.dev)
+        self.wsn = torch.empty(int(lib.zklc_bn254_fr_ntt_workspace_bytes(self.log_n)), dtype=torch.uint8, device=self.dev)
+        self.den = np.array(fr_to_mont_words(pow((pow(5, self.n, R) - 1) % R, R - 2, R)), dtype=np.uint64)
+        self.last_ms = {}
+
+    def _ntt(self, d, flags, coset):
+        self.ctx._check(self.ctx._lib.zklc_bn254_fr_ntt_dev(self.ctx._h, self.ctx.stream_ptr(), d.data_ptr(), self.log_n, flags, coset,
+                                                            self.wsn.data_ptr(), self.wsn.numel()))
+
+    def compute_h(self, a, b, c):
+        """gnark `computeH`; a, b, c: uint64 [n, 4] (Montgomery) constraint evaluations -> device tensor of the n coefficients of h
+        (regular form is produced by the caller: the MSM takes non-Montgomery scalars)"""
+        torch = self.torch
+        from . import _lib
+        d = [torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint64).view(np.int64)).to(self.dev) for x in (a, b, c)]
+        for x in d:
+            self._ntt(x, _lib.NTT_INVERSE, 0)                 # evaluations on the subgroup -> coefficients
+            self._ntt(x, 0, 1)                                # -> evaluations on the coset 5 <w>
+        self.ctx._check(self.ctx._lib.zklc_bn254_fr_mul_sub_scale_dev(self.ctx._h, self.ctx.stream_ptr(), d[0].data_ptr(), d[1].data_ptr(),
+                                                                      d[2].data_ptr(), self.den.ctypes.data, self.n))
+        self._ntt(d[0], _lib.NTT_INVERSE, 1)                  # coset evaluations of (a b - c) / Z -> coefficients of h
+        # b and c go back to torch's allocator when this function returns, and torch hands blocks out on ITS stream: the kernels
+        # that still read them run on ctx's stream, so drain it first
+        self.ctx.synchronize()
+        return d[0]
+
+    def _msm1(self, d_pts, d_sc, n):
+        torch = self.torch
+        out = torch.zeros(8, dtype=torch.int64, device=self.dev)
+        inf = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        torch.cuda.current_stream(self.dev).synchronize()
+        self.ctx.bn254_g1_msm_dev(d_pts, d_sc, n, out, inf, self.ws1, self.ws1.numel(), stream=self.ctx.stream_ptr())
+        return out, inf
+
+    def prove(self, witness, abc, r, s):
+        """witness: all wire values (ints, witness[0] = 1); abc = (a, b, c): per-constraint values of A w, B w, C w (ints, padded
+        to n by this function); r, s: the prover's blinding scalars.  Returns the proof as 8 integers in the order of gnark's
+        WriteRawTo / Verifier.sol: A.x, A.y, B.x1, B.x0, B.y1, B.y0, C.x, C.y."""
+        import time
+        torch = self.torch
+        t0 = time.perf_counter()
+        assert len(witness) == self.n_wires and witness[0] % R == 1
+        mont = lambda v: np.array([fr_to_mont_words(x) for x in list(v) + [0] * (self.n - len(v))], dtype=np.uint64)
+        d_h = self.compute_h(*(mont(v) for v in abc))
+        t1 = time.perf_counter()
+        # h comes back in Montgomery form; the MSM wants regular scalars: one more pass through the host for this size class would
+        # cost PCIe, so the conversion is a multiplication by 1 on the device: (h * 1_regular) leaves h / 2^256 ... done by the
+        # same pointwise kernel: a <- (a * b - c) * scale with b = 1 (Montgomery of 1 is 2^256: use b = raw 1), c = 0, scale = raw 1
+        one_raw = torch.zeros((self.n, 4), dtype=torch.int64, device=self.dev)
+        one_raw[:, 0] = 1                                     # the Montgomery form of 2^-256: multiplying by it strips one factor 2^256
+        zero = torch.zeros((self.n, 4), dtype=torch.int64, device=self.dev)
+        mont_one = np.array(fr_to_mont_words(1), dtype=np.uint64)
+        torch.cuda.current_stream(self.dev).synchronize()     # torch filled one_raw / zero on ITS stream; the kernels run on ctx's
+        self.ctx._check(self.ctx._lib.zklc_bn254_fr_mul_sub_scale_dev(self.ctx._h, self.ctx.stream_ptr(), d_h.data_ptr(), one_raw.data_ptr(),
+                                                                      zero.data_ptr(), mont_one.ctypes.data, self.n))
+        w_reg = np.array([fr_to_regular_words(x) for x in witness], dtype=np.uint64)
+        tail = lambda *xs: np.array([fr_to_regular_words(x) for x in xs], dtype=np.uint64)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(self.dev)
+        sc_a = up(np.concatenate([w_reg, tail(1, r)]))
+        sc_b = up(np.concatenate([w_reg, tail(1, s)]))
+        torch.cuda.current_stream(self.dev).synchronize()
+        ar, ar_inf = self._msm1(self.d_A, sc_a, self.d_A.shape[0])
+        bs1, bs1_inf = self._msm1(self.d_B1, sc_b, self.d_B1.shape[0])
+        bs2 = torch.zeros(17, dtype=torch.int64, device=self.dev)
+        torch.cuda.current_stream(self.dev).synchronize()
+        self.ctx._check(self.ctx._lib.zklc_bn254_g2_msm_dev(self.ctx._h, self.ctx.stream_ptr(), self.d_B2.data_ptr(), sc_b.data_ptr(),
+                                                            self.d_B2.shape[0], bs2.data_ptr(), bs2.data_ptr() + 128, self.ws2.data_ptr(),
+                                                            self.ws2.numel()))
+        # Krs: the points Ar and Bs1 of this proof go into the two free slots before delta
+        nk = self.d_KZ.shape[0]
+        self.ctx.synchronize()                                # Ar, Bs1, h are complete before torch touches them
+        self.d_KZ[nk - 3] = ar
+        self.d_KZ[nk - 2] = bs1
+        sc_k = torch.cat([up(w_reg[1 + self.n_public:]), d_h[:self.n - 1], up(tail(s, r, (R - r * s % R) % R))])
+        torch.cuda.current_stream(self.dev).synchronize()
+        krs, krs_inf = self._msm1(self.d_KZ, sc_k, nk)
+        self.ctx.synchronize()
+        t2 = time.perf_counter()
+        if int(ar_inf[0]) or int(krs_inf[0]) or int(bs2[16]) or int(bs1_inf[0]):
+            raise ValueError("groth16: a proof element is the point at infinity (degenerate key or witness)")
+        a_w, k_w, b_w = ar.cpu().numpy().view(np.uint64), krs.cpu().numpy().view(np.uint64), bs2[:16].cpu().numpy().view(np.uint64)
+        f = fp_from_mont_words
+        proof = [f(a_w[0:4]), f(a_w[4:8]), f(b_w[4:8]), f(b_w[0:4]), f(b_w[12:16]), f(b_w[8:12]), f(k_w[0:4]), f(k_w[4:8])]
+        self.last_ms = {"compute_h": (t1 - t0) * 1e3, "msm": (t2 - t1) * 1e3}
+        return proof
