@@ -95,6 +95,19 @@ def pmc_traffic(n):
         return None
 
 
+VALU_INT_PEAK_TLOPS = 37.7    # measured issue ceiling of the quarter-rate integer class (v_mad_u64_u32, carry adds): profiles/r02_valu_ubench.txt
+
+
+def poseidon_pmc():
+    """counters of gl_hash_leaves_kernel at the bench's Merkle shape from the committed rocprofv3 PMC passes
+    (tools/pmc_merkle.sh -> profiles/poseidon_pmc_latest.json); None when absent"""
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "poseidon_pmc_latest.json")))
+        return j if j.get("leaves") == 1 << 20 and j.get("width") == 234 else None
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(pk, sg, ms, budget_s=12.0):
     """Oracle C restatement (oracle/c/ed25519_oracle.c) on all host cores, bounded sample."""
     from oracle import cport
@@ -265,6 +278,15 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
     return res
 
 
+def pts1_256(B):
+    """256 distinct G1 points in gnark's layout (an arithmetic progression on the curve; host, untimed)"""
+    cur, step, out = B.mul(54321, B.G1), B.mul(991, B.G1), []
+    for _ in range(256):
+        out.append(B.to_mont_words(cur[0]) + B.to_mont_words(cur[1]))
+        cur = B.add(cur, step)
+    return out
+
+
 def run_bn254_extras(ctx, dev, reduce_max, barrier, world):
     """G2 MSM, Fr coset NTT and Groth16-shaped pairing checks (the rest of the Groth16 wrap)"""
     import torch
@@ -321,6 +343,36 @@ def run_bn254_extras(ctx, dev, reduce_max, barrier, world):
     ms = timed(lambda: ctx._check(lib.zklc_bn254_pairing_check_dev(ctx._h, sp, d1.data_ptr(), d2.data_ptr(), 4, checks, d_r.data_ptr(), None)), reps=2)
     assert int(d_r.sum()) == checks
     out["pairing_checks_k4_x4096"] = {"ms": ms, "value": world * checks / ms * 1e3, "unit": "checks/s"}
+    del d1, d2, d_r
+    # the whole of `groth16.Prove` at the size BASELINE configs[3] names (2^22 constraints / wires): computeH (seven Fr NTTs + the
+    # pointwise quotient in HBM) and the four multi-exponentiations, through zklc_amd.groth16.Groth16Prover (row a10).  Synthetic
+    # key (256 distinct points tiled) and random operands: the proof is not meaningful, the work is the real prover's.
+    from zklc_amd.groth16 import Groth16Prover, fr_to_mont_words
+    lg = 22
+    n = 1 << lg
+    g1p = np.array(pts1_256(B), dtype=np.uint64)
+    g2p = np.array(pts, dtype=np.uint64)
+    tile1 = lambda k: np.tile(g1p, ((k + 255) // 256, 1))[:k]
+    pk = {"n": n, "n_public": 4, "A_words": tile1(n), "B1_words": tile1(n), "K_words": tile1(n - 5), "Z_words": tile1(n - 1),
+          "B2_words": np.tile(g2p, (n // 256, 1)), "alpha1_words": g1p[1:2], "beta1_words": g1p[2:3], "delta1_words": g1p[3:4],
+          "beta2_words": g2p[1:2], "delta2_words": g2p[2:3]}
+    t0 = time.perf_counter()
+    gp = Groth16Prover(ctx, pk)
+    t_up = time.perf_counter() - t0
+    del pk
+    w = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64)
+    w[:, 3] &= np.uint64((1 << 60) - 1)
+    w[0] = [1, 0, 0, 0]
+    abc = tuple(rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64) & np.uint64((1 << 61) - 1) for _ in range(3))
+    gp.prove_words(w, abc, 12345, 67890)
+    t0 = time.perf_counter()
+    gp.prove_words(w, abc, 12345, 67890)
+    dt = time.perf_counter() - t0
+    out["groth16_prove_2p22"] = {"ms": reduce_max(dt * 1e3), "value": world / dt, "unit": "proofs/s", "stages_ms": dict(gp.last_ms),
+                                 "key_upload_s_untimed": t_up,
+                                 "published_cpu": "30 s per Groth16 proof on a 16-core Ryzen 9 7950X (gnark-plonky2-verifier/README.md:35-39; "
+                                                  "the only number the reference publishes for this step; its circuit size is not stated)",
+                                 "note": "2^22 wires / constraints, operands handed over as host arrays (PCIe inside), synthetic key"}
     return out
 
 
@@ -758,6 +810,41 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                               "uploaded by an untimed first block and reused (the reference rebuilds every circuit on every call); "
                               "dag_thread_seconds includes the wait for the signature aggregate inside prove_approvals; the "
                               "reference CPU prover cannot be built here (no Rust toolchain) and publishes no time for this step"}
+    if args.c5_validators and not strong:
+        # BASELINE configs[4] (C5), the part the unmodified circuits can express: a synthetic epoch of N validators who all sign the
+        # same Approval message -> batched GPU pre-verification, N Ed25519-circuit proofs (witnesses on the GPU), the left fold and
+        # the closing proof with sha256(valid_keys), through the same pipeline as the block above (one rank = one GPU)
+        from oracle import ed25519_ref as ref
+        nv = int(args.c5_validators)
+        keys = [ref.synthetic_seed(1, i) for i in range(nv)]
+        pk_l = [ref.keypair(k_)[2] for k_ in keys]
+        sg_l = [ref.sign(k_, c2_msg) for k_ in keys]
+        t_ = time.perf_counter()
+        okv = ctx.ed25519_verify_batch(b"".join(pk_l), b"".join(sg_l), c2_msg)
+        t_pre = time.perf_counter() - t_
+        assert int(okv.sum()) == nv
+        vkeys = b"".join(bytes([i & 0xFF]) + pk_l[i] for i in range(nv))
+        fills = [E.fill_ecdsa_targets(ed_targets, c2_msg, sg, pk_) for sg, pk_ in zip(sg_l, pk_l)]
+        n_sig, my_sigs = nv, list(range(nv))
+        reset()
+        t_ = time.perf_counter()
+        th = [threading.Thread(target=witness_producer)] + [threading.Thread(target=ed_worker, args=(c_, pr)) for c_, pr in workers] + \
+             [threading.Thread(target=fold_worker, args=(vkeys,))]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        if st["errors"]:
+            raise st["errors"][0]
+        rc5, proof5, _ = stub.future.result()
+        dt5 = reduce_max(time.perf_counter() - t_)
+        from oracle import plonky2_verifier as V5
+        V5.verify(json.loads(json.dumps(S.proof_from_bytes(proof5, rc5.common, HASH_GL))), rc5.verifier_only, rc5.common)
+        out["c5_synthetic_epoch"] = {"validators": nv, "seconds": dt5, "signature_proofs_per_s": world * nv / dt5, "preverify_ms": t_pre * 1e3,
+                                     "aggregate_verified": True, "witness_on": "gpu" if dev_wit else "host",
+                                     "note": "N Ed25519-circuit proofs + %d fold steps + closing proof on one GPU per rank; the keys / "
+                                             "stakes circuit of the reference cannot express N > 255 positions (pos as u8), so C5 stops "
+                                             "at the signature aggregate" % (nv - 1)}
     for c_, pr in workers:
         pr.close()
         if c_ is not ctx:
@@ -796,6 +883,8 @@ def main():
                     help="weak: every rank proves its own block per step; strong: all ranks prove ONE block per step (signature shards, "
                          "tree fold over the ranks, header proofs on the other ranks)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo lets several ranks share one GPU)")
+    ap.add_argument("--c5-validators", type=int, default=0, help="also run the C5 stage: a synthetic epoch of this many validators "
+                    "(1000 in BASELINE configs[4]; ~85 s on one MI355X), reported under stages.prove.c5_synthetic_epoch")
     ap.add_argument("--host-witness", action="store_true", help="Ed25519-circuit witnesses from the host interpreter (threads + PCIe) instead of the GPU")
     ap.add_argument("--witness-batch", type=int, default=32, help="signatures per device witness batch (<= 64; 0.7 GB of HBM each)")
     args = ap.parse_args()
@@ -925,13 +1014,25 @@ def main():
                            "proofs_per_block": dict(blk["dag_thread_counts"], ed25519_circuit=blk["approvals"],
                                                     fold_and_closing_recursions=blk["approvals"], keys_stakes_and_its_hash=3, bn128_wrap=1),
                            "msm_2p22_melem_per_s": stages["msm"]["value"]},
-                "roofline": dict(mk["roofline"], kernel="gl_hash_leaves_kernel (+ Merkle levels): Poseidon leaf hashing, 58 % of the "
-                                                        "kernel time of a block proof", kernel_ms=mk["ms"],
+                "roofline": dict(mk["roofline"], kernel="gl_hash_leaves_kernel (+ Merkle levels, ~3 % of the permutations): Poseidon leaf "
+                                                        "hashing, ~45 % of the kernel time of a block proof", kernel_ms=mk["ms"],
                                  note="measured live by the `merkle` stage (HIP events on the launch stream): 2^20 leaves x 234 columns; "
-                                      + mk["roofline"]["note"]),
+                                      + mk["roofline"]["note"] + "; the binding resource is integer VALU issue, see `valu`"),
                 "final_proof_verified": blk["final_proof_verified"],
                 "block_i": blk, "stages": dict(stages, ed25519_verify=verify),
             }
+            pm = poseidon_pmc()
+            if pm is not None:
+                out["roofline"]["traffic"] = pm.get("hbm_bytes_per_launch")
+                if "SQ_INSTS_VALU_per_launch" in pm:
+                    lane_instr = pm["SQ_INSTS_VALU_per_launch"] * 64
+                    ach = lane_instr / (mk["ms"] * 1e-3) / 1e12
+                    out["roofline"]["valu"] = {
+                        "bound": "valu-int", "achieved": ach, "peak": VALU_INT_PEAK_TLOPS, "unit": "T lane-instr/s", "frac": ach / VALU_INT_PEAK_TLOPS,
+                        "instructions_per_permutation": lane_instr / ((1 << 20) * 31),
+                        "note": "SQ_INSTS_VALU of the kernel (profiles/poseidon_pmc_latest.json) x 64 lanes / the live kernel time; peak = the "
+                                "measured issue rate of v_mad_u64_u32 / v_add_co / v_addc (profiles/r02_valu_ubench.txt); fast-class "
+                                "instructions (v_mov, v_add_u32) issue ~1.7x faster, so the fraction can exceed 1"}
             if "cpu_baseline" in edp:
                 cb = edp["cpu_baseline"]
                 out["cpu_baseline"] = {"value": cb["value"] / blk["approvals"], "unit": "proofs/s (upper bound)", "cores": cb["cores"],

@@ -126,12 +126,20 @@ class Groth16Prover:
         """witness: all wire values (ints, witness[0] = 1); abc = (a, b, c): per-constraint values of A w, B w, C w (ints, padded
         to n by this function); r, s: the prover's blinding scalars.  Returns the proof as 8 integers in the order of gnark's
         WriteRawTo / Verifier.sol: A.x, A.y, B.x1, B.x0, B.y1, B.y0, C.x, C.y."""
+        assert len(witness) == self.n_wires and witness[0] % R == 1
+        mont = lambda v: np.array([fr_to_mont_words(x) for x in list(v) + [0] * (self.n - len(v))], dtype=np.uint64)
+        w_reg = np.array([fr_to_regular_words(x) for x in witness], dtype=np.uint64)
+        return self.prove_words(w_reg, tuple(mont(v) for v in abc), r, s)
+
+    def prove_words(self, w_reg, abc_mont, r, s):
+        """the same with the operands as arrays, the way a cgo shim hands them over: w_reg uint64 [n_wires, 4] = the witness in
+        regular (non-Montgomery) form (gnark converts with `fr.Element.BigInt` before MultiExp as well), abc_mont three uint64
+        [n, 4] arrays in gnark's Montgomery layout"""
         import time
         torch = self.torch
         t0 = time.perf_counter()
-        assert len(witness) == self.n_wires and witness[0] % R == 1
-        mont = lambda v: np.array([fr_to_mont_words(x) for x in list(v) + [0] * (self.n - len(v))], dtype=np.uint64)
-        d_h = self.compute_h(*(mont(v) for v in abc))
+        w_reg = np.ascontiguousarray(w_reg, dtype=np.uint64).reshape(self.n_wires, 4)
+        d_h = self.compute_h(*abc_mont)
         t1 = time.perf_counter()
         # h comes back in Montgomery form; the MSM wants regular scalars: one more pass through the host for this size class would
         # cost PCIe, so the conversion is a multiplication by 1 on the device: (h * 1_regular) leaves h / 2^256 ... done by the
@@ -143,7 +151,6 @@ class Groth16Prover:
         torch.cuda.current_stream(self.dev).synchronize()     # torch filled one_raw / zero on ITS stream; the kernels run on ctx's
         self.ctx._check(self.ctx._lib.zklc_bn254_fr_mul_sub_scale_dev(self.ctx._h, self.ctx.stream_ptr(), d_h.data_ptr(), one_raw.data_ptr(),
                                                                       zero.data_ptr(), mont_one.ctypes.data, self.n))
-        w_reg = np.array([fr_to_regular_words(x) for x in witness], dtype=np.uint64)
         tail = lambda *xs: np.array([fr_to_regular_words(x) for x in xs], dtype=np.uint64)
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(self.dev)
         sc_a = up(np.concatenate([w_reg, tail(1, r)]))
