@@ -981,7 +981,7 @@ def main():
             "config": {"workload": "C2: batched Ed25519 verify, %d Block_i approval sets x %d validators per GPU per step "
                                    "(%d signatures, 41-byte per-block message, 1%% corrupted)" % (n // VALIDATORS, VALIDATORS, n),
                        "signatures_per_gpu": n, "blocks_per_s": value / VALIDATORS, "valid": n_valid,
-                       "kernel_variant": int(os.environ.get("ZKLC_ED_VARIANT", "1"))},
+                       "kernel": "ed25519_verify_kernel_v1 (8-entry per-lane table in LDS, radix-2^25.5 field)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n),
                          "kernel": "ed25519_verify_kernel", "kernel_ms": kernel_ms,

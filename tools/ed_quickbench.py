@@ -1,4 +1,5 @@
-"""Quick A/B of the Ed25519 verify-kernel variants on the GPU (not the driver's bench)."""
+"""Quick timing of the Ed25519 verify kernel at several batch sizes (not the driver's bench).  The four variants of round 1
+(profiles/r01_ed25519_variants_v2.txt) are gone: only the fastest (v1) is compiled."""
 import os
 import sys
 import time
@@ -18,8 +19,7 @@ for n in [100, 1 << 14, 1 << 18, 1 << 20]:
     sg = torch.tensor(np.frombuffer(b"".join(sigs), np.uint8).copy(), device="cuda").view(base_n, 64).repeat(reps, 1)[:n].contiguous()
     m = torch.tensor(np.frombuffer(msg, np.uint8).copy(), device="cuda")
     ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
-    for v in range(4):
-        os.environ["ZKLC_ED_VARIANT"] = str(v)
+    for v in (1,):
         with zklc_amd.Context(0) as c:
             st = torch.cuda.Stream()
             st.wait_stream(torch.cuda.current_stream())

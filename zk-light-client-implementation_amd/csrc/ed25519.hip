@@ -1,20 +1,13 @@
 // Batched Ed25519 verification + SHA-512 kernels (gfx950) and their C ABI.
-// The verify kernel itself lives in ed25519_kernels.inc (compiled as several
-// tuning variants, ed25519_v*.hip); this TU holds the base-table and SHA-512
-// kernels and the C ABI entry points.
+// The verify kernel itself lives in ed25519_kernels.inc (instantiated by
+// ed25519_v1.hip: 8-entry per-lane table in LDS, field operations inlined -- the
+// fastest of the four variants measured in round 1, profiles/r01_ed25519_variants_v2.txt);
+// this TU holds the base-table and SHA-512 kernels and the C ABI entry points.
 #include "ed25519_verify.cuh"
 #include "zklc_internal.h"
 #include <stdlib.h>
 
-#define ZKLC_ED_NVARIANTS 4
-typedef void (*zklc_ed_launch_fn)(hipStream_t, const uint8_t *, const uint8_t *, const uint8_t *, u32, u32, u32, const void *,
-                                  uint8_t *);
-void zklc_ed_launch_v0(hipStream_t, const uint8_t *, const uint8_t *, const uint8_t *, u32, u32, u32, const void *, uint8_t *);
 void zklc_ed_launch_v1(hipStream_t, const uint8_t *, const uint8_t *, const uint8_t *, u32, u32, u32, const void *, uint8_t *);
-void zklc_ed_launch_v2(hipStream_t, const uint8_t *, const uint8_t *, const uint8_t *, u32, u32, u32, const void *, uint8_t *);
-void zklc_ed_launch_v3(hipStream_t, const uint8_t *, const uint8_t *, const uint8_t *, u32, u32, u32, const void *, uint8_t *);
-static const zklc_ed_launch_fn ED_LAUNCHERS[ZKLC_ED_NVARIANTS] = {zklc_ed_launch_v0, zklc_ed_launch_v1, zklc_ed_launch_v2,
-                                                                  zklc_ed_launch_v3};
 
 __global__ void __launch_bounds__(128) ed25519_base_table_kernel(ge_niels *tab) {
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,14 +32,7 @@ sha512_batch_kernel(const uint8_t *__restrict__ in, u32 stride, u32 len, u32 n, 
 }
 
 int32_t zklc_ed25519_init(zklc_ctx *ctx) {
-    // tuning knob: which compiled variant of the verify kernel to launch
-    // 0: W=3 table, field ops as calls   1: W=3, field ops inlined (default, fastest: profiles/r01_ed25519_variants_v2.txt)
-    // 2: W=2 table (8 waves/CU), inlined  3: W=2, calls
     ctx->ed_variant = 1;
-    if (const char *e = getenv("ZKLC_ED_VARIANT")) {
-        int v = atoi(e);
-        if (v >= 0 && v < ZKLC_ED_NVARIANTS) ctx->ed_variant = v;
-    }
     ZKLC_HIP(ctx, hipMalloc(&ctx->ed_btab, sizeof(ge_niels) * ZKLC_ED_BTABLE));
     hipLaunchKernelGGL(ed25519_base_table_kernel, dim3(1), dim3(128), 0, ctx->stream, (ge_niels *)ctx->ed_btab);
     ZKLC_HIP(ctx, hipGetLastError());
@@ -68,8 +54,7 @@ extern "C" int32_t zklc_ed25519_verify_batch_dev(zklc_ctx *ctx, void *stream, co
     if (msg_stride != 0 && msg_stride < msg_len) return ZKLC_ERR_INVALID_ARG;
     if (((uintptr_t)d_pks | (uintptr_t)d_sigs) & 15) return ZKLC_ERR_INVALID_ARG;  // 16-byte vector loads
     ZKLC_HIP(ctx, hipSetDevice(ctx->device));
-    ED_LAUNCHERS[ctx->ed_variant](zklc_pick_stream(ctx, stream), d_pks, d_sigs, d_msgs, msg_len, msg_stride, n, ctx->ed_btab,
-                                  d_ok);
+    zklc_ed_launch_v1(zklc_pick_stream(ctx, stream), d_pks, d_sigs, d_msgs, msg_len, msg_stride, n, ctx->ed_btab, d_ok);
     ZKLC_HIP(ctx, hipGetLastError());
     return ZKLC_OK;
 }
