@@ -69,6 +69,32 @@ def test_lde_matches_oracle(zctx, log_n, rate_bits, batch):
         assert int(want[0, k]) == gl.eval_poly([int(x) for x in c[0]], 7 * pow(w, k, P) % P)
 
 
+@pytest.mark.parametrize("log_n,rate_bits", [(18, 3), (19, 3), (13, 0)])
+def test_big_tile_sizes_match_oracle(zctx, log_n, rate_bits):
+    """2^21 (the Ed25519 circuit's LDE) and 2^22 take the 2^13-element LDS tile (two passes instead of three), 2^13 a single pass:
+    forward / inverse / DIT transforms and the LDE against the C oracle on one polynomial, round trip on a second"""
+    rng = np.random.default_rng(500 + log_n)
+    logN = log_n + rate_bits
+    a = rand_gl(rng, (2, 1 << logN))
+    want = cport.gl_ntt(a[:1], nthreads=8)
+    f = zctx.gl_ntt(a, flags=OUT_BR)
+    br = bitrev_fast(logN)
+    assert np.array_equal(f[:1][:, br], want)
+    assert np.array_equal(zctx.gl_ntt(f, flags=INV | IN_BR), a)
+    assert np.array_equal(zctx.gl_ntt(a[:1], flags=INV), cport.gl_ntt(a[:1], inverse=True, nthreads=8))
+    if rate_bits:
+        c = rand_gl(rng, (1, 1 << log_n))
+        assert np.array_equal(zctx.gl_lde(c, rate_bits, 7), cport.gl_lde(c, rate_bits, 7, nthreads=8))
+
+
+def bitrev_fast(bits):
+    idx = np.arange(1 << bits, dtype=np.uint64)
+    out = np.zeros_like(idx)
+    for b in range(bits):
+        out |= ((idx >> np.uint64(b)) & np.uint64(1)) << np.uint64(bits - 1 - b)
+    return out.astype(np.int64)
+
+
 def test_lde_c3_shape_linearity(zctx):
     """Full C3 shape (2^17 -> 2^20) through size-independent properties: linearity and
     agreement with the oracle on one polynomial."""

@@ -30,10 +30,12 @@ P = 2**64 - 2**32 + 1
 M32 = 0xFFFFFFFF
 MDS_C = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
 
-VB, NT = 48, 60          # fixed temporary VGPRs v[48:107]
-LB = 32                  # s[32:33] table pointer, s34 round counter of the looped statement
-SB = 36                  # constants s[36:83]
-FB, NF = 84, 9           # flag pairs s[84:85] .. s[100:101]; flag index NF = vcc
+VB, NT = 48, 64          # fixed temporary VGPRs v[48:111]
+LB = 32                  # s[32:33] table pointer, s34 round counter of the looped statement, s35 = 25 * 2^10
+SB = 36                  # constants s[36:83]: two buffers of four multiply-accumulate slots (6 dwords each)
+FB, NF = 84, 7           # flag pairs s[84:85] .. s[96:97]; flag index NF = vcc
+S25K, S22, S12, S10 = "s35", "s98", "s99", "s100"      # 25 << 10, 1 << 22, 1 << 12, 1 << 10 (set by the statements that use them)
+ONE = "v%d" % (VB + NT - 1)                            # a VGPR holding 1
 
 
 def T(n):
@@ -125,62 +127,69 @@ def mds_row_stream(r, lo, hi_, out, base, rc, fl, fd):
     return ins
 
 
-def dot_streams(xs, ks, base, flags, fd, yterm=None, needconst=True):
-    """sum_j x_j k_j as four column accumulators (64 bits + a carry counter each).  xs: [(x0, x1)] registers, ks: [(k0, k1)]
-    SGPRs.  Returns the four streams; temporaries T(base .. base+11).  yterm = (y, 25, event): adds 25 y once `event` is up"""
-    C0, C1a, C1b, C2 = T(base), T(base + 2), T(base + 4), T(base + 6)
-    n0, n1a, n1b, n2 = T(base + 8), T(base + 9), T(base + 10), T(base + 11)
-    st = [[("mov", n, 0)] + ([("needconst",)] if needconst else []) for n in (n0, n1a, n1b, n2)]
-    for j, ((x0, x1), (k0, k1)) in enumerate(zip(xs, ks)):
-        for s_, (acc, cnt, xa, kb) in enumerate(((C0, n0, x0, k0), (C1a, n1a, x0, k1), (C1b, n1b, x1, k0), (C2, n2, x1, k1))):
-            st[s_].append(("mad", acc, flags[s_], xa, kb, acc if j else None))
-            st[s_].append(("addc", cnt, fd, cnt, 0, flags[s_]))
-    for s_ in range(4):
-        st[s_].append(("signal", "rd%d_%d" % (base, s_)))     # the x_j have been read: they may be overwritten from here on
-    if yterm:
-        (y0, y1), c, ev = yterm
-        st[0] += [("wait", ev), ("mad", C0, flags[0], y0, c, C0), ("addc", n0, fd, n0, 0, flags[0])]
-        st[1] += [("wait", ev), ("mad", C1a, flags[1], y1, c, C1a), ("addc", n1a, fd, n1a, 0, flags[1])]
-    return st
+def limbs22(k):
+    return [k & 0x3FFFFF, (k >> 22) & 0x3FFFFF, k >> 44]
 
 
-def fold_stream(base, out, f, fl, fd, waits):
-    """the 160-bit value of dot_streams' accumulators -> out (loose)"""
-    C0, C1a, C1b, C2 = T(base), T(base + 2), T(base + 4), T(base + 6)
-    n0, n1a, n1b, n2 = T(base + 8), T(base + 9), T(base + 10), T(base + 11)
-    ins = [("wait", w) for w in waits]
-    ins += [
-        ("add_co", C1a, fl, C1a, C1b),
-        ("addc", hi(C1a), fl, hi(C1a), hi(C1b), fl),
-        ("addc", n1a, fd, n1a, n1b, fl),               # column 1 = {n1a, C1a}
-        ("add_co", hi(C0), fl, hi(C0), C1a),           # w1
-        ("addc", C2, fl, C2, hi(C1a), fl),             # w2 = C2.lo + C1.hi + c
-        ("addc", hi(C2), fl, hi(C2), n1a, fl),         # w3 = C2.hi + n1 + c
-        ("addc", n2, fd, n2, 0, fl),                   # w4 = n2 + c
-        ("add_co", C2, fl, C2, n0),                    # w2 += n0
-        ("addc", hi(C2), fl, hi(C2), 0, fl),
-        ("addc", n2, fd, n2, 0, fl),
-    ]
-    return ins + reduce128(C0, C2, hi(C2), n2, C1a, out, f, fl, fd)
+class MacStream:
+    """A sequence of 64 x 64-bit multiply-accumulates x * k (k a constant of the table) WITHOUT carries: k and k' = 2^32 k mod p
+    are split into limbs of 22 bits (ka, kb, kc), so that  x k = x0 k + x1 k'  (mod p)  is six v_mad_u64_u32 into three 64-bit
+    column accumulators of weights 1, 2^22, 2^44 -- every product is below 2^54 and a column takes hundreds of them before it
+    could overflow.  The constants travel through two SGPR buffers of four slots (6 dwords each): a buffer is fetched while the
+    other one is used (`s_waitcnt` + the next `s_load` at the head of every group of four slots).  The table is built here in
+    the order the stream consumes it."""
+
+    def __init__(self, fd):
+        self.ins, self.table, self.n, self.fd = [], [], 0, fd
+
+    def _slot(self, dwords):
+        if self.n % 4 == 0:
+            g = self.n // 4
+            nb = 24 * ((g + 1) % 2)
+            self.ins += [("waitcnt",), ("sload", K(nb), 16, 96 * (g + 1)), ("sload", K(nb + 16), 8, 96 * (g + 1) + 64)]
+        base = 24 * ((self.n // 4) % 2) + 6 * (self.n % 4)
+        self.table += dwords
+        self.n += 1
+        return base
+
+    def const(self, acc, k):
+        """acc = k (initialises the three columns)"""
+        b = self._slot(limbs22(k % P) + [0, 0, 0])
+        self.ins += [("mad", acc[c], self.fd, ONE, K(b + c), None) for c in range(3)]
+
+    def mac(self, acc, x, k):
+        k %= P
+        b = self._slot(limbs22(k) + limbs22((k << 32) % P))
+        self.ins += [("mad", acc[c], self.fd, x[h], K(b + 3 * h + c), acc[c]) for h in range(2) for c in range(3)]
+
+    def raw(self, *ins):
+        self.ins += list(ins)
+
+    def finish(self, even_groups=True):
+        """pads the table to whole groups (an even number of them for a looped body: the fetch at the head of the last group
+        then brings the NEXT block's first group into buffer 0) plus the one group the last fetch reads"""
+        while self.n % 4 or (even_groups and (self.n // 4) % 2):
+            self.table += [0] * 6
+            self.n += 1
+        return self.n // 4
 
 
-def update_stream(y, v, s, sc, f, fl, fd, evs):
-    """s <- s + y * v (loose); v = (v0, v1) SGPRs"""
-    P0, S, P3 = sc
-    return [("wait", e) for e in evs] + [
-        ("mad", P0, fd, y[0], v[0], None),
-        ("mad", S, fd, y[0], v[1], None),
-        ("mad", S, fl, y[1], v[0], S),
-        ("mad", P3, fd, y[1], v[1], None),
-        ("addc", hi(P3), fd, hi(P3), 0, fl),
-        ("add_co", hi(P0), fl, hi(P0), S),
-        ("addc", P3, fl, P3, hi(S), fl),
-        ("addc", hi(P3), fd, hi(P3), 0, fl),
-        ("add_co", P0, fl, P0, s[0]),                  # + s (the sum stays below 2^128)
-        ("addc", hi(P0), fl, hi(P0), s[1], fl),
-        ("addc", P3, fl, P3, 0, fl),
-        ("addc", hi(P3), fd, hi(P3), 0, fl),
-    ] + reduce128(P0, P3, hi(P3), None, S, s, f, fl, fd)
+def prefetch0(off=0):
+    return [("sload", K(0), 16, off), ("sload", K(16), 8, off + 64)]
+
+
+def fold3(acc, TP, f, out, fl, fd):
+    """the value C0 + C1 2^22 + C2 2^44 of three column accumulators (each < 2^60) -> out (loose 64 bits).  Scratch: TP (pair), f"""
+    C0, C1, C2 = acc
+    return [
+        ("mad", C0, fd, C1, S22, C0),                  # A = C0 + C1.lo 2^22                      (< 2^61)
+        ("mad", TP, fd, hi(C1), S22, None),            # B = C1.hi 2^22            weight 2^32   (< 2^51)
+        ("mad", TP, fd, C2, S12, TP),                  # B += C2.lo 2^12
+        ("mad", C1, fd, hi(C2), S12, None),            # D = C2.hi 2^12            weight 2^64   (< 2^41)
+        ("add_co", hi(C0), fl, hi(C0), TP),            # w1
+        ("addc", C1, fl, C1, hi(TP), fl),              # w2
+        ("addc", hi(C1), fd, hi(C1), 0, fl),           # w3
+    ] + reduce128(C0, C1, hi(C1), None, TP, out, f, fl, fd)
 
 
 # ------------------------------------------------------------------------------------------------------- scheduler
@@ -197,8 +206,9 @@ def flag_written(ins):
     return ins[2] if ins[0] in ("mad", "add_co", "addc", "sub_co", "subb") else None
 
 
-def schedule(streams, prologue=()):
-    """greedy round-robin merge; a flag reader is placed >= 3 slots after the flag's writer"""
+def schedule(streams, prologue=(), priority=False):
+    """greedy merge (round-robin, or always the first stream that can issue when priority=True: later streams are filler);
+    a flag reader is placed >= 3 slots after the flag's writer"""
     out = list(prologue)
     pos = len(out)
     lastw, events = {}, set()
@@ -210,6 +220,8 @@ def schedule(streams, prologue=()):
         progressed = False
         for k in range(len(streams)):
             i = (rr + k) % len(streams)
+            if priority:
+                i = k
             while heads[i] < len(streams[i]) and streams[i][heads[i]][0] in ("needconst", "wait", "signal"):
                 m = streams[i][heads[i]]
                 if m[0] == "needconst":
@@ -246,7 +258,7 @@ def schedule(streams, prologue=()):
             lastw[w] = pos
         heads[chosen] += 1
         pos += 1
-        rr = (chosen + 1) % len(streams)
+        rr = 0 if priority else (chosen + 1) % len(streams)
     return out, nops
 
 
@@ -255,7 +267,7 @@ def check_hazards(prog):
     for pos, ins in enumerate(prog):
         for f in flags_read(ins):
             assert pos - lastw.get(f, -9) >= 3, ("flag hazard", pos, ins)
-        w = flag_written(ins) if ins[0] not in ("nop", "waitcnt", "sload") else None
+        w = flag_written(ins) if ins[0] not in ("nop", "waitcnt", "sload", "smov") else None
         if w is not None:
             lastw[w] = pos
 
@@ -294,7 +306,7 @@ def simulate(prog, regs, consts=None):
         elif op == "add64":
             v = (val64(ins[2]) + val64(ins[3])) & (2**64 - 1)
             R[ins[1]], R[hi(ins[1])] = v & M32, v >> 32
-        elif op == "mov":
+        elif op in ("mov", "smov"):
             R[ins[1]] = val(ins[2])
         elif op == "sload":
             _, base, n, off = ins
@@ -340,6 +352,8 @@ def emit(ins, ptr_operand):
         return "v_lshl_add_u64 %s, %s, 0, %s" % (fmt_pair(ins[1]), fmt_pair(ins[2]), fmt_pair(ins[3]))
     if op == "mov":
         return "v_mov_b32_e32 %s, %s" % (ins[1], fmt_src(ins[2]))
+    if op == "smov":
+        return "s_mov_b32 %s, 0x%x" % (ins[1], ins[2])
     if op == "sload":
         _, base, n, off = ins
         b = int(base[1:])
@@ -354,7 +368,7 @@ def emit(ins, ptr_operand):
 def check_constant_bus(prog):
     """a gfx9 VOP3 instruction may read ONE SGPR (pair) through the constant bus; a carry-in counts"""
     for ins in prog:
-        if ins[0] in ("nop", "waitcnt", "sload"):
+        if ins[0] in ("nop", "waitcnt", "sload", "smov"):
             continue
         srcs = [x for x in ins[3:] if isinstance(x, str)] if ins[0] != "cnd" else [x for x in ins[2:] if isinstance(x, str)]
         if ins[0] == "add64":
@@ -365,7 +379,7 @@ def check_constant_bus(prog):
         assert len(sg) <= 1, ("constant bus", ins)
 
 
-CLOBBERS = ["v%d" % (VB + i) for i in range(NT)] + ["s%d" % i for i in range(LB, FB + 2 * NF)] + ["vcc", "scc"]
+CLOBBERS = ["v%d" % (VB + i) for i in range(NT)] + ["s%d" % i for i in range(LB, FB + 2 * NF)] + ["s98", "s99", "s100", "vcc", "scc"]
 
 
 def statement(name, prog, inouts, ins_ops, outs=(), ptr=False, comment="", loop=None, pre=()):
@@ -389,6 +403,8 @@ def statement(name, prog, inouts, ins_ops, outs=(), ptr=False, comment="", loop=
                   "s_sub_u32 s%d, s%d, 1" % (LB + 2, LB + 2), "s_cmp_lg_u32 s%d, 0" % (LB + 2), "s_cbranch_scc1 pgl_loop_%="]
     else:
         lines = [emit(tr(i), ptr_op) for i in prog]
+    if any(i[0] == "sload" for i in list(prog) + list(pre)):
+        lines.append("s_waitcnt lgkmcnt(0)")       # a prefetch may still be in flight: its SGPRs are ours until it lands
     params = ["u32 &%s" % n for n in list(outs) + list(inouts)] + ["u32 %s" % n for n in ins_ops] + (["const u32 *tab"] if ptr else [])
     c = ["// %s" % comment if comment else "", "ZKLC_D void %s(%s) {" % (name, ", ".join(params)), "    asm volatile("]
     for ln in lines:
@@ -401,58 +417,6 @@ def statement(name, prog, inouts, ins_ops, outs=(), ptr=False, comment="", loop=
 
 
 # ---------------------------------------------------------------------------------------------- statement builders
-def build_sbox3():
-    fd = F(0)
-    xs = [("x%dl" % i, "x%dh" % i) for i in range(3)]
-    streams = [sbox_stream(xs[i], 12 * i, F(1 + i), fd) for i in range(3)]
-    prog, nops = schedule(streams)
-    return prog, [r for x in xs for r in x], nops
-
-
-def build_mds2(rows):
-    fd = F(0)
-    lo = ["l%d" % i for i in range(12)]
-    hi_ = ["h%d" % i for i in range(12)]
-    outs = []
-    streams = []
-    for k, r in enumerate(rows):
-        o = ("o%dl" % k, "o%dh" % k)
-        outs += list(o)
-        streams.append(mds_row_stream(r, lo, hi_, o, 10 * k, (K(4 * k), K(4 * k + 2)), F(1 + k), fd))
-    prologue = [("sload", K(0), 8, 32 * (rows[0] // 2))]
-    prog, nops = schedule(streams, prologue)
-    return prog, outs, lo + hi_, nops
-
-
-def build_partial():
-    """one fast partial round: y = s0^7 + rc; s0' = 25 y + sum_j w_j s_j; s_j += y v_j.  Table row (48 dwords):
-    w (k0, k1) x 11 | rc lo, hi | v (v0, v1) x 11 | 2 pad"""
-    fd = F(0)
-    s0 = ("q0l", "q0h")
-    sj = [("q%dl" % j, "q%dh" % j) for j in range(1, 12)]
-    Y = (T(12), T(13))
-    DB = 14                       # dot accumulators T(14..25), fold scratch f = T(26)
-    sbox = sbox_stream(s0, 0, F(1), fd, out=Y)
-    f = T(10)
-    sbox += [("needconst",), ("mov", f, K(23)), ("add_co", Y[0], F(1), Y[0], K(22)), ("addc", Y[1], F(1), Y[1], f, F(1)),
-             ("cnd", f, 0, -1, F(1)), ("add_co", Y[0], F(1), Y[0], f), ("addc", Y[1], fd, Y[1], 0, F(1)), ("signal", "y")]
-    ks = [(K(2 * j), K(2 * j + 1)) for j in range(11)]
-    dots = dot_streams(sj, ks, DB, [F(2), F(3), F(4), F(5)], fd, yterm=(Y, 25, "y"))
-    for k, d in enumerate(dots):
-        d.append(("signal", "dot%d" % k))
-    fold = fold_stream(DB, s0, T(26), F(2), fd, ["dot0", "dot1", "dot2", "dot3"])
-    # state updates: three streams; the first reuses the S-box scratch (free once y exists)
-    usc = [((T(4), T(6), T(8)), T(10), F(1)), ((T(28), T(30), T(32)), T(34), F(6)), ((T(36), T(38), T(40)), T(42), F(7))]
-    ups = [[], [], []]
-    for j in range(11):
-        sc, fj, fl = usc[j % 3]
-        ups[j % 3] += update_stream(Y, (K(24 + 2 * j), K(25 + 2 * j)), sj[j], sc, fj, fl, fd, ["y"] + ["rd%d_%d" % (DB, q) for q in range(4)])
-    # the fold rewrites s0 (an S-box input) only after the S-box finished: it waits for the dot products, which wait for y
-    prologue = [("sload", K(0), 16, 0), ("sload", K(16), 16, 64), ("sload", K(32), 16, 128)]
-    prog, nops = schedule([sbox] + dots + [fold] + ups, prologue)
-    return prog, list(s0) + [r for x in sj for r in x], nops
-
-
 def build_fullround():
     """one full round in place: twelve S-boxes (three streams of four; results in temporaries), then the MDS layer + the next
     constant layer written back to the state operands (three streams of four rows).  The 48 dwords of constants are fetched
@@ -478,55 +442,90 @@ def build_fullround():
     return prog, [r for x in xs for r in x], nops
 
 
-def build_partial_loop():
-    """the body of the loop over the 22 fast partial rounds (one asm statement, pointer and counter in SGPRs):
-    y = s0^7 + rc; s0' = 25 y + sum_j w_j s_j; s_j += y v_j.  Table row (48 dwords): w (k0, k1) x 11 | 2 pad | v (v0, v1) x 11 |
-    rc lo, hi.  The w block of the NEXT row is fetched as soon as the dot products have read this row's, the v block at the
-    top of the body (first used ~200 slots later), so no load latency is exposed."""
+STMT_PRE = [("smov", S25K, 25 << 10), ("smov", S22, 1 << 22), ("smov", S12, 1 << 12), ("smov", S10, 1 << 10), ("mov", ONE, 1)]
+
+
+def build_fullround_init(cs):
+    """the LAST full round of the first half merged with the dense 11 x 11 initial matrix of the fast partial rounds: twelve
+    S-boxes, then out = G y + g with G = diag(1, Init^T) MDS (64-bit constants, carry-free multiply-accumulates in groups of
+    four outputs) and g = diag(1, Init^T) first_round_constants.  Returns (program, operands, nops, table)."""
+    fd = F(0)
+    xs = [("x%dl" % i, "x%dh" % i) for i in range(12)]
+    Y = [(T(2 * i), T(2 * i + 1)) for i in range(12)]
+    streams = []
+    for k in range(3):
+        st = []
+        for i in range(k, 12, 3):
+            st += sbox_stream(xs[i], 24 + 12 * k, F(1 + k), fd, out=Y[i])
+            st.append(("signal", "sb%d" % i))
+        streams.append(st)
+    D = MacStream(fd)
+    D.raw(*[("wait", "sb%d" % i) for i in range(12)])
+    accs = [(T(24 + 6 * t), T(26 + 6 * t), T(28 + 6 * t)) for t in range(4)]
+    folds = [[] for _ in range(4)]
+    for g in range(3):
+        rows = list(range(4 * g, 4 * g + 4))
+        if g:
+            D.raw(*[("wait", "f%d_%d" % (g - 1, t)) for t in range(4)])
+        for t, r in enumerate(rows):
+            D.const(accs[t], cs["g"][r])
+        for i in range(12):
+            for t, r in enumerate(rows):
+                D.mac(accs[t], Y[i], cs["G"][r][i])
+        D.raw(("signal", "m%d" % g))
+        for t, r in enumerate(rows):
+            folds[t] += [("wait", "m%d" % g)] + fold3(accs[t], T(48 + 4 * t), T(50 + 4 * t), xs[r], F(1 + t), fd) + [("signal", "f%d_%d" % (g, t))]
+    D.finish(even_groups=False)
+    prog, nops = schedule(streams + [D.ins] + folds, STMT_PRE + prefetch0())
+    return prog, [r for x in xs for r in x], nops, D.table + [0] * 24
+
+
+def build_partial_block(cs, b):
+    """eleven fast partial rounds (block b = 0, 1) in the LAZY form: with u = the state words 1..11 at the start of the block and
+    z_k = s0^7 of round k,   s0 <- 25 z_q + K_q + sum_i u_i w_q[i] + sum_{k<q} z_k c_q[k]   (c_q[k] = <v_k, w_q>, K_q collects
+    the round constants), and the words 1..11 are only materialised at the end of the block: u_j += Kv_j + sum_k z_k v_k[j].
+    Every product is a carry-free multiply-accumulate (MacStream): the S-box -> fold chain of a round has priority and the
+    dot products of the NEXT round (double-buffered accumulators) fill its hazard slots.  Returns (body, operands, nops, table)."""
     fd = F(0)
     s0 = ("q0l", "q0h")
-    sj = [("q%dl" % j, "q%dh" % j) for j in range(1, 12)]
-    Y = (T(12), T(13))
-    DB = 14
-    sbox = sbox_stream(s0, 0, F(1), fd, out=Y)
-    f = T(10)
-    sbox += [("needconst",), ("mov", f, K(47)), ("add_co", Y[0], F(1), Y[0], K(46)), ("addc", Y[1], F(1), Y[1], f, F(1)),
-             ("cnd", f, 0, -1, F(1)), ("add_co", Y[0], F(1), Y[0], f), ("addc", Y[1], fd, Y[1], 0, F(1)), ("signal", "y")]
-    ks = [(K(2 * j), K(2 * j + 1)) for j in range(11)]
-    dots = dot_streams(sj, ks, DB, [F(2), F(3), F(4), F(5)], fd, yterm=(Y, 25, "y"), needconst=False)
-    for k, d in enumerate(dots):
-        d.append(("signal", "dot%d" % k))
-    rds = ["rd%d_%d" % (DB, q) for q in range(4)]
-    prefetch = [("wait", e) for e in rds] + [("sload", K(0), 8, 192), ("sload", K(8), 16, 192 + 32)]
-    fold = fold_stream(DB, s0, T(26), F(2), fd, ["dot0", "dot1", "dot2", "dot3"])
-    usc = [((T(4), T(6), T(8)), T(10), F(1)), ((T(28), T(30), T(32)), T(34), F(6)), ((T(36), T(38), T(40)), T(42), F(7))]
-    ups = [[], [], []]
-    for j in range(11):
-        sc, fj, fl = usc[j % 3]
-        ups[j % 3] += update_stream(Y, (K(24 + 2 * j), K(25 + 2 * j)), sj[j], sc, fj, fl, fd, ["y"] + rds)
-    pre = [("sload", K(0), 8, 0), ("sload", K(8), 16, 32)]
-    top = [("waitcnt",), ("sload", K(24), 8, 96), ("sload", K(32), 16, 128)]
-    prog, nops = schedule([sbox] + dots + [prefetch, fold] + ups, top)
-    return pre, prog, list(s0) + [r for x in sj for r in x], nops
-
-
-def build_init2(n_out):
-    """n_out (1 or 2) outputs of the 11 x 11 initial matrix of the fast partial rounds: t_d = sum_{r=1..11} s_r init[r-1][d-1].
-    Table row per output (24 dwords): (k0, k1) x 11 | 2 pad"""
-    fd = F(0)
-    sj = [("q%dl" % j, "q%dh" % j) for j in range(1, 12)]
-    streams, outs = [], []
-    for k in range(n_out):
-        ks = [(K(24 * k + 2 * j), K(24 * k + 2 * j + 1)) for j in range(11)]
-        dots = dot_streams(sj, ks, 14 * k, [F(1 + 4 * k + q) for q in range(4)], fd)
-        for q, d in enumerate(dots):
-            d.append(("signal", "d%d_%d" % (k, q)))
-        o = ("t%dl" % k, "t%dh" % k)
-        outs += list(o)
-        streams += dots + [fold_stream(14 * k, o, T(14 * k + 12), F(1 + 4 * k), fd, ["d%d_%d" % (k, q) for q in range(4)])]
-    prologue = [("sload", K(0), 8, 0), ("sload", K(8), 16, 32)] + ([("sload", K(24), 8, 96), ("sload", K(32), 16, 128)] if n_out == 2 else [])
-    prog, nops = schedule(streams, prologue)
-    return prog, outs, [r for x in sj for r in x], nops
+    u = [("q%dl" % j, "q%dh" % j) for j in range(1, 12)]
+    Z = [(T(2 * k), T(2 * k + 1)) for k in range(11)]
+    ACC = [(T(34), T(36), T(38)), (T(40), T(42), T(44))]
+    B = cs["blocks"][b]
+    chain = []
+    D = MacStream(fd)
+    for q in range(11):
+        acc = ACC[q % 2]
+        chain += sbox_stream(s0, 22, F(1), fd, out=Z[q]) + [("signal", "z%d" % q), ("wait", "dot%d" % q),
+                                                            ("mad", acc[0], fd, Z[q][0], 25, acc[0]),
+                                                            ("mad", acc[1], fd, Z[q][1], S25K, acc[1])]
+        chain += fold3(acc, T(46), T(32), s0, F(1), fd) + [("signal", "fold%d" % q)]
+        if q >= 2:
+            D.raw(("wait", "fold%d" % (q - 2)))
+        D.const(acc, B["K"][q])
+        for i in range(11):
+            D.mac(acc, u[i], B["w"][q][i])
+        for k in range(q):
+            D.raw(("wait", "z%d" % k))
+            D.mac(acc, Z[k], B["c"][q][k])
+        D.raw(("signal", "dot%d" % q))
+    accs = [(T(22 + 6 * t), T(24 + 6 * t), T(26 + 6 * t)) for t in range(4)]
+    folds = [[] for _ in range(4)]
+    groups = [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10]]
+    for g, js in enumerate(groups):
+        D.raw(("wait", "fold10"), *[("wait", "mf%d_%d" % (g - 1, t)) for t in range(len(groups[g - 1]) if g else 0)])
+        for t, j in enumerate(js):
+            D.const(accs[t], B["Kv"][j])
+            D.raw(("mad", accs[t][0], fd, u[j][0], 1, accs[t][0]), ("mad", accs[t][1], fd, u[j][1], S10, accs[t][1]))
+        for k in range(11):
+            for t, j in enumerate(js):
+                D.mac(accs[t], Z[k], B["v"][k][j])
+        D.raw(("signal", "mat%d" % g))
+        for t, j in enumerate(js):
+            folds[t] += [("wait", "mat%d" % g)] + fold3(accs[t], T(46 + 4 * t), T(48 + 4 * t), u[j], F(2 + t), fd) + [("signal", "mf%d_%d" % (g, t))]
+    n_groups = D.finish(even_groups=True)
+    prog, nops = schedule([chain, D.ins] + folds, priority=True)
+    return prog, list(s0) + [r for x in u for r in x], nops, D.table, n_groups
 
 
 # ------------------------------------------------------------------------------------------------------ self-test
@@ -555,39 +554,47 @@ def selftest(consts, tables):
             for r in range(12):
                 want = sum(MDS_C[i] * y[(i + r) % 12] for i in range(12)) + (8 * y[0] if r == 0 else 0) + consts["next"][layer][r]
                 assert get64(R, ("x%dl" % r, "x%dh" % r)) % P == want % P, "full round"
-    # the 22 partial rounds as the loop runs them (the w block of row i + 1 is fetched inside iteration i)
-    pre, body, ops, _ = build_partial_loop()
+    # the fourth full round merged with the initial matrix of the partial rounds, against the two separate layers
+    prog, ops, _, tab = build_fullround_init(consts)
+    assert tab == tables["finit"]
+    check_hazards(prog)
+    check_constant_bus(prog)
+    for _ in range(40):
+        st = [rnd64(rng) for _ in range(12)]
+        regs = {}
+        for i, x in enumerate(st):
+            regs["x%dl" % i], regs["x%dh" % i] = x & M32, x >> 32
+        R = simulate(prog, regs, tab)
+        y = [pow(x, 7, P) for x in st]
+        t = [(sum(MDS_C[i] * y[(i + r) % 12] for i in range(12)) + (8 * y[0] if r == 0 else 0) + consts["next"][3][r]) % P for r in range(12)]
+        want = [t[0]] + [sum(t[r] * consts["init"][r - 1][d - 1] for r in range(1, 12)) % P for d in range(1, 12)]
+        for r in range(12):
+            assert get64(R, ("x%dl" % r, "x%dh" % r)) % P == want[r], "full round + initial matrix, word %d" % r
+    # the 22 partial rounds as the loop runs them (two blocks of eleven; the constant layer that follows is folded in)
+    bodies = [build_partial_block(consts, b) for b in range(2)]
+    strip = lambda prog: [tuple(x for x in ins) for ins in prog]
+    assert strip(bodies[0][0]) == strip(bodies[1][0]), "the two blocks must share one loop body"
+    body, n_groups = bodies[0][0], bodies[0][4]
+    assert bodies[0][3] + bodies[1][3] + [0] * 24 == tables["pblocks"] and len(bodies[0][3]) == 24 * n_groups
     check_hazards(body + body)
     check_constant_bus(body)
+    pre = STMT_PRE + prefetch0()
     for _ in range(12):
         st = [rnd64(rng) for _ in range(12)]
         regs = {}
         for i, x in enumerate(st):
             regs["q%dl" % i], regs["q%dh" % i] = x & M32, x >> 32
-        R = simulate(pre, regs, tables["partial"])
+        R = simulate(pre, regs, tables["pblocks"])
         cur = list(st)
-        for rnd in range(22):
-            R = simulate(body, R, tables["partial"][48 * rnd:])
-            y = (pow(cur[0], 7, P) + consts["fp_rc"][rnd]) % P
-            d = (25 * y + sum(consts["w"][rnd][j - 1] * cur[j] for j in range(1, 12))) % P
-            cur = [d] + [(cur[j] + y * consts["v"][rnd][j - 1]) % P for j in range(1, 12)]
+        for b in range(2):
+            R = simulate(body, R, tables["pblocks"][24 * n_groups * b:])
+            for rnd in range(11 * b, 11 * b + 11):
+                y = (pow(cur[0], 7, P) + consts["fp_rc"][rnd]) % P
+                d = (25 * y + sum(consts["w"][rnd][j - 1] * cur[j] for j in range(1, 12))) % P
+                cur = [d] + [(cur[j] + y * consts["v"][rnd][j - 1]) % P for j in range(1, 12)]
+            want = cur if b == 0 else [(x + c) % P for x, c in zip(cur, consts["rc26"])]
             for j in range(12):
-                assert get64(R, ("q%dl" % j, "q%dh" % j)) % P == cur[j], "partial round %d word %d" % (rnd, j)
-    # initial matrix
-    for d0 in range(0, 11, 2):
-        n_out = min(2, 11 - d0)
-        prog, outs, ins, _ = build_init2(n_out)
-        check_hazards(prog)
-        check_constant_bus(prog)
-        for _ in range(20):
-            s = [rnd64(rng) for _ in range(12)]
-            regs = {}
-            for i in range(1, 12):
-                regs["q%dl" % i], regs["q%dh" % i] = s[i] & M32, s[i] >> 32
-            R = simulate(prog, regs, tables["init"][24 * d0:24 * d0 + 24 * n_out])
-            for k in range(n_out):
-                want = sum(s[r] * consts["init"][r - 1][d0 + k] for r in range(1, 12)) % P
-                assert get64(R, ("t%dl" % k, "t%dh" % k)) % P == want, "init"
+                assert get64(R, ("q%dl" % j, "q%dh" % j)) % P == want[j], "partial block %d word %d" % (b, j)
     return True
 
 
@@ -599,31 +606,39 @@ def load_constants():
     nxt = [rc[12:24], rc[24:36], rc[36:48], first, rc[12 * 27:12 * 28], rc[12 * 28:12 * 29], rc[12 * 29:12 * 30], [0] * 12]
     consts = {"next": nxt, "fp_rc": j["fast_partial_round_constants"], "w": j["fast_partial_round_w_hats"],
               "v": j["fast_partial_round_vs"], "init": j["fast_partial_round_initial_matrix"], "rc0": rc[0:12], "rc26": rc[12 * 26:12 * 27]}
+    # full round 3 + initial matrix: out = E (MDS y + first), E = diag(1, Init^T)
+    mds = [[0] * 12 for _ in range(12)]
+    for r in range(12):
+        for i in range(12):
+            mds[r][(i + r) % 12] += MDS_C[i]
+    mds[0][0] += 8
+    E = [[0] * 12 for _ in range(12)]
+    E[0][0] = 1
+    for d in range(1, 12):
+        for r in range(1, 12):
+            E[d][r] = consts["init"][r - 1][d - 1]
+    consts["G"] = [[sum(E[d][r] * mds[r][i] for r in range(12)) % P for i in range(12)] for d in range(12)]
+    consts["g"] = [sum(E[d][r] * first[r] for r in range(12)) % P for d in range(12)]
+    # the lazy blocks of eleven partial rounds
+    consts["blocks"] = []
+    for b in range(2):
+        w = [consts["w"][11 * b + q] for q in range(11)]
+        v = [consts["v"][11 * b + k] for k in range(11)]
+        rcs = [consts["fp_rc"][11 * b + k] for k in range(11)]
+        c = [[sum(v[k][j] * w[q][j] for j in range(11)) % P for k in range(q)] for q in range(11)]
+        Kq = [(25 * rcs[q] + sum(rcs[k] * c[q][k] for k in range(q))) % P for q in range(11)]
+        Kv = [sum(rcs[k] * v[k][j] for k in range(11)) % P for j in range(11)]
+        if b == 1:                 # the constant layer in front of the second half of the full rounds
+            Kq[10] = (Kq[10] + consts["rc26"][0]) % P
+            Kv = [(x + consts["rc26"][j + 1]) % P for j, x in enumerate(Kv)]
+        consts["blocks"].append({"w": w, "v": v, "c": c, "K": Kq, "Kv": Kv})
     t_rc = []
     for layer in nxt:
         for c in layer:
             t_rc += [c & M32, 0, c >> 32, 0]
-    t_part = []
-    for r in range(22):
-        row = []
-        for x in consts["w"][r]:
-            row += [x & M32, x >> 32]
-        row += [0, 0]
-        for x in consts["v"][r]:
-            row += [x & M32, x >> 32]
-        row += [consts["fp_rc"][r] & M32, consts["fp_rc"][r] >> 32]
-        assert len(row) == 48
-        t_part += row
-    t_part += [0] * 48            # the loop's last iteration prefetches one row past the end
-    t_init = []
-    for d in range(11):
-        row = []
-        for r in range(1, 12):
-            x = consts["init"][r - 1][d]
-            row += [x & M32, x >> 32]
-        row += [0, 0]
-        t_init += row
-    return consts, {"rc": t_rc, "partial": t_part, "init": t_init}
+    t_finit = build_fullround_init(consts)[3]
+    t_blocks = build_partial_block(consts, 0)[3] + build_partial_block(consts, 1)[3] + [0] * 24
+    return consts, {"rc": t_rc, "finit": t_finit, "pblocks": t_blocks}
 
 
 def c_table(name, vals):
@@ -643,28 +658,27 @@ def main():
     parts = ["// GENERATED by tools/gen_poseidon_asm.py -- do not edit.  Hand-scheduled gfx950 statements of the Poseidon-Goldilocks",
              "// permutation (see the generator for the derivation, the hazard rule and the simulator that checks every list).",
              "// Tables: PGL_ASM_RC[layer][row] = {lo, 0, hi, 0} of the constant added after the MDS of full round `layer`;",
-             "// PGL_ASM_PARTIAL[round] = w_hat pairs | pad | v pairs | rc (48 dwords, + one padding row); PGL_ASM_INIT[d] = column d of the initial",
-             "// matrix as (lo, hi) pairs | pad (24 dwords).",
-             c_table("PGL_ASM_RC", tables["rc"]), c_table("PGL_ASM_PARTIAL", tables["partial"]), c_table("PGL_ASM_INIT", tables["init"]),
+             "// PGL_ASM_FINIT / PGL_ASM_PBLOCKS: multiply-accumulate slots {ka, kb, kc, k'a, k'b, k'c} (22-bit limbs of k and of 2^32 k mod p)",
+             "// in the order the statements consume them, four slots per fetch (generator: MacStream).",
+             c_table("PGL_ASM_RC", tables["rc"]), c_table("PGL_ASM_FINIT", tables["finit"]), c_table("PGL_ASM_PBLOCKS", tables["pblocks"]),
              "#if defined(__HIP_DEVICE_COMPILE__)"]
     stats = []
     prog, ops, nops = build_fullround()
     stats.append(("full round", len(prog), nops))
     parts.append(statement("pgl_asm_full_round", prog, ops, [], ptr=True,
                            comment="one full round in place: x^7 on the twelve words, MDS, next constant layer (tab: 48 dwords of PGL_ASM_RC)"))
-    pre, prog, ops, nops = build_partial_loop()
-    stats.append(("partial round", len(prog), nops))
-    parts.append(statement("pgl_asm_partial_rounds", prog, ops, [], ptr=True, loop=(22, 192), pre=pre,
-                           comment="the 22 fast partial rounds (tab: PGL_ASM_PARTIAL)"))
-    for n_out in (2, 1):
-        prog, outs, ins, nops = build_init2(n_out)
-        stats.append(("init x%d" % n_out, len(prog), nops))
-        parts.append(statement("pgl_asm_init%d" % n_out, prog, [], ins, outs=outs, ptr=True,
-                               comment="%d output(s) of the initial matrix of the fast partial rounds (tab: %d dwords of PGL_ASM_INIT)" % (n_out, 24 * n_out)))
+    prog, ops, nops, _ = build_fullround_init(consts)
+    stats.append(("full round + initial matrix", len(prog), nops))
+    parts.append(statement("pgl_asm_full_round_init", prog, ops, [], ptr=True,
+                           comment="the fourth full round merged with the initial matrix of the fast partial rounds (tab: PGL_ASM_FINIT)"))
+    prog, ops, nops, tab, n_groups = build_partial_block(consts, 0)
+    stats.append(("block of 11 partial rounds", len(prog), nops))
+    parts.append(statement("pgl_asm_partial_rounds", prog, ops, [], ptr=True, loop=(2, 96 * n_groups), pre=STMT_PRE + prefetch0(),
+                           comment="the 22 fast partial rounds as two lazy blocks + the constant layer that follows (tab: PGL_ASM_PBLOCKS)"))
     parts.append("#endif")
-    total = 8 * stats[0][1] + 22 * stats[1][1] + 5 * stats[2][1] + stats[3][1]
+    total = 7 * stats[0][1] + stats[1][1] + 2 * stats[2][1]
     parts.insert(5, "// instructions per statement (of which s_nop): " + "; ".join("%s %d (%d)" % s for s in stats)
-                 + "; permutation ~%d + constant layers / canonicalisation" % total)
+                 + "; permutation ~%d + first constant layer / canonicalisation" % total)
     open(os.path.join(ROOT, "zk-light-client-implementation_amd", "csrc", "poseidon_gl_asm.inc"), "w").write("\n".join(parts) + "\n")
     print("generated poseidon_gl_asm.inc:", stats, "total ~", total)
 

@@ -32,7 +32,7 @@ def timeit(fn, st, iters=5):
 
 with zklc_amd.Context(0) as c:
     st = torch.cuda.Stream()
-    for log_n, rate, batch in [(17, 3, 234), (17, 3, 20), (17, 3, 16), (12, 3, 135)]:
+    for log_n, rate, batch in [(18, 3, 234), (17, 3, 234), (17, 3, 20), (12, 3, 135)]:
         n, N = 1 << log_n, 1 << (log_n + rate)
         coeffs = rand_gl((batch, n), 1)
         out = torch.empty((batch, N), dtype=torch.int64, device="cuda")

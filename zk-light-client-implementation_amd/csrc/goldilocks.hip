@@ -16,6 +16,9 @@
 #define NTT_THREADS 256
 #define NTT_TILE_LOG_MAX 12
 #define NTT_TILE_MAX (1 << NTT_TILE_LOG_MAX)
+// the radix-8 pass kernel takes its tile as dynamic LDS: 2^12 elements (36 KB with padding, 256 threads) or 2^13 (72 KB, 512 threads)
+#define NTT_TILE_LOG_BIG 13
+#define NTT_THREADS_MAX 512
 
 // ---------------------------------------------------------------- tables
 __global__ void gl_pow_table_kernel(u64 *out, u64 base, u64 n, u64 exp_stride) {
@@ -162,10 +165,11 @@ ZKLC_D void gl_ntt_group(u64 *tile, const u64 *__restrict__ tws, u64 n_full, u32
 }
 
 template <bool DIT>
-__global__ void __launch_bounds__(NTT_THREADS)
+__global__ void __launch_bounds__(NTT_THREADS_MAX)
 gl_ntt_pass_r8_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t in_stride, size_t out_stride, ntt_pass p,
                       const u64 *__restrict__ tw, const u64 *__restrict__ scale_hi, const u64 *__restrict__ scale_lo) {
-    __shared__ u64 tile[NTT_TILE_MAX + NTT_TILE_MAX / 8];
+    extern __shared__ u64 tile[];      // 2^(k+c+d) elements + one pad per 8 (NTT_TI)
+    const u32 n_threads = blockDim.x;
     const int tile_log = p.k + p.c + p.d;
     const int tile_n = 1 << tile_log;
     const int lowbits = p.logn - p.s0 - p.k;
@@ -185,7 +189,7 @@ gl_ntt_pass_r8_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t 
         return (H << (lowbits + p.k)) | (mid << lowbits) | L;
     };
 
-    for (u32 e = tid; e < (u32)tile_n; e += NTT_THREADS) {
+    for (u32 e = tid; e < (u32)tile_n; e += n_threads) {
         u64 g = global_index(e);
         u64 v = 0;
         if (g < (1ULL << p.log_in)) {
@@ -205,7 +209,7 @@ gl_ntt_pass_r8_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t 
         const int sh = p.s0 + t0;
         const int hi_shift = mg + lowbits;
         const u32 n_groups = (u32)tile_n >> g;
-        for (u32 gi = tid; gi < n_groups; gi += NTT_THREADS) {
+        for (u32 gi = tid; gi < n_groups; gi += n_threads) {
             u32 base = ((gi >> pb_low) << (pb_low + g)) | (gi & ((1u << pb_low) - 1));
             u64 lowc = base & ((1u << p.c) - 1);
             u64 mid_low = (base >> p.c) & ((1u << mg) - 1);
@@ -221,7 +225,7 @@ gl_ntt_pass_r8_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t 
         done += g;
     }
 
-    for (u32 e = tid; e < (u32)tile_n; e += NTT_THREADS) {
+    for (u32 e = tid; e < (u32)tile_n; e += n_threads) {
         u64 v = tile[NTT_TI(e)];
         if (p.out_scale != 1) v = gl_mul(v, p.out_scale);
         dst[global_index(e)] = v;
@@ -446,18 +450,31 @@ static int32_t gl_ntt_run(zklc_ctx *ctx, hipStream_t st, const u64 *in, size_t i
         return ZKLC_OK;
     }
     static const bool radix2 = getenv("ZKLC_NTT_RADIX2") != nullptr;   // A/B switch: the original one-stage-per-barrier loop
+    static const bool lds_ok = [] {     // 72 KB of dynamic LDS is above the default 64 KB cap
+        const int bytes = ((1 << NTT_TILE_LOG_BIG) + (1 << NTT_TILE_LOG_BIG) / 8) * (int)sizeof(u64);
+        return hipFuncSetAttribute((const void *)gl_ntt_pass_r8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void *)gl_ntt_pass_r8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    }();
+    if (!lds_ok) return ZKLC_ERR_HIP;
     const u64 *tw;
     int32_t rc = radix2 ? gl_get_twiddles(ctx, st, logn, inverse, &tw) : gl_get_staged_twiddles(ctx, st, logn, inverse, &tw);
     if (rc) return rc;
     if (load_shift) {
         if ((rc = gl_get_scale(ctx, st, load_shift, log_in))) return rc;
     }
-    // plan: strided windows of <= 8 bits from the top, then one contiguous window of <= 12 bits
+    // plan: strided windows from the top (each leaves >= 4 low bits in the tile: 128-byte runs), then one contiguous window.
+    // Tile of 2^12 elements, or 2^13 where that saves a whole pass over the data (e.g. 2^21: two passes instead of three);
+    // ZKLC_NTT_TILE=12|13 pins it (A/B).
+    static const int tile_pin = getenv("ZKLC_NTT_TILE") ? atoi(getenv("ZKLC_NTT_TILE")) : 0;
+    auto n_passes = [&](int T) { return 1 + (logn > T ? (logn - T + (T - 4) - 1) / (T - 4) : 0); };
+    int T = NTT_TILE_LOG_MAX;
+    if (!radix2 && (tile_pin == NTT_TILE_LOG_BIG || (tile_pin == 0 && n_passes(NTT_TILE_LOG_BIG) < n_passes(NTT_TILE_LOG_MAX))))
+        T = NTT_TILE_LOG_BIG;
     int ks[8], np = 0;
-    int k_last = logn < NTT_TILE_LOG_MAX ? logn : NTT_TILE_LOG_MAX;
+    int k_last = logn < T ? logn : T;
     int remaining = logn - k_last;
-    while (remaining > 0) {
-        int k = remaining < 8 ? remaining : 8;
+    for (int m = n_passes(T) - 1; m > 0; m--) {      // even split of the strided bits
+        int k = (remaining + m - 1) / m;
         ks[np++] = k;
         remaining -= k;
     }
@@ -475,8 +492,8 @@ static int32_t gl_ntt_run(zklc_ctx *ctx, hipStream_t st, const u64 *in, size_t i
         p.s0 = s0_of[i];
         p.k = ks[i];
         int lowbits = logn - p.s0 - p.k;
-        p.c = lowbits < (NTT_TILE_LOG_MAX - p.k) ? lowbits : (NTT_TILE_LOG_MAX - p.k);
-        int room = NTT_TILE_LOG_MAX - p.k - p.c;
+        p.c = lowbits < (T - p.k) ? lowbits : (T - p.k);
+        int room = T - p.k - p.c;
         p.d = p.s0 < room ? p.s0 : room;
         bool first = (ii == 0), last = (ii == np - 1);
         p.log_in = first ? log_in : logn;
@@ -492,12 +509,16 @@ static int32_t gl_ntt_run(zklc_ctx *ctx, hipStream_t st, const u64 *in, size_t i
             else
                 hipLaunchKernelGGL(gl_ntt_pass_kernel<false>, grid, dim3(NTT_THREADS), 0, st, src, out, sstride, out_stride, p, tw,
                                    (const u64 *)ctx->gl_scale_hi, (const u64 *)ctx->gl_scale_lo);
-        } else if (dit) {
-            hipLaunchKernelGGL(gl_ntt_pass_r8_kernel<true>, grid, dim3(NTT_THREADS), 0, st, src, out, sstride, out_stride, p, tw,
-                               (const u64 *)ctx->gl_scale_hi, (const u64 *)ctx->gl_scale_lo);
         } else {
-            hipLaunchKernelGGL(gl_ntt_pass_r8_kernel<false>, grid, dim3(NTT_THREADS), 0, st, src, out, sstride, out_stride, p, tw,
-                               (const u64 *)ctx->gl_scale_hi, (const u64 *)ctx->gl_scale_lo);
+            const int tile_log = p.k + p.c + p.d;
+            const unsigned threads = tile_log > NTT_TILE_LOG_MAX ? NTT_THREADS_MAX : NTT_THREADS;
+            const size_t lds = ((size_t(1) << tile_log) + (size_t(1) << tile_log) / 8) * sizeof(u64);
+            if (dit)
+                hipLaunchKernelGGL(gl_ntt_pass_r8_kernel<true>, grid, dim3(threads), lds, st, src, out, sstride, out_stride, p, tw,
+                                   (const u64 *)ctx->gl_scale_hi, (const u64 *)ctx->gl_scale_lo);
+            else
+                hipLaunchKernelGGL(gl_ntt_pass_r8_kernel<false>, grid, dim3(threads), lds, st, src, out, sstride, out_stride, p, tw,
+                                   (const u64 *)ctx->gl_scale_hi, (const u64 *)ctx->gl_scale_lo);
         }
         ZKLC_HIP(ctx, hipGetLastError());
     }
