@@ -160,13 +160,13 @@ void hostsim_p2_eval_gate(u32 type, const u32 *params, const u64 *extra, const u
     v.p = 0;
     v.nsel = 0;
     for (int k = 0; k < 4; k++) v.pih[k] = pih[k];
-    static u64 tab[P2_MAX_CH][1024];
+    static u32 tab[P2_MAX_CH][1024 * 6];
     p2_consumer out;
     out.nch = (int)nch;
     for (int c = 0; c < P2_MAX_CH; c++) {
         u64 a = c < (int)nch ? alpha[c] : 0, pw = 1;
         for (int i = 0; i < 1024; i++) {
-            tab[c][i] = pw;
+            gl_limbs22(pw, &tab[c][6 * i]);
             pw = gl_mul(pw, a);
         }
         out.apow[c] = tab[c];

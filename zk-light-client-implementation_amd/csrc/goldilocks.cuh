@@ -103,6 +103,48 @@ ZKLC_HD u64 gl_acc_reduce(const gl_acc160 &a) {
     return gl_sub(r, (u64)a.over << 32);
 }
 
+// Carry-free accumulation of x * k for many (x, k) where k comes from a TABLE: the table holds the 22-bit limbs of k and of
+// k' = 2^32 k mod p ({ka, kb, kc, k'a, k'b, k'c}, gl_limbs22), so that  x k = x0 k + x1 k'  (mod p) is six 32 x 22-bit products
+// added into three 64-bit columns of weights 1, 2^22, 2^44 -- six v_mad_u64_u32 and no carry handling at all (a 128-bit
+// product accumulated with carries costs ~20 instructions).  A column holds 2^10 products: callers fold before 500 terms.
+struct gl_acc3 {
+    u64 c0, c1, c2;
+};
+ZKLC_HD void gl_limbs22(u64 k, u32 *out6) {
+    u64 k2 = gl_mul(k, 1ULL << 32);
+    out6[0] = (u32)(k & 0x3FFFFF);
+    out6[1] = (u32)((k >> 22) & 0x3FFFFF);
+    out6[2] = (u32)(k >> 44);
+    out6[3] = (u32)(k2 & 0x3FFFFF);
+    out6[4] = (u32)((k2 >> 22) & 0x3FFFFF);
+    out6[5] = (u32)(k2 >> 44);
+}
+ZKLC_HD void gl_acc3_mul(gl_acc3 &a, u64 x, const u32 *k6) {
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+    a.c0 += (u64)x0 * k6[0];
+    a.c1 += (u64)x0 * k6[1];
+    a.c2 += (u64)x0 * k6[2];
+    a.c0 += (u64)x1 * k6[3];
+    a.c1 += (u64)x1 * k6[4];
+    a.c2 += (u64)x1 * k6[5];
+}
+// c0 + c1 2^22 + c2 2^44 mod p, canonical (any 64-bit columns)
+ZKLC_HD u64 gl_acc3_reduce(const gl_acc3 &a) {
+    u64 t1 = a.c1 << 22, t2 = a.c2 << 44;
+    u64 lo = a.c0 + t1;
+    u64 hi = (a.c1 >> 42) + (a.c2 >> 20) + (lo < t1);
+    lo += t2;
+    hi += lo < t2;
+    return gl_reduce128(lo, hi);
+}
+// the accumulator restarted from its own value (columns back below 2^22)
+ZKLC_HD void gl_acc3_normalize(gl_acc3 &a) {
+    u64 v = gl_acc3_reduce(a);
+    a.c0 = v & 0x3FFFFF;
+    a.c1 = (v >> 22) & 0x3FFFFF;
+    a.c2 = v >> 44;
+}
+
 ZKLC_HD u64 gl_pow(u64 a, u64 e) {
     u64 r = 1;
 #if defined(__HIPCC__)

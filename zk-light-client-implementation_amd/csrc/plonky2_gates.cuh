@@ -38,25 +38,28 @@ struct p2_gate {
 // sum_i alpha_c^(k0 + i) * constraint_i with the powers of alpha read from a table (wave-uniform index -> scalar loads)
 // and the products accumulated unreduced in 160 bits: 2 wide multiplications per constraint instead of 4 modular ones.
 struct p2_consumer {
-    const u64 *apow[P2_MAX_CH];   // apow[c][k] = alpha_c^k
-    gl_acc160 acc[P2_MAX_CH];
-    u32 k;
+    const u32 *apow[P2_MAX_CH];   // apow[c][6 k ..] = the six 22-bit limbs of alpha_c^k (gl_limbs22)
+    gl_acc3 acc[P2_MAX_CH];
+    u32 k, n;
     int nch;
     ZKLC_M void reset(u32 k0) {
         k = k0;
+        n = 0;
 #pragma unroll
-        for (int c = 0; c < P2_MAX_CH; c++) {
-            acc[c].lo = acc[c].hi = 0;
-            acc[c].over = 0;
-        }
+        for (int c = 0; c < P2_MAX_CH; c++) acc[c].c0 = acc[c].c1 = acc[c].c2 = 0;
     }
     ZKLC_M void emit(u64 v) {
+        if (++n == 480) {              // a column takes 2^10 products of 54 bits; no gate of the reference comes close
+            n = 0;
+#pragma unroll
+            for (int c = 0; c < P2_MAX_CH; c++) gl_acc3_normalize(acc[c]);
+        }
 #pragma unroll
         for (int c = 0; c < P2_MAX_CH; c++)
-            if (c < nch) gl_acc_mul(acc[c], v, apow[c][k]);
+            if (c < nch) gl_acc3_mul(acc[c], v, apow[c] + 6 * (size_t)k);
         k++;
     }
-    ZKLC_M u64 result(int c) const { return gl_acc_reduce(acc[c]); }
+    ZKLC_M u64 result(int c) const { return gl_acc3_reduce(acc[c]); }
     ZKLC_M void emit2(gl2 c) {
         emit(c.a);
         emit(c.b);

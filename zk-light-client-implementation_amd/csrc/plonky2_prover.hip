@@ -49,6 +49,15 @@ __global__ void p2_ext_powers_kernel(gl2 *out, gl2 z, u64 n) {
     if (j < n) out[j] = gl2_pow(z, j);
 }
 
+// out[12 j ..] = the 22-bit limbs (gl_limbs22) of the two coordinates of z^j: the constant table of gl_acc3_mul
+__global__ void p2_ext_pow_limbs_kernel(u32 *out, gl2 z, u32 n) {
+    u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    gl2 v = gl2_pow(z, j);
+    gl_limbs22(v.a, out + 12 * (size_t)j);
+    gl_limbs22(v.b, out + 12 * (size_t)j + 6);
+}
+
 // ---------------------------------------------------------------------------------------- Z and partial products
 // prover.rs `wires_permutation_partial_products_and_zs`: per row the running products of the chunk quotients
 //   rp[k][i] = prod_{k' <= k} prod_{j in chunk k'} (w_j + beta k_j x_i + gamma) / (w_j + beta sigma_j(x_i) + gamma)
@@ -165,7 +174,7 @@ struct p2_quotient_args {
     u64 n_field;                    // n as a field element
     u64 pih[4];
     p2_challenges ch;
-    const u64 *apow[P2_MAX_CH];     // powers of the alphas, one table per challenge
+    const u32 *apow[P2_MAX_CH];     // powers of the alphas as 22-bit limbs (gl_limbs22: 6 words per power), one table per challenge
     u64 *out;                       // [nch][N]
     const u64 *xs, *l0;             // per LDE point (bit-reversed order): x = g w^bitrev(p) and L_0(x) = (x^n - 1) / (n (x - 1))
     u32 num_wires;
@@ -439,30 +448,57 @@ struct p2_fri_combine_args {
     u64 w_lde;
     gl2 alpha, zeta, g_zeta, y0, y1, alpha_pow_nch;
     gl2 *out;             // [N] extension elements
+    const u32 *apow;      // alpha^i, i < sum(widths), as limbs (p2_ext_pow_limbs_kernel)
 };
 // fri/oracle.rs `prove_openings` in evaluation form (= fri.go:208-251 on the verifier side):
 //   out(x) = alpha^nch * (sum_i alpha^i p_i(x) - y0) / (x - zeta) + (sum_{i<nch} alpha^i z_i(x) - y1) / (x - g zeta)
+// The sums are NOT evaluated by Horner's rule (one extension multiplication per polynomial and a dependency chain as long as
+// the list): alpha^i comes from a table of 22-bit limbs (p2_ext_pow_limbs_kernel) and every p_i(x) alpha^i is twelve carry-free
+// v_mad_u64_u32 into two column accumulators (gl_acc3_mul) -- ~4 k instructions per point for the 357 polynomials of the
+// Ed25519 circuit instead of ~30 k, which leaves the kernel to the 8 bytes per polynomial and point it has to read.
 __global__ void __launch_bounds__(P2_THREADS) p2_fri_combine_kernel(p2_fri_combine_args a) {
     const size_t N = (size_t)1 << a.lde_bits;
     size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
     u64 i = __brevll((u64)p) >> (64 - a.lde_bits);
     u64 x = gl_mul(GL_GENERATOR, gl_pow(a.w_lde, i));
-    gl2 acc = gl2_make(0, 0);
-    for (int m = 3; m >= 0; m--) {
+    gl_acc3 sa = {0, 0, 0}, sb = {0, 0, 0};
+    const u32 *k6 = a.apow;
+    u32 terms = 0;
+    for (int m = 0; m < 4; m++) {
         const u64 *mat = a.mats[m] + p;
-        u32 j = a.widths[m];
-        for (; j >= 8; j -= 8) {   // Horner over the columns, eight loads in flight
-            u64 v[8];
+        const u32 w = a.widths[m];
+        u32 j = 0;
+        for (; j + 16 <= w; j += 16, k6 += 16 * 12) {   // sixteen loads in flight
+            u64 v[16];
 #pragma unroll
-            for (int q = 0; q < 8; q++) v[q] = mat[(size_t)(j - 1 - q) * N];
+            for (int q = 0; q < 16; q++) v[q] = mat[(size_t)(j + q) * N];
 #pragma unroll
-            for (int q = 0; q < 8; q++) acc = gl2_add_base(gl2_mul(acc, a.alpha), v[q]);
+            for (int q = 0; q < 16; q++) {
+                gl_acc3_mul(sa, v[q], k6 + 12 * q);
+                gl_acc3_mul(sb, v[q], k6 + 12 * q + 6);
+            }
+            if ((terms += 16) >= 384) {                  // a column holds 2^10 products = 512 terms; the tails below add < 48
+                terms = 0;
+                gl_acc3_normalize(sa);
+                gl_acc3_normalize(sb);
+            }
         }
-        while (j-- > 0) acc = gl2_add_base(gl2_mul(acc, a.alpha), mat[(size_t)j * N]);
+        for (; j < w; j++, k6 += 12) {
+            u64 v = mat[(size_t)j * N];
+            gl_acc3_mul(sa, v, k6);
+            gl_acc3_mul(sb, v, k6 + 6);
+        }
+        terms += 16;
     }
-    gl2 acc1 = gl2_make(0, 0);
-    for (u32 j = a.nch; j-- > 0;) acc1 = gl2_add_base(gl2_mul(acc1, a.alpha), a.mats[2][(size_t)j * N + p]);
+    gl2 acc = gl2_make(gl_acc3_reduce(sa), gl_acc3_reduce(sb));
+    gl_acc3 ta = {0, 0, 0}, tb = {0, 0, 0};
+    for (u32 j = 0; j < a.nch; j++) {
+        u64 v = a.mats[2][(size_t)j * N + p];
+        gl_acc3_mul(ta, v, a.apow + 12 * (size_t)j);
+        gl_acc3_mul(tb, v, a.apow + 12 * (size_t)j + 6);
+    }
+    gl2 acc1 = gl2_make(gl_acc3_reduce(ta), gl_acc3_reduce(tb));
     gl2 q0 = gl2_mul(gl2_sub(acc, a.y0), gl2_inv(gl2_sub(gl2_make(x, 0), a.zeta)));
     gl2 q1 = gl2_mul(gl2_sub(acc1, a.y1), gl2_inv(gl2_sub(gl2_make(x, 0), a.g_zeta)));
     a.out[p] = gl2_add(gl2_mul(q0, a.alpha_pow_nch), q1);
@@ -598,7 +634,8 @@ struct zklc_plonky2_circuit {
     u64 *d_wire_vals = nullptr;       // witness values (routed columns are needed after the iNTT)
     u64 *d_rp = nullptr, *d_excl = nullptr, *d_totals = nullptr, *d_grand = nullptr;
     u64 *d_qv = nullptr;              // quotient values [nch][N]
-    u64 *d_apow = nullptr;            // powers of the alphas for the quotient kernel
+    u32 *d_apow = nullptr;            // powers of the alphas for the quotient kernels (6 limb words per power)
+    u32 *d_fri_apow = nullptr;        // powers of the FRI batching challenge (12 limb words per power)
     u64 *d_xs = nullptr, *d_l0 = nullptr;   // per LDE point: x and L_0(x) (p2_point_tables_kernel)
     p2_fused_plan plan = {};          // job lists of the fused quotient kernel; plan.nwaves == 0: per-gate launches
     size_t fused_lds = 0;
@@ -865,8 +902,9 @@ static int32_t p2_create(zklc_ctx *ctx, const zklc_plonky2_params *params, const
     P2_ALLOC(c, c->d_excl, (size_t)n * 8);
     P2_ALLOC(c, c->d_totals, (size_t)((n + P2_SCAN_BLOCK - 1) / P2_SCAN_BLOCK) * 8);
     P2_ALLOC(c, c->d_grand, 8);
-    P2_ALLOC(c, c->d_apow, (size_t)nch_ * (nch_ + nch_ * (P.num_partial_products + 1) + P.num_gate_constraints + 1) * 8);
+    P2_ALLOC(c, c->d_apow, (size_t)nch_ * (nch_ + nch_ * (P.num_partial_products + 1) + P.num_gate_constraints + 1) * 24);
     P2_ALLOC(c, c->d_zpow, (size_t)n * sizeof(gl2));
+    P2_ALLOC(c, c->d_fri_apow, (size_t)(c->cs.width + c->wires.width + c->zs.width + c->quot.width + 1) * 12 * sizeof(u32));
     P2_ALLOC(c, c->d_xs, (size_t)N * 8);
     P2_ALLOC(c, c->d_l0, (size_t)N * 8);
     u32 total_polys = c->cs.width + c->wires.width + c->zs.width + c->quot.width + nch;
@@ -1092,17 +1130,20 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
         a.ch = chal;
         {
             u32 n_pow = nch + nch * (npp + 1) + P.num_gate_constraints + 1;
-            std::vector<u64> tab((size_t)nch * n_pow);
+            std::vector<u32> tab((size_t)nch * n_pow * 6);
             for (u32 k = 0; k < nch; k++) {
                 u64 v = 1;
                 for (u32 i = 0; i < n_pow; i++) {
-                    tab[(size_t)k * n_pow + i] = v;
+                    u32 *t6 = &tab[((size_t)k * n_pow + i) * 6];      // gl_limbs22 on the host
+                    const u64 v2 = h_mul(v, 1ULL << 32);
+                    t6[0] = (u32)(v & 0x3FFFFF), t6[1] = (u32)((v >> 22) & 0x3FFFFF), t6[2] = (u32)(v >> 44);
+                    t6[3] = (u32)(v2 & 0x3FFFFF), t6[4] = (u32)((v2 >> 22) & 0x3FFFFF), t6[5] = (u32)(v2 >> 44);
                     v = h_mul(v, chal.alpha[k]);
                 }
             }
-            ZKLC_HIP(ctx, hipMemcpyAsync(c->d_apow, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st));
+            ZKLC_HIP(ctx, hipMemcpyAsync(c->d_apow, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
             ZKLC_HIP(ctx, zklc_stream_wait(st));   // `tab` is a stack-lifetime source
-            for (u32 k = 0; k < nch; k++) a.apow[k] = c->d_apow + (size_t)k * n_pow;
+            for (u32 k = 0; k < nch; k++) a.apow[k] = c->d_apow + (size_t)k * n_pow * 6;
             for (u32 k = nch; k < P2_MAX_CH; k++) a.apow[k] = c->d_apow;
         }
         if (c->plan.nwaves) {
@@ -1186,6 +1227,9 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
         a.y1 = y1;
         a.alpha_pow_nch = h2_pow(fri_alpha, nch);
         a.out = c->d_fri[0];
+        a.apow = c->d_fri_apow;
+        hipLaunchKernelGGL(p2_ext_pow_limbs_kernel, dim3((w0 + w1 + w2 + w3 + 255) / 256), dim3(256), 0, st, c->d_fri_apow, fri_alpha,
+                           w0 + w1 + w2 + w3);
         hipLaunchKernelGGL(p2_fri_combine_kernel, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a);
         ZKLC_HIP(ctx, hipGetLastError());
         u32 bits = c->lde_bits;
