@@ -222,9 +222,16 @@ __global__ void __launch_bounds__(P2_THREADS) p2_quotient_base_kernel(p2_quotien
     for (u32 c = 0; c < a.nch; c++) a.out[(size_t)c * N + p] = gl_mul(out.result(c), a.zh_inv[coset]);
 }
 
-// gate constraints, filtered (evaluate_gates.go:59-105); TYPE is a compile-time constant so only that evaluator is inlined
+// gate constraints, filtered (evaluate_gates.go:59-105); TYPE is a compile-time constant so only that evaluator is inlined.
+// One launch takes ALL gates of the list that have this type (the eight U32AddMany variants of the Ed25519 circuit, the two
+// BaseSum variants): they read nearly the same wire columns, and the second to eighth pass over a wave's 64 points finds them in
+// the memory-side cache instead of streaming the LDE matrix from HBM once per variant.
+#define P2_GATE_LIST_MAX 8
+struct p2_gate_list {
+    u32 n, idx[P2_GATE_LIST_MAX];
+};
 template <int TYPE>
-__global__ void __launch_bounds__(P2_THREADS) p2_quotient_gate_kernel(p2_quotient_args a, u32 g) {
+__global__ void __launch_bounds__(P2_THREADS) p2_quotient_gate_kernel(p2_quotient_args a, p2_gate_list list) {
     const size_t N = (size_t)1 << a.lde_bits;
     size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= N) return;
@@ -237,21 +244,28 @@ __global__ void __launch_bounds__(P2_THREADS) p2_quotient_gate_kernel(p2_quotien
     v.p = p;
     v.nsel = a.nsel;
     for (int k = 0; k < 4; k++) v.pih[k] = a.pih[k];
-    p2_gate gate = a.gates[g];
-    gate.type = TYPE;
     p2_consumer out;
     out.nch = a.nch;
     for (int c = 0; c < P2_MAX_CH; c++) out.apow[c] = a.apow[c];
-    out.reset(a.nch + a.nch * (a.npp + 1));   // the gate constraints follow the Z1 and partial-product terms
-    p2_eval_gate(gate, v, a.extra, out);
-    u64 f = gl_mul(p2_filter(g, gate.group_start, gate.group_end, v.sel(gate.selector_index), a.nsel > 1), a.zh_inv[coset]);
+    u64 sum[P2_MAX_CH];
+    for (int c = 0; c < P2_MAX_CH; c++) sum[c] = 0;
+#pragma unroll 1
+    for (u32 t = 0; t < list.n; t++) {
+        const u32 g = list.idx[t];
+        p2_gate gate = a.gates[g];
+        gate.type = TYPE;
+        out.reset(a.nch + a.nch * (a.npp + 1));   // the gate constraints follow the Z1 and partial-product terms
+        p2_eval_gate(gate, v, a.extra, out);
+        u64 f = p2_filter(g, gate.group_start, gate.group_end, v.sel(gate.selector_index), a.nsel > 1);
+        for (u32 c = 0; c < a.nch; c++) sum[c] = gl_add(sum[c], gl_mul(f, out.result((int)c)));
+    }
     for (u32 c = 0; c < a.nch; c++) {
         u64 *o = a.out + (size_t)c * N + p;
-        *o = gl_add(*o, gl_mul(f, out.result((int)c)));
+        *o = gl_add(*o, gl_mul(sum[c], a.zh_inv[coset]));
     }
 }
 
-typedef void (*p2_gate_kernel_fn)(p2_quotient_args, u32);
+typedef void (*p2_gate_kernel_fn)(p2_quotient_args, p2_gate_list);
 static p2_gate_kernel_fn p2_gate_kernel_of(u32 type) {
     switch (type) {
 #define P2_CASE(T) case T: return p2_quotient_gate_kernel<T>;
@@ -791,9 +805,12 @@ static int32_t p2_plan_quotient(zklc_plonky2_circuit *c, hipStream_t st) {
         if (g < P.num_gates && !fn) continue;
         for (int rep = 0; rep < 2; rep++) {
             ZKLC_HIP(ctx, hipEventRecord(e0, st));
-            if (fn)
-                hipLaunchKernelGGL(fn, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a, g);
-            else
+            if (fn) {
+                p2_gate_list one = {};
+                one.n = 1;
+                one.idx[0] = g;
+                hipLaunchKernelGGL(fn, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a, one);
+            } else
                 hipLaunchKernelGGL(p2_quotient_base_kernel, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a);
             ZKLC_HIP(ctx, hipEventRecord(e1, st));
             ZKLC_HIP(ctx, hipEventSynchronize(e1));
@@ -1150,9 +1167,18 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
             hipLaunchKernelGGL(p2_quotient_fused_kernel, dim3(N / 64), dim3(64 * c->plan.nwaves), c->fused_lds, st, a, c->plan);
         } else {
             hipLaunchKernelGGL(p2_quotient_base_kernel, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a);
+            static const bool one_per_launch = getenv("ZKLC_P2_GATE_LAUNCH") && !strcmp(getenv("ZKLC_P2_GATE_LAUNCH"), "single");   // A/B
+            std::vector<bool> done(P.num_gates, false);
             for (u32 g = 0; g < P.num_gates; g++) {
                 p2_gate_kernel_fn fn = p2_gate_kernel_of(c->gates[g].type);
-                if (fn) hipLaunchKernelGGL(fn, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a, g);
+                if (!fn || done[g]) continue;
+                p2_gate_list list = {};
+                for (u32 h = g; h < P.num_gates && list.n < (one_per_launch ? 1u : (u32)P2_GATE_LIST_MAX); h++)
+                    if (!done[h] && c->gates[h].type == c->gates[g].type) {
+                        list.idx[list.n++] = h;
+                        done[h] = true;
+                    }
+                hipLaunchKernelGGL(fn, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a, list);
             }
         }
         ZKLC_HIP(ctx, hipGetLastError());
