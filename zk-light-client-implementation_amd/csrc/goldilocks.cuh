@@ -110,6 +110,16 @@ ZKLC_HD u64 gl_acc_reduce(const gl_acc160 &a) {
 struct gl_acc3 {
     u64 c0, c1, c2;
 };
+// A uniform read-only table in global memory, addressed through the CONSTANT address space: the compiler may then fetch it with
+// scalar loads (s_load_dwordx8/x16 into SGPRs, batched over consecutive entries).  Through a plain pointer the same reads are
+// per-lane global loads whose latency sits in front of every use, because a kernel that also stores cannot prove them invariant.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(4))) const u32 gl_ktab;
+typedef __attribute__((address_space(4))) const u64 gl_ktab64;
+#else
+typedef const u32 gl_ktab;
+typedef const u64 gl_ktab64;
+#endif
 ZKLC_HD void gl_limbs22(u64 k, u32 *out6) {
     u64 k2 = gl_mul(k, 1ULL << 32);
     out6[0] = (u32)(k & 0x3FFFFF);
@@ -119,7 +129,8 @@ ZKLC_HD void gl_limbs22(u64 k, u32 *out6) {
     out6[4] = (u32)((k2 >> 22) & 0x3FFFFF);
     out6[5] = (u32)(k2 >> 44);
 }
-ZKLC_HD void gl_acc3_mul(gl_acc3 &a, u64 x, const u32 *k6) {
+template <class K>
+ZKLC_HD void gl_acc3_mul(gl_acc3 &a, u64 x, K k6) {
     const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
     a.c0 += (u64)x0 * k6[0];
     a.c1 += (u64)x0 * k6[1];

@@ -38,7 +38,7 @@ struct p2_gate {
 // sum_i alpha_c^(k0 + i) * constraint_i with the powers of alpha read from a table (wave-uniform index -> scalar loads)
 // and the products accumulated unreduced in 160 bits: 2 wide multiplications per constraint instead of 4 modular ones.
 struct p2_consumer {
-    const u32 *apow[P2_MAX_CH];   // apow[c][6 k ..] = the six 22-bit limbs of alpha_c^k (gl_limbs22)
+    gl_ktab *apow[P2_MAX_CH];     // apow[c][6 k ..] = the six 22-bit limbs of alpha_c^k (gl_limbs22); scalar loads
     gl_acc3 acc[P2_MAX_CH];
     u32 k, n;
     int nch;
@@ -114,6 +114,27 @@ ZKLC_D u64 p2_mul4_loose(u64 a) {
 }
 // Horner step of sum_j limb_j 4^j: loose accumulator, canonical limb
 ZKLC_D u64 p2_horner4(u64 acc, u64 limb) { return gl_add_lc(p2_mul4_loose(acc), limb); }
+// N consecutive wires into registers with all loads in flight at once.  The evaluators below used to read a wire, use it, read the
+// next: a loop the compiler keeps rolled, one global load per iteration with its full latency exposed -- the per-gate quotient
+// kernels were bound by that latency, not by HBM bandwidth or the VALU (profiles/r02_prove_ed25519_kernel_stats_v3.csv).
+template <int N, class V>
+ZKLC_D void p2_load(const V &v, u32 first, u64 *dst) {
+#pragma unroll
+    for (int q = 0; q < N; q++) dst[q] = v.w(first + q);
+}
+// sum of n consecutive wires (canonical), four loads in flight
+template <class V>
+ZKLC_D u64 p2_sum_wires(const V &v, u32 first, u32 n) {
+    u64 sum = 0;
+    u32 j = 0;
+    for (; j + 4 <= n; j += 4) {
+        u64 t[4];
+        p2_load<4>(v, first + j, t);
+        sum = gl_add(gl_add(sum, t[0]), gl_add(t[1], gl_add(t[2], t[3])));
+    }
+    for (; j < n; j++) sum = gl_add(sum, v.w(first + j));
+    return sum;
+}
 
 template <class V>
 ZKLC_D void p2_eval_constant(const V &v, u32 n, p2_consumer &out) {
@@ -128,7 +149,15 @@ ZKLC_D void p2_eval_public_input(const V &v, p2_consumer &out) {
 template <class V>
 ZKLC_D void p2_eval_arithmetic(const V &v, u32 num_ops, p2_consumer &out) {
     u64 c0 = v.c(0), c1 = v.c(1);
-    for (u32 i = 0; i < num_ops; i++) {
+    u32 i = 0;
+    for (; i + 4 <= num_ops; i += 4) {
+        u64 w[16];
+        p2_load<16>(v, 4 * i, w);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            out.emit(gl_sub(w[4 * q + 3], gl_add(gl_mul(gl_mul(w[4 * q], w[4 * q + 1]), c0), gl_mul(w[4 * q + 2], c1))));
+    }
+    for (; i < num_ops; i++) {
         u64 m0 = v.w(4 * i), m1 = v.w(4 * i + 1), a = v.w(4 * i + 2), o = v.w(4 * i + 3);
         out.emit(gl_sub(o, gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(a, c1))));
     }
@@ -156,15 +185,24 @@ ZKLC_D void p2_eval_mul_ext(const V &v, u32 num_ops, p2_consumer &out) {
 template <class V>
 ZKLC_D void p2_eval_base_sum(const V &v, u32 num_limbs, u32 base, p2_consumer &out) {
     u64 acc = 0;
-    if (base == 2)
-        for (u32 i = num_limbs; i-- > 0;) acc = gl_add(gl_add(acc, acc), v.w(1 + i));
-    else if (base == 4) {
-        for (u32 i = num_limbs; i-- > 0;) acc = p2_horner4(acc, v.w(1 + i));
-        acc = gl_canonical(acc);
-    } else
-        for (u32 i = num_limbs; i-- > 0;) acc = gl_add(gl_mul(acc, base), v.w(1 + i));
+    u32 i = num_limbs;
+    for (; i >= 8; i -= 8) {     // Horner from the top limb, eight loads in flight
+        u64 l[8];
+        p2_load<8>(v, 1 + i - 8, l);
+#pragma unroll
+        for (int q = 7; q >= 0; q--) acc = base == 2 ? gl_add(gl_add(acc, acc), l[q]) : base == 4 ? p2_horner4(acc, l[q]) : gl_add(gl_mul(acc, base), l[q]);
+    }
+    while (i-- > 0) acc = base == 2 ? gl_add(gl_add(acc, acc), v.w(1 + i)) : base == 4 ? p2_horner4(acc, v.w(1 + i)) : gl_add(gl_mul(acc, base), v.w(1 + i));
+    if (base == 4) acc = gl_canonical(acc);
     out.emit(gl_sub(acc, v.w(0)));
-    for (u32 i = 0; i < num_limbs; i++) out.emit(p2_range_product(v.w(1 + i), base));
+    i = 0;
+    for (; i + 8 <= num_limbs; i += 8) {
+        u64 l[8];
+        p2_load<8>(v, 1 + i, l);
+#pragma unroll
+        for (int q = 0; q < 8; q++) out.emit(p2_range_product(l[q], base));
+    }
+    for (; i < num_limbs; i++) out.emit(p2_range_product(v.w(1 + i), base));
 }
 
 // poseidon_gate.go:84-181
@@ -354,21 +392,26 @@ ZKLC_D void p2_eval_coset_interpolation(const V &v, u32 bits, u32 degree, const 
 template <class V>
 ZKLC_D void p2_eval_u32_arithmetic(const V &v, u32 num_ops, p2_consumer &out) {
     for (u32 i = 0; i < num_ops; i++) {
-        u64 m0 = v.w(6 * i), m1 = v.w(6 * i + 1), add = v.w(6 * i + 2), lo = v.w(6 * i + 3), hi = v.w(6 * i + 4),
-            inv = v.w(6 * i + 5);
+        u64 r[6], lh[16], ll[16];
+        p2_load<6>(v, 6 * i, r);
+        p2_load<16>(v, 6 * num_ops + 32 * i + 16, lh);
+        p2_load<16>(v, 6 * num_ops + 32 * i, ll);
+        u64 m0 = r[0], m1 = r[1], add = r[2], lo = r[3], hi = r[4], inv = r[5];
         u64 computed = gl_add(gl_mul(m0, m1), add);
         u64 diff = gl_sub(0xFFFFFFFFULL, hi);
         u64 hi_not_max = gl_sub(gl_mul(inv, diff), 1);
         out.emit(gl_mul(hi_not_max, lo));
         out.emit(gl_sub(gl_add(gl_mul(hi, 1ULL << 32), lo), computed));
         u64 comb_lo = 0, comb_hi = 0;
-        for (u32 j = 32; j-- > 0;) {
-            u64 l = v.w(6 * num_ops + 32 * i + j);
-            out.emit(p2_range_product(l, 4));
-            if (j < 16)
-                comb_lo = p2_horner4(comb_lo, l);
-            else
-                comb_hi = p2_horner4(comb_hi, l);
+#pragma unroll
+        for (int j = 15; j >= 0; j--) {
+            out.emit(p2_range_product(lh[j], 4));
+            comb_hi = p2_horner4(comb_hi, lh[j]);
+        }
+#pragma unroll
+        for (int j = 15; j >= 0; j--) {
+            out.emit(p2_range_product(ll[j], 4));
+            comb_lo = p2_horner4(comb_lo, ll[j]);
         }
         out.emit(gl_sub(gl_canonical(comb_lo), lo));
         out.emit(gl_sub(gl_canonical(comb_hi), hi));
@@ -380,18 +423,20 @@ template <class V>
 ZKLC_D void p2_eval_u32_add_many(const V &v, u32 num_addends, u32 num_ops, p2_consumer &out) {
     const u32 per = num_addends + 3;
     for (u32 i = 0; i < num_ops; i++) {
-        u64 sum = v.w(per * i + num_addends);  // carry in
-        for (u32 j = 0; j < num_addends; j++) sum = gl_add(sum, v.w(per * i + j));
-        u64 res = v.w(per * i + num_addends + 1), carry = v.w(per * i + num_addends + 2);
+        u64 l[18], rc[2];
+        p2_load<18>(v, per * num_ops + 18 * i, l);
+        p2_load<2>(v, per * i + num_addends + 1, rc);
+        u64 sum = p2_sum_wires(v, per * i, num_addends + 1);   // the addends and the carry in
+        u64 res = rc[0], carry = rc[1];
         out.emit(gl_sub(gl_add(gl_mul(carry, 1ULL << 32), res), sum));
         u64 comb_res = 0, comb_carry = 0;
-        for (u32 j = 18; j-- > 0;) {
-            u64 l = v.w(per * num_ops + 18 * i + j);
-            out.emit(p2_range_product(l, 4));
+#pragma unroll
+        for (int j = 17; j >= 0; j--) {
+            out.emit(p2_range_product(l[j], 4));
             if (j < 16)
-                comb_res = p2_horner4(comb_res, l);
+                comb_res = p2_horner4(comb_res, l[j]);
             else
-                comb_carry = p2_horner4(comb_carry, l);
+                comb_carry = p2_horner4(comb_carry, l[j]);
         }
         out.emit(gl_sub(gl_canonical(comb_res), res));
         out.emit(gl_sub(gl_canonical(comb_carry), carry));
@@ -402,14 +447,17 @@ ZKLC_D void p2_eval_u32_add_many(const V &v, u32 num_addends, u32 num_ops, p2_co
 template <class V>
 ZKLC_D void p2_eval_u32_subtraction(const V &v, u32 num_ops, p2_consumer &out) {
     for (u32 i = 0; i < num_ops; i++) {
-        u64 x = v.w(5 * i), y = v.w(5 * i + 1), bin = v.w(5 * i + 2), res = v.w(5 * i + 3), bout = v.w(5 * i + 4);
+        u64 r[5], l[16];
+        p2_load<5>(v, 5 * i, r);
+        p2_load<16>(v, 5 * num_ops + 16 * i, l);
+        u64 x = r[0], y = r[1], bin = r[2], res = r[3], bout = r[4];
         u64 initial = gl_sub(gl_sub(x, y), bin);
         out.emit(gl_sub(res, gl_add(initial, gl_mul(bout, 1ULL << 32))));
         u64 comb = 0;
-        for (u32 j = 16; j-- > 0;) {
-            u64 l = v.w(5 * num_ops + 16 * i + j);
-            out.emit(p2_range_product(l, 4));
-            comb = p2_horner4(comb, l);
+#pragma unroll
+        for (int j = 15; j >= 0; j--) {
+            out.emit(p2_range_product(l[j], 4));
+            comb = p2_horner4(comb, l[j]);
         }
         out.emit(gl_sub(gl_canonical(comb), res));
         out.emit(gl_mul(bout, gl_sub(1, bout)));
@@ -420,10 +468,14 @@ ZKLC_D void p2_eval_u32_subtraction(const V &v, u32 num_ops, p2_consumer &out) {
 template <class V>
 ZKLC_D void p2_eval_u32_range_check(const V &v, u32 n, p2_consumer &out) {
     for (u32 i = 0; i < n; i++) {
+        u64 l[16];
+        p2_load<16>(v, n + 16 * i, l);
         u64 sum = 0;
-        for (u32 j = 16; j-- > 0;) sum = p2_horner4(sum, v.w(n + 16 * i + j));
+#pragma unroll
+        for (int j = 15; j >= 0; j--) sum = p2_horner4(sum, l[j]);
         out.emit(gl_sub(gl_canonical(sum), v.w(i)));
-        for (u32 j = 0; j < 16; j++) out.emit(p2_range_product(v.w(n + 16 * i + j), 4));
+#pragma unroll
+        for (int j = 0; j < 16; j++) out.emit(p2_range_product(l[j], 4));
     }
 }
 
@@ -433,33 +485,52 @@ ZKLC_D void p2_eval_comparison(const V &v, u32 num_bits, u32 num_chunks, p2_cons
     const u32 chunk_bits = (num_bits + num_chunks - 1) / num_chunks;
     const u32 chunk_size = 1u << chunk_bits;
     u64 c1 = 0, c2 = 0;
-    if (chunk_size == 4) {
-        for (u32 i = num_chunks; i-- > 0;) {
-            c1 = p2_horner4(c1, v.w(4 + i));
-            c2 = p2_horner4(c2, v.w(4 + num_chunks + i));
+    {
+        u32 i = num_chunks;
+        for (; i >= 8; i -= 8) {     // both Horner sums from the top chunk, sixteen loads in flight
+            u64 a[8], b[8];
+            p2_load<8>(v, 4 + i - 8, a);
+            p2_load<8>(v, 4 + num_chunks + i - 8, b);
+#pragma unroll
+            for (int q = 7; q >= 0; q--) {
+                c1 = chunk_size == 4 ? p2_horner4(c1, a[q]) : gl_add(gl_mul(c1, chunk_size), a[q]);
+                c2 = chunk_size == 4 ? p2_horner4(c2, b[q]) : gl_add(gl_mul(c2, chunk_size), b[q]);
+            }
         }
-        c1 = gl_canonical(c1);
-        c2 = gl_canonical(c2);
-    } else
-        for (u32 i = num_chunks; i-- > 0;) {
-            c1 = gl_add(gl_mul(c1, chunk_size), v.w(4 + i));
-            c2 = gl_add(gl_mul(c2, chunk_size), v.w(4 + num_chunks + i));
+        while (i-- > 0) {
+            c1 = chunk_size == 4 ? p2_horner4(c1, v.w(4 + i)) : gl_add(gl_mul(c1, chunk_size), v.w(4 + i));
+            c2 = chunk_size == 4 ? p2_horner4(c2, v.w(4 + num_chunks + i)) : gl_add(gl_mul(c2, chunk_size), v.w(4 + num_chunks + i));
         }
+        if (chunk_size == 4) {
+            c1 = gl_canonical(c1);
+            c2 = gl_canonical(c2);
+        }
+    }
     out.emit(gl_sub(c1, v.w(0)));
     out.emit(gl_sub(c2, v.w(1)));
     u64 msd = 0;
-    for (u32 i = 0; i < num_chunks; i++) {
-        u64 a = v.w(4 + i), b = v.w(4 + num_chunks + i);
+    auto chunk = [&](u64 a, u64 b, u64 dummy, u64 eq, u64 inter) {
         out.emit(p2_range_product(a, chunk_size));
         out.emit(p2_range_product(b, chunk_size));
         u64 diff = gl_sub(b, a);
-        u64 dummy = v.w(4 + 2 * num_chunks + i), eq = v.w(4 + 3 * num_chunks + i);
         out.emit(gl_sub(gl_mul(diff, dummy), gl_sub(1, eq)));
         out.emit(gl_mul(eq, diff));
-        u64 inter = v.w(4 + 4 * num_chunks + i);
         out.emit(gl_sub(inter, gl_mul(eq, msd)));
         msd = gl_add(inter, gl_mul(gl_sub(1, eq), diff));
+    };
+    u32 i = 0;
+    for (; i + 4 <= num_chunks; i += 4) {     // twenty loads in flight
+        u64 a[4], b[4], d[4], e[4], in[4];
+        p2_load<4>(v, 4 + i, a);
+        p2_load<4>(v, 4 + num_chunks + i, b);
+        p2_load<4>(v, 4 + 2 * num_chunks + i, d);
+        p2_load<4>(v, 4 + 3 * num_chunks + i, e);
+        p2_load<4>(v, 4 + 4 * num_chunks + i, in);
+#pragma unroll
+        for (int q = 0; q < 4; q++) chunk(a[q], b[q], d[q], e[q], in[q]);
     }
+    for (; i < num_chunks; i++)
+        chunk(v.w(4 + i), v.w(4 + num_chunks + i), v.w(4 + 2 * num_chunks + i), v.w(4 + 3 * num_chunks + i), v.w(4 + 4 * num_chunks + i));
     u64 msd_w = v.w(3);
     out.emit(gl_sub(msd_w, msd));
     u64 comb = 0;

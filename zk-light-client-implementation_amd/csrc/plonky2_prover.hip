@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(P2_THREADS) p2_quotient_base_kernel(p2_quotien
 
     p2_consumer out;
     out.nch = a.nch;
-    for (int c = 0; c < P2_MAX_CH; c++) out.apow[c] = a.apow[c];
+    for (int c = 0; c < P2_MAX_CH; c++) out.apow[c] = (gl_ktab *)a.apow[c];
     out.reset(0);
     // L_0(x) (Z(x) - 1)
     for (u32 c = 0; c < a.nch; c++) out.emit(gl_mul(l0, gl_sub(a.zs[(size_t)c * N + p], 1)));
@@ -209,9 +209,26 @@ __global__ void __launch_bounds__(P2_THREADS) p2_quotient_base_kernel(p2_quotien
         for (u32 k = 0; k < nchunks; k++) {
             u64 np = 1, dp = 1;
             u32 end = (k + 1) * a.qdf < a.routed ? (k + 1) * a.qdf : a.routed;
-            for (u32 j = k * a.qdf; j < end; j++) {
+            gl_ktab64 *kis = (gl_ktab64 *)a.k_is;
+            u32 j = k * a.qdf;
+            if (end - j == 8) {          // the usual chunk (quotient degree factor 8): sixteen loads in flight
+                u64 wv[8], sv[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    wv[q] = a.wires[(size_t)(j + q) * N + p];
+                    sv[q] = a.cs[(size_t)(a.num_constants + j + q) * N + p];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    u64 w = gl_add(wv[q], gamma);
+                    np = gl_mul(np, gl_add(w, gl_mul(beta, gl_mul(kis[j + q], x))));
+                    dp = gl_mul(dp, gl_add(w, gl_mul(beta, sv[q])));
+                }
+                j = end;
+            }
+            for (; j < end; j++) {
                 u64 w = gl_add(a.wires[(size_t)j * N + p], gamma);
-                np = gl_mul(np, gl_add(w, gl_mul(beta, gl_mul(a.k_is[j], x))));
+                np = gl_mul(np, gl_add(w, gl_mul(beta, gl_mul(kis[j], x))));
                 dp = gl_mul(dp, gl_add(w, gl_mul(beta, a.cs[(size_t)(a.num_constants + j) * N + p])));
             }
             u64 next = k + 1 < nchunks ? a.zs[(size_t)(a.nch + c * a.npp + k) * N + p] : a.zs[(size_t)c * N + p_next];
@@ -219,7 +236,10 @@ __global__ void __launch_bounds__(P2_THREADS) p2_quotient_base_kernel(p2_quotien
             prev = next;
         }
     }
-    for (u32 c = 0; c < a.nch; c++) a.out[(size_t)c * N + p] = gl_mul(out.result(c), a.zh_inv[coset]);
+    const u64 zi = a.zh_inv[coset];
+#pragma unroll
+    for (int c = 0; c < P2_MAX_CH; c++)      // static indices: a dynamic one would push the accumulators into memory
+        if (c < (int)a.nch) a.out[(size_t)c * N + p] = gl_mul(out.result(c), zi);
 }
 
 // gate constraints, filtered (evaluate_gates.go:59-105); TYPE is a compile-time constant so only that evaluator is inlined.
@@ -246,7 +266,7 @@ __global__ void __launch_bounds__(P2_THREADS) p2_quotient_gate_kernel(p2_quotien
     for (int k = 0; k < 4; k++) v.pih[k] = a.pih[k];
     p2_consumer out;
     out.nch = a.nch;
-    for (int c = 0; c < P2_MAX_CH; c++) out.apow[c] = a.apow[c];
+    for (int c = 0; c < P2_MAX_CH; c++) out.apow[c] = (gl_ktab *)a.apow[c];
     u64 sum[P2_MAX_CH];
     for (int c = 0; c < P2_MAX_CH; c++) sum[c] = 0;
 #pragma unroll 1
@@ -257,12 +277,17 @@ __global__ void __launch_bounds__(P2_THREADS) p2_quotient_gate_kernel(p2_quotien
         out.reset(a.nch + a.nch * (a.npp + 1));   // the gate constraints follow the Z1 and partial-product terms
         p2_eval_gate(gate, v, a.extra, out);
         u64 f = p2_filter(g, gate.group_start, gate.group_end, v.sel(gate.selector_index), a.nsel > 1);
-        for (u32 c = 0; c < a.nch; c++) sum[c] = gl_add(sum[c], gl_mul(f, out.result((int)c)));
+#pragma unroll
+        for (int c = 0; c < P2_MAX_CH; c++)      // static indices: a dynamic one would push the accumulators into memory
+            if (c < (int)a.nch) sum[c] = gl_add(sum[c], gl_mul(f, out.result(c)));
     }
-    for (u32 c = 0; c < a.nch; c++) {
-        u64 *o = a.out + (size_t)c * N + p;
-        *o = gl_add(*o, gl_mul(sum[c], a.zh_inv[coset]));
-    }
+    const u64 zi = a.zh_inv[coset];
+#pragma unroll
+    for (int c = 0; c < P2_MAX_CH; c++)
+        if (c < (int)a.nch) {
+            u64 *o = a.out + (size_t)c * N + p;
+            *o = gl_add(*o, gl_mul(sum[c], zi));
+        }
 }
 
 typedef void (*p2_gate_kernel_fn)(p2_quotient_args, p2_gate_list);
@@ -329,7 +354,7 @@ __global__ void __launch_bounds__(64 * P2_FQ_MAX_WAVES) p2_quotient_fused_kernel
     u64 sum[P2_MAX_CH] = {0, 0};
     p2_consumer out;
     out.nch = a.nch;
-    for (int c = 0; c < P2_MAX_CH; c++) out.apow[c] = a.apow[c];
+    for (int c = 0; c < P2_MAX_CH; c++) out.apow[c] = (gl_ktab *)a.apow[c];
     const u32 njobs = plan.njobs[wave];
     for (u32 jb = 0; jb < njobs; jb++) {
         const u32 g = plan.jobs[wave][jb];
@@ -477,7 +502,7 @@ __global__ void __launch_bounds__(P2_THREADS) p2_fri_combine_kernel(p2_fri_combi
     u64 i = __brevll((u64)p) >> (64 - a.lde_bits);
     u64 x = gl_mul(GL_GENERATOR, gl_pow(a.w_lde, i));
     gl_acc3 sa = {0, 0, 0}, sb = {0, 0, 0};
-    const u32 *k6 = a.apow;
+    gl_ktab *k6 = (gl_ktab *)a.apow;
     u32 terms = 0;
     for (int m = 0; m < 4; m++) {
         const u64 *mat = a.mats[m] + p;
@@ -509,8 +534,8 @@ __global__ void __launch_bounds__(P2_THREADS) p2_fri_combine_kernel(p2_fri_combi
     gl_acc3 ta = {0, 0, 0}, tb = {0, 0, 0};
     for (u32 j = 0; j < a.nch; j++) {
         u64 v = a.mats[2][(size_t)j * N + p];
-        gl_acc3_mul(ta, v, a.apow + 12 * (size_t)j);
-        gl_acc3_mul(tb, v, a.apow + 12 * (size_t)j + 6);
+        gl_acc3_mul(ta, v, (gl_ktab *)a.apow + 12 * (size_t)j);
+        gl_acc3_mul(tb, v, (gl_ktab *)a.apow + 12 * (size_t)j + 6);
     }
     gl2 acc1 = gl2_make(gl_acc3_reduce(ta), gl_acc3_reduce(tb));
     gl2 q0 = gl2_mul(gl2_sub(acc, a.y0), gl2_inv(gl2_sub(gl2_make(x, 0), a.zeta)));
