@@ -1015,7 +1015,7 @@ def main():
                                                     fold_and_closing_recursions=blk["approvals"], keys_stakes_and_its_hash=3, bn128_wrap=1),
                            "msm_2p22_melem_per_s": stages["msm"]["value"]},
                 "roofline": dict(mk["roofline"], kernel="gl_hash_leaves_kernel (+ Merkle levels, ~3 % of the permutations): Poseidon leaf "
-                                                        "hashing, ~45 % of the kernel time of a block proof", kernel_ms=mk["ms"],
+                                                        "hashing, ~50 % of the kernel time of a block proof", kernel_ms=mk["ms"],
                                  note="measured live by the `merkle` stage (HIP events on the launch stream): 2^20 leaves x 234 columns; "
                                       + mk["roofline"]["note"] + "; the binding resource is integer VALU issue, see `valu`"),
                 "final_proof_verified": blk["final_proof_verified"],
@@ -1029,7 +1029,7 @@ def main():
                     ach = lane_instr / (mk["ms"] * 1e-3) / 1e12
                     out["roofline"]["valu"] = {
                         "bound": "valu-int", "achieved": ach, "peak": VALU_INT_PEAK_TLOPS, "unit": "T lane-instr/s", "frac": ach / VALU_INT_PEAK_TLOPS,
-                        "instructions_per_permutation": lane_instr / ((1 << 20) * 31),
+                        "instructions_per_permutation": lane_instr / ((1 << 20) * 30),   # ceil(234 / 8) permutations per leaf
                         "note": "SQ_INSTS_VALU of the kernel (profiles/poseidon_pmc_latest.json) x 64 lanes / the live kernel time; peak = the "
                                 "measured issue rate of v_mad_u64_u32 / v_add_co / v_addc (profiles/r02_valu_ubench.txt); fast-class "
                                 "instructions (v_mov, v_add_u32) issue ~1.7x faster, so the fraction can exceed 1"}
