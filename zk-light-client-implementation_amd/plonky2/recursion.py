@@ -888,6 +888,20 @@ class RecursiveCircuit:
                 self._wbuf = np.zeros(shape, dtype=np.uint64)
         return self._wbuf
 
+    def device_witness_state(self, ctx):
+        """(DeviceWitness, zero-initialised wire matrix in HBM) of this circuit on `ctx`, created on first use"""
+        if getattr(self, "_dw", None) is None:
+            import torch
+            self._dw = self.data.device_witness(ctx)
+            self._dbuf = torch.zeros((1, self.data.config["num_wires"], self.data.n), dtype=torch.int64, device="cuda:%d" % ctx.device_id)
+            torch.cuda.synchronize(ctx.device_id)      # the fill ran on torch's stream, the kernels run on the context's
+        return self._dw, self._dbuf
+
+    def close_device_witness(self):
+        if getattr(self, "_dw", None) is not None:
+            self._dw.close()
+            self._dw = self._dbuf = None
+
     def input_vector(self, inner_proofs, public_inputs):
         """inner_proofs: [(verifier_only_json, proof bytes or proof json)]"""
         import numpy as np
@@ -916,8 +930,12 @@ class RecursionProver:
     circuits' common data and the number of public inputs, so it is built and uploaded once per distinct shape and reused:
     a fold (prove_block_data/signatures.rs:97-105) settles on two shapes plus the closing one."""
 
-    def __init__(self, ctx, hasher=0, threads=None, inner_hasher=0):
+    def __init__(self, ctx, hasher=0, threads=None, inner_hasher=0, device_witness=True):
+        """device_witness: the generators of the recursion circuit run on the GPU (csrc/plonky2_witness_dev.hip: ~150 dependence
+        levels, one launch) and the proof is made from the matrix in HBM -- on the serial fold chain of `prove_approvals`
+        (signatures.rs:97-105) the witness of a step was its longest part (20-37 ms on one host thread).  False: host interpreter."""
         self.ctx, self.hasher, self.threads, self.inner_hasher = ctx, hasher, threads, inner_hasher
+        self.device_witness = device_witness
         assert inner_hasher == 0, "the in-circuit verifier handles Poseidon-Goldilocks inner proofs"
         self._cache = {}
 
@@ -948,14 +966,22 @@ class RecursionProver:
         t0 = time.perf_counter()
         vals = rc.input_vector([(v, p) for _, v, p in inners], pis)
         t1 = time.perf_counter()
-        wires, wpis = rc.data.generate_witness_native(None, out=rc.wire_buffer(), threads=1, input_values=vals[None, :])
-        t2 = time.perf_counter()
-        out = rc.prover.prove_host_ptr(wires.ctypes.data, [int(x) for x in wpis[0]])
+        if self.device_witness:
+            dw, dbuf = rc.device_witness_state(self.ctx)
+            st = self.ctx.stream_ptr()
+            wpis = dw.run(dbuf.data_ptr(), input_values=vals[None, :], stream=st)
+            t2 = time.perf_counter()
+            out = rc.prover.prove_dev(dbuf.data_ptr(), [int(x) for x in wpis[0]], stream=st)
+        else:
+            wires, wpis = rc.data.generate_witness_native(None, out=rc.wire_buffer(), threads=1, input_values=vals[None, :])
+            t2 = time.perf_counter()
+            out = rc.prover.prove_host_ptr(wires.ctypes.data, [int(x) for x in wpis[0]])
         t3 = time.perf_counter()
         self.last_host_ms = {"inputs": (t1 - t0) * 1e3, "witness": (t2 - t1) * 1e3, "prove": (t3 - t2) * 1e3}
         return rc, (out if raw else S.proof_from_bytes(out, rc.common, self.hasher))
 
     def close(self):
         for rc in self._cache.values():
+            rc.close_device_witness()
             rc.prover.close()
         self._cache = {}
