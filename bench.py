@@ -441,8 +441,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     # (bin/prove_block.rs:279-287).  All of them live on the fold thread's own context (= HIP stream).
     nthreads = max(2, args.prove_streams)
     fold_ctx = zklc_amd.Context(torch.cuda.current_device(), high_priority=True)
-    dwr = not args.host_witness        # recursion witnesses on the GPU as well
-    rp, rpw = RecursionProver(fold_ctx, HASH_GL, device_witness=dwr), RecursionProver(fold_ctx, HASH_BN128, device_witness=dwr)
+    rp, rpw = RecursionProver(fold_ctx, HASH_GL), RecursionProver(fold_ctx, HASH_BN128)
     ed3 = [(ed_common, ed_vd, p_) for p_ in c1_proofs]
     shapes_t = {}
 
@@ -578,9 +577,9 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     ks_ctx = zklc_amd.Context(torch.cuda.current_device())
     ks_prover = KeysStakesProver(ks_ctx)          # keys / stakes needs only valid_keys: its own thread + stream from the start
     dag_ctx = zklc_amd.Context(torch.cuda.current_device(), high_priority=True)
-    stub = PipelinedApprovals(RecursionProver(dag_ctx, HASH_GL, device_witness=not args.host_witness))
+    stub = PipelinedApprovals(RecursionProver(dag_ctx, HASH_GL))
     bprover = BlockProver(dag_ctx, stub)
-    rpw_block = RecursionProver(dag_ctx, HASH_BN128, device_witness=not args.host_witness)
+    rpw_block = RecursionProver(dag_ctx, HASH_BN128)
     lock = threading.Lock()
     st = {}
 

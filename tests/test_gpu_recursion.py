@@ -48,6 +48,14 @@ def test_recursive_proof_valid_fold_wrap_and_invalid(zctx):
     # a recursion proof does not verify under the verifier data of another circuit
     with pytest.raises(AssertionError):
         rp.recursive_proof((rc1.common, rc2.verifier_only, p1))
+    # the opt-in device interpreter for the recursion circuit's witness: the same proof bytes from the matrix in HBM
+    rpd = RecursionProver(zctx, HASH_GL, device_witness=True)
+    rc2d, p2d = rpd.recursive_proof((rc1.common, rc1.verifier_only, p1), (common, vd, proof), raw=True)
+    _, p2h = rp.recursive_proof((rc1.common, rc1.verifier_only, p1), (common, vd, proof), raw=True)
+    assert bytes(p2d) == bytes(p2h)
+    with pytest.raises(AssertionError):
+        rpd.recursive_proof((common, vd, bad))
+    rpd.close()
     inner.close()
     rp.close()
     wrap.close()

@@ -930,10 +930,13 @@ class RecursionProver:
     circuits' common data and the number of public inputs, so it is built and uploaded once per distinct shape and reused:
     a fold (prove_block_data/signatures.rs:97-105) settles on two shapes plus the closing one."""
 
-    def __init__(self, ctx, hasher=0, threads=None, inner_hasher=0, device_witness=True):
-        """device_witness: the generators of the recursion circuit run on the GPU (csrc/plonky2_witness_dev.hip: ~150 dependence
-        levels, one launch) and the proof is made from the matrix in HBM -- on the serial fold chain of `prove_approvals`
-        (signatures.rs:97-105) the witness of a step was its longest part (20-37 ms on one host thread).  False: host interpreter."""
+    def __init__(self, ctx, hasher=0, threads=None, inner_hasher=0, device_witness=False):
+        """device_witness=True: the generators of the recursion circuit run on the GPU (csrc/plonky2_witness_dev.hip: ~12 k coarse
+        instructions in ~150 dependence levels, one single-workgroup launch) and the proof is made from the matrix in HBM.
+        Measured inside a block proof (profiles/r02_bench_block_v4_recursion_witness_on_gpu.json) this is SLOWER than the host
+        interpreter -- 45 ms against 37 ms per fold step: one witness has no parallelism to offer and its launch queues behind
+        the signature proofs' kernels -- so the default stays the host interpreter; the batch form (64 signatures) is where the
+        device interpreter pays."""
         self.ctx, self.hasher, self.threads, self.inner_hasher = ctx, hasher, threads, inner_hasher
         self.device_witness = device_witness
         assert inner_hasher == 0, "the in-circuit verifier handles Poseidon-Goldilocks inner proofs"

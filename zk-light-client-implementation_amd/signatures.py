@@ -101,7 +101,7 @@ class ApprovalProver:
         self.device_witness, self.witness_batch = device_witness, max(1, min(64, witness_batch))
         self._dwit, self._dbuf = {}, None
         self._ed = {}                       # message length in bits -> (CircuitData, targets, Prover, verifier_only)
-        self.recursion = RecursionProver(ctx, HASH_GL, threads=witness_threads, device_witness=device_witness)
+        self.recursion = RecursionProver(ctx, HASH_GL, threads=witness_threads)
 
     def ed25519_circuit(self, msg_len_bytes, example=None):
         """get_ed25519_circuit_targets (ed25519.rs:18-42): build once per message length"""
