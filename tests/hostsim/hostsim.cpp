@@ -98,6 +98,18 @@ u64 hostsim_gl_acc(const u64 *x, const u64 *y, u32 n) {
     for (u32 i = 0; i < n; i++) gl_acc_mul(acc, x[i], y[i]);
     return gl_acc_reduce(acc);
 }
+// sum_i x[i] * k[i] through the carry-free three-column accumulator and the 22-bit limb table (gl_acc3 / gl_limbs22): the
+// accumulation of the quotient kernels' p2_consumer and of p2_fri_combine_kernel; `fold_every` terms between normalisations
+u64 hostsim_gl_acc3(const u64 *x, const u64 *k, u32 n, u32 fold_every) {
+    gl_acc3 acc = {0, 0, 0};
+    u32 t6[6];
+    for (u32 i = 0; i < n; i++) {
+        if (fold_every && i && i % fold_every == 0) gl_acc3_normalize(acc);
+        gl_limbs22(k[i], t6);
+        gl_acc3_mul(acc, x[i], (const u32 *)t6);
+    }
+    return gl_acc3_reduce(acc);
+}
 void hostsim_poseidon_gl_permute(u64 *s) { poseidon_gl_permute(s); }
 void hostsim_poseidon_gl_hash(const u64 *in, u32 len, u64 *out4) { poseidon_gl_hash_or_noop(in, 1, len, out4); }
 void hostsim_poseidon_gl_two_to_one(const u64 *l, const u64 *r, u64 *out4) { poseidon_gl_two_to_one(l, r, out4); }

@@ -86,6 +86,16 @@ def test_loose_arithmetic_edges(hostsim):
             y = np.array([M - 1 if k % 2 else P - 1 for k in range(n)], dtype=np.uint64)
             want = sum(int(a) * int(b) for a, b in zip(x, y)) % P
             assert hostsim.hostsim_gl_acc(x.ctypes.data, y.ctypes.data, n) == want
+    # the carry-free three-column accumulator over 22-bit limb tables (quotient constraints, FRI combine): extreme and random
+    # operands, column capacity (511 terms of maximal products without a fold) and the fold-and-restart path
+    hostsim.hostsim_gl_acc3.restype = ctypes.c_uint64
+    hostsim.hostsim_gl_acc3.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+    for n, fold in [(1, 0), (3, 0), (357, 0), (511, 0), (2000, 480), (2000, 384), (1000, 1)]:
+        for xs, ks in (([M - 1] * n, [P - 1] * n), ([M - 1] * n, [(1 << 44) - 1 | ((1 << 20) - 1) << 44] * n),
+                       ([rng.randrange(M) for _ in range(n)], [rng.randrange(P) for _ in range(n)])):
+            x, k = np.array(xs, dtype=np.uint64), np.array(ks, dtype=np.uint64)
+            want = sum(int(a) * int(b) for a, b in zip(xs, ks)) % P
+            assert hostsim.hostsim_gl_acc3(x.ctypes.data, k.ctypes.data, n, fold) == want, (n, fold)
 
 
 def test_poseidon_asm_generator_selftest_and_committed_file_is_current():
