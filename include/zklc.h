@@ -246,7 +246,8 @@ int32_t zklc_plonky2_witness_run_dev(zklc_ctx *ctx, void *stream, zklc_witness_p
  * called from `groth16.Prove` at gnark-plonky2-verifier/cmd/web-api.go:77.
  * points: n affine points in gnark-crypto's memory layout = x then y, each 4 little-endian
  * u64 limbs in Montgomery form (x * 2^256 mod p); (0, 0) is the point at infinity.
- * scalars: n x 4 little-endian u64, REGULAR (non-Montgomery) form, reduced (< r).
+ * scalars: n x 4 little-endian u64, REGULAR (non-Montgomery) form; expected reduced (< r) -- a scalar >= r is reduced by the
+ * kernel (the points have order r), it is not an error.
  * out_affine: 8 u64 in the same layout, canonical; *out_is_infinity = 1 when the sum is
  * the point at infinity (then out_affine is zero).  Pointers must be 16-byte aligned. */
 int32_t zklc_bn254_g1_msm(zklc_ctx *ctx, const uint64_t *points, const uint64_t *scalars, uint64_t n, uint64_t *out_affine,

@@ -31,6 +31,18 @@ def test_tiny_against_python(zctx):
     assert not inf and unwords(out) == want
 
 
+def test_scalars_that_are_not_reduced(zctx):
+    """a scalar >= r (anything up to 2^256 - 1) is reduced by the kernel instead of losing its top bits (G1 and G2)"""
+    scalars = [bn.R, bn.R + 1, 2**256 - 1, 5 * bn.R + 12345, 2**255 + 2**254 + 3, bn.R - 1]
+    pts = cport.bn254_gen_points(len(scalars), 7, 11)
+    sc = np.array([scalar_words(s) for s in scalars], dtype=np.uint64)
+    out, inf = zctx.bn254_g1_msm(pts, sc)
+    want = bn.msm([s % bn.R for s in scalars], [bn.mul(7 + 11 * i, bn.G1) for i in range(len(scalars))])
+    assert not inf and unwords(out) == want
+    out, inf = zctx.bn254_g1_msm(pts[:1], sc[:1])        # r * P = infinity
+    assert inf and not out.any()
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 1000, 5000, 40000])
 def test_uniform_scalars(zctx, n):
     rng = np.random.default_rng(n)

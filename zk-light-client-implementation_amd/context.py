@@ -234,7 +234,12 @@ class Context:
         return out, bool(inf.value)
 
     def bn254_pairing_check(self, g1, g2, k, want_gt=False):
-        """g1: uint64 [batch, k, 8], g2: uint64 [batch, k, 16] (gnark Montgomery affine) -> (is_one uint32[batch], gt uint64[batch, 48])"""
+        """g1: uint64 [batch, k, 8], g2: uint64 [batch, k, 16] (gnark Montgomery affine) -> (is_one uint32[batch], gt uint64[batch, 48]).
+        PRECONDITION (include/zklc.h): the kernel checks neither that the points are on the curve nor that the G2 points lie in
+        the r-torsion subgroup, and an all-zero encoding is the point at infinity -- like gnark-crypto's `PairingCheck`, whose
+        callers (`groth16.Verify`) validate the proof's points when they are decoded.  A verifier built on this call must do the
+        same (`zklc_amd.formats.decompress_proof` / `oracle.bn254` have the curve and subgroup checks) or it accepts invalid-curve
+        and small-subgroup points."""
         a = np.ascontiguousarray(g1, dtype=np.uint64).reshape(-1, k, 8)
         b = np.ascontiguousarray(g2, dtype=np.uint64).reshape(-1, k, 16)
         batch = a.shape[0]

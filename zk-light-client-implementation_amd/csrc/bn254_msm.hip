@@ -36,6 +36,26 @@ ZKLC_D void msm_load_scalar(const u64 *scalars, u32 i, u32 *w) {
     ulonglong2 a = p[0], b = p[1];
     w[0] = (u32)a.x; w[1] = (u32)(a.x >> 32); w[2] = (u32)a.y; w[3] = (u32)(a.y >> 32);
     w[4] = (u32)b.x; w[5] = (u32)(b.x >> 32); w[6] = (u32)b.y; w[7] = (u32)(b.y >> 32);
+    // the window recoding covers 254 bits: a scalar that is not reduced (>= r, anything up to 2^256 - 1) is reduced here -- the
+    // points have order r, so the sum is the same -- instead of silently losing its top bits.  Reduced scalars leave at the
+    // first comparison of the top word.
+    const u32 R[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+#pragma unroll 1
+    for (int it = 0; it < 6; it++) {       // 2^256 / r < 6
+        bool ge = true;
+        for (int k = 7; k >= 0; k--)
+            if (w[k] != R[k]) {
+                ge = w[k] > R[k];
+                break;
+            }
+        if (!ge) break;
+        u64 borrow = 0;
+        for (int k = 0; k < 8; k++) {
+            u64 d = (u64)w[k] - R[k] - borrow;
+            w[k] = (u32)d;
+            borrow = (d >> 32) & 1;
+        }
+    }
 }
 
 // signed digit of window w given the running carry (updated): digit in [-(2^(c-1) - 1), 2^(c-1)]

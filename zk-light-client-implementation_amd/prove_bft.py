@@ -58,7 +58,8 @@ class BlockProver:
 
     # ---- block_finality.rs:30-96
     def prove_consecutive_heights_proofs(self, proofs):
-        assert len(proofs) >= 3
+        if len(proofs) < 3:
+            raise ValueError("prove_consecutive_heights_proofs needs at least three header proofs")
         h = [pi_bytes(p, 32, 40) for p in proofs]
         p1 = self.prims.prove_consecutive_heights(h[0], h[1])
         p2 = self.prims.prove_consecutive_heights(h[1], h[2])
@@ -95,7 +96,8 @@ class BlockProver:
         import hashlib
         cur_hash = pi_bytes(current_block_header_proof, 0, 32)
         cur_epoch_id = pi_bytes(current_block_header_proof, 40, 72)
-        assert 3 <= len(proofs) <= 4
+        if not 3 <= len(proofs) <= 4:
+            raise ValueError("prove_block_finality takes 3 or 4 header proofs, got %d" % len(proofs))
         ks = None
         ks_elsewhere = msg_to_sign is not None and hasattr(self.approvals, "keys_stakes_early")   # proven by another thread
         if msg_to_sign is not None and not ks_elsewhere and hasattr(self.approvals, "valid_keys_early"):
@@ -134,8 +136,8 @@ class BlockProver:
             if ks is None:
                 ks = self._timed("prove_valid_keys_stakes", self.keys.prove_valid_keys_stakes_in_validators_list, valid_keys,
                                  pi_bytes(sig, 0), validators)
-            else:
-                assert pi_bytes(sig, 0) == hashlib.sha256(valid_keys).digest()
+            elif pi_bytes(sig, 0) != hashlib.sha256(valid_keys).digest():
+                raise ValueError("the signature aggregate does not carry sha256(valid_keys) of the approvals it was given")
             aggregation = self._rec(self._rec(sig, ks, ks[2]["public_inputs"]), agg, agg[2]["public_inputs"])
         aggregation = self._rec(aggregation, tail, aggregation[2]["public_inputs"])
         pis = current_block_header_proof[2]["public_inputs"] + aggregation[2]["public_inputs"]

@@ -148,17 +148,27 @@ class ApprovalProver:
                 out.append((common, vd, prover.prove_bytes(wires[k], [int(x) for x in pis[k]])))
         return out
 
+    def _precheck(self, msg, approvals, validators):
+        """the batched pre-check of one approval set, once: `valid_keys_early` and `prove_approvals` of the same block share it
+        (one launch and one slicing instead of two and three)"""
+        key = (bytes(msg), id(approvals), id(validators), len(approvals))
+        if getattr(self, "_pre", (None,))[0] != key:
+            valid_keys, valid_pos, _, _ = verify_approvals(self.ctx, msg, approvals, validators, strict=True)
+            _, pks, sigs = slice_approvals(approvals, validators)
+            self._pre = (key, valid_keys, valid_pos, pks, sigs)
+        return self._pre[1:]
+
     def valid_keys_early(self, msg, approvals, validators):
         """the `valid_keys` bytes prove_approvals will return: they only need the batched pre-check"""
-        return verify_approvals(self.ctx, msg, approvals, validators, strict=True)[0]
+        return self._precheck(msg, approvals, validators)[0]
 
     def prove_approvals(self, msg, approvals, validators):
         """-> ((RecursiveCircuit, proof), valid_keys); raises InvalidSignature like the reference's panic (:119-121)"""
         import hashlib
-        valid_keys, valid_pos, _, _ = verify_approvals(self.ctx, msg, approvals, validators, strict=True)
+        valid_keys, valid_pos, pks, sigs = self._precheck(msg, approvals, validators)
+        self._pre = (None,)                                   # one block's worth: the lists may be mutated or reused afterwards
         if not valid_pos:
             raise ValueError("no approvals present")         # the reference indexes agg_data_proof[0] (:131) and panics
-        _, pks, sigs = slice_approvals(approvals, validators)
         proofs = self.ed25519_proofs(msg, [s.tobytes() for s in sigs], [p.tobytes() for p in pks])
         agg = proofs[0]
         for nxt in proofs[1:]:        # proofs travel as `to_bytes` bytes between the steps (signatures.rs:225-230)
