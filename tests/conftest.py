@@ -87,3 +87,25 @@ def zctx():
     ctx = zklc_amd.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def approval_prover(zctx):
+    """ApprovalProver with the reference's per-signature circuit (2^18 rows x 234 wires) built ONCE for the session: its
+    construction and the compilation of its generator program are ~40 s of host Python, and four test modules prove with it"""
+    from zklc_amd.signatures import ApprovalProver
+    ap = ApprovalProver(zctx)
+    ap.ed25519_circuit(41)
+    yield ap
+    ap.close()
+
+
+@pytest.fixture(scope="session")
+def block_prover(zctx, approval_prover):
+    """BlockProver over the session's ApprovalProver: the SHA-256 and recursion circuits of the header chains and of the joins are
+    built by the first block proof of the session and reused by the others (5-block window, 6-block epoch branch)"""
+    from zklc_amd.prove_bft import BlockProver
+    bp = BlockProver(zctx, approval_prover)
+    yield bp
+    bp.hashes.sha.close()       # the recursion prover and the Ed25519 circuit belong to `approval_prover`, closed by its fixture
+    bp.prims.close()

@@ -13,10 +13,8 @@ from oracle import plonky2_verifier as V
 pytestmark = pytest.mark.gpu
 
 
-def test_epoch_blocks_proof_on_the_gpu(zctx):
+def test_epoch_blocks_proof_on_the_gpu(zctx, block_prover):
     import time
-    from zklc_amd.prove_bft import BlockProver
-    from zklc_amd.signatures import ApprovalProver
     w = load_golden("block_window_epoch_CRTZ.json")
     hx = bytes.fromhex
     blocks = []
@@ -25,14 +23,14 @@ def test_epoch_blocks_proof_on_the_gpu(zctx):
         f["height"] = blk["height"]
         f["approvals"] = [hx(a) for a in blk["approvals"]]
         blocks.append((f, hx(blk["bytes"])))
-    ap = ApprovalProver(zctx, witness_batch=16)
-    bp = BlockProver(zctx, ap)
+    bp = block_prover
+    bp.counts, bp.seconds = {}, {}
     t0 = time.time()
     b0, bn_1 = bp.prove_block_bft(hx(w["ep2_last_block"]["bytes"]), hx(w["ep2_last_block"]["hash"]), hx(w["ep1_first_block"]["bytes"]),
                                   hx(w["ep1_first_block"]["hash"]), blocks, [hx(v) for v in w["validators"]],
                                   ep3_last_block_bytes=hx(w["ep3_last_block"]["bytes"]), ep3_last_block_hash=hx(w["ep3_last_block"]["hash"]),
                                   validators_n_1=[hx(v) for v in w["validators_n_1"]])
-    print("epoch blocks: %.1f s (first call, circuits built in Python); counts %s" % (time.time() - t0, bp.counts))
+    print("epoch blocks: %.1f s (circuits of the shapes not seen earlier in the session are built in Python); counts %s" % (time.time() - t0, bp.counts))
     for proof in (b0, bn_1):
         V.verify(json.loads(json.dumps(proof[2])), proof[1], proof[0])
     assert b0[2]["public_inputs"] == [1] + list(hx(w["blocks"][4]["hash"])) + list(hx(w["ep2_last_block"]["hash"])) + \
@@ -40,4 +38,3 @@ def test_epoch_blocks_proof_on_the_gpu(zctx):
     assert bn_1[2]["public_inputs"] == [1] + list(hx(w["blocks"][5]["hash"])) + list(hx(w["ep3_last_block"]["hash"])) + \
         list(hx(w["ep2_last_block"]["hash"]))
     assert bp.counts["prove_header_hash"] == 9 and bp.counts["prove_approvals"] == 2
-    bp.close()

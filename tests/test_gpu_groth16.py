@@ -14,10 +14,10 @@ pytestmark = pytest.mark.gpu
 
 
 def test_groth16_prove_on_the_gpu_equals_the_oracle_and_verifies(zctx):
-    n_con, n_pub = 200, 3
+    n_con, n_pub = 100, 3
     r1cs, wit = G.square_chain_r1cs(n_con, n_public=n_pub)
     pk, vk = G.setup(r1cs, n_pub, (0x1234567891, 0xabcdef12345, 0x777766665555, 0x3133731337, 0x42424242))
-    assert pk["n"] == 256
+    assert pk["n"] == 128
     prover = Groth16Prover(zctx, pk)
     for seed, (r, s) in enumerate([(0x1111222233334444, 0x5555666677778888), (G.R - 2, 3)]):
         pubs = [11 + seed, 22, 33]
@@ -26,7 +26,7 @@ def test_groth16_prove_on_the_gpu_equals_the_oracle_and_verifies(zctx):
         got = prover.prove(w, abc, r, s)
         want = G.proof_to_uint256x8(G.prove(pk, r1cs, w, r, s))
         assert got == want, "GPU Groth16 proof differs from the oracle prover"
-        print("groth16 prove (n = 256): ms", prover.last_ms)
+        print("groth16 prove (n = 128): ms", prover.last_ms)
         assert G.verify(vk, ((got[0], got[1]), ((got[3], got[2]), (got[5], got[4])), (got[6], got[7])), pubs)
         # the verification equation on the GPU pairing kernel: e(A, B) e(C, -delta) e(alpha, -beta) e(L, -gamma) = 1
         l = vk["K"][0]

@@ -148,16 +148,6 @@ def test_reference_sha512_circuit_proof(zctx):
     print("sha512 circuit: 2^14 rows, proof stages", prover.last_timings())
 
 
-@pytest.fixture(scope="module")
-def approval_prover(zctx):
-    """ApprovalProver with the reference's per-signature circuit built once for the module (a few minutes of host Python)"""
-    from zklc_amd.signatures import ApprovalProver
-    ap = ApprovalProver(zctx)
-    ap.ed25519_circuit(41)
-    yield ap
-    ap.close()
-
-
 def test_reference_ed25519_circuit_proof_of_a_near_mainnet_signature(zctx, approval_prover):
     """the reference's per-signature circuit (crypto/plonky2_ed25519/src/gadgets/eddsa.rs:34-85, restated in
     zklc_amd/plonky2/ed25519_circuit.py: SHA-512 + two point decompressions + windowed [h]A + fixed-base [s]B over
@@ -175,7 +165,8 @@ def test_reference_ed25519_circuit_proof_of_a_near_mainnet_signature(zctx, appro
     import os
     import time
     # native witness generation (csrc/plonky2_witness.cpp): all three signatures of the fixture
-    data.witness_program(E.fill_ecdsa_targets(targets, msg, sig, pk))
+    if data._program is None:
+        data.witness_program(E.fill_ecdsa_targets(targets, msg, sig, pk))
     sigs = [(bytes.fromhex(x["approval"])[2:], bytes.fromhex(x["validator_tail"])[1:33]) for x in j["entries"]]
     t0 = time.time()
     wn, pn = data.generate_witness_native([E.fill_ecdsa_targets(targets, msg, s_, p_) for s_, p_ in sigs])
@@ -242,7 +233,7 @@ def test_prove_approvals_on_the_reference_small_fixture(zctx, approval_prover):
     wrap.close()
 
 
-def test_full_block_proof_on_a_mainnet_window(zctx, approval_prover):
+def test_full_block_proof_on_a_mainnet_window(zctx, block_prover):
     """`prove_block_bft` (near_bft_finality/src/prove_bft/bft.rs:38-500, the path of bin/prove_random.rs) on the reference's own
     data set -- NEAR mainnet blocks 121798939..43 of epoch HPi5.., its 100 block producers, Block_0 of the previous epoch and the
     last block of the one before (tests/golden/block_window_HPi5.json: borsh bytes rebuilt from the JSON views and pinned by the
@@ -261,7 +252,8 @@ def test_full_block_proof_on_a_mainnet_window(zctx, approval_prover):
         f["approvals"] = [hx(a) for a in blk["approvals"]]
         blocks.append((f, hx(blk["bytes"])))
     validators = [hx(v) for v in w["validators"]]
-    bp = BlockProver(zctx, approval_prover)
+    bp = block_prover
+    bp.counts, bp.seconds = {}, {}
     t0 = time.time()
     bi, none = bp.prove_block_bft(hx(w["ep2_last_block"]["bytes"]), hx(w["ep2_last_block"]["hash"]), hx(w["ep1_first_block"]["bytes"]),
                                   hx(w["ep1_first_block"]["hash"]), blocks, validators)
@@ -275,8 +267,6 @@ def test_full_block_proof_on_a_mainnet_window(zctx, approval_prover):
           % (len(bp.hashes.sha._circuits), dt, n_present, bp.counts, {k: round(v, 1) for k, v in bp.seconds.items()}))
     import os
     if not os.environ.get("ZKLC_SLOW_TESTS"):
-        bp.hashes.sha.close()
-        bp.prims.close()
         return
     # second call: every circuit except the keys / stakes one is resident
     bp.counts, bp.seconds = {}, {}
@@ -286,5 +276,3 @@ def test_full_block_proof_on_a_mainnet_window(zctx, approval_prover):
     assert bi2[2] == bi[2]
     print("full Block_i proof, circuits resident, sequential host driver: %.1f s; seconds %s"
           % (time.time() - t0, {k: round(v, 1) for k, v in bp.seconds.items()}))
-    bp.hashes.sha.close()
-    bp.prims.close()

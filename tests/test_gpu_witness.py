@@ -76,7 +76,7 @@ def test_device_witness_equals_host_interpreter_on_the_nonnative_gadgets(zctx):
     dw.close()
 
 
-def test_device_witness_of_the_reference_ed25519_circuit_and_proof_from_hbm(zctx):
+def test_device_witness_of_the_reference_ed25519_circuit_and_proof_from_hbm(zctx, approval_prover):
     """the reference's per-signature circuit (crypto/plonky2_ed25519/src/gadgets/eddsa.rs:34-85; 1.13 M generators, 2^18 x 234
     wires): the three real NEAR approval signatures of the C1 fixture, witnesses generated on the GPU == the host interpreter's,
     the proof is made from the matrix in HBM (zklc_plonky2_prove_dev) and accepted by the verifier restatement; a corrupted
@@ -85,12 +85,11 @@ def test_device_witness_of_the_reference_ed25519_circuit_and_proof_from_hbm(zctx
     from zklc_amd.plonky2 import ed25519_circuit as E, sha512
     j = load_golden("ed25519_near_c1_small.json")
     msg = bytes.fromhex(j["msg"])
-    b = CircuitBuilder(wide_ecc_config())
-    targets = E.ed25519_circuit(b, 8 * len(msg))
-    data = b.build()
+    data, targets, prover, _ = approval_prover.ed25519_circuit(len(msg))       # the session's circuit and its GPU prover
     sigs = [(bytes.fromhex(x["approval"])[2:], bytes.fromhex(x["validator_tail"])[1:33]) for x in j["entries"]]
     fills = [E.fill_ecdsa_targets(targets, msg, s_, p_) for s_, p_ in sigs]
-    data.witness_program(fills[0])
+    if data._program is None:
+        data.witness_program(fills[0])
     wn, pn = data.generate_witness_native(fills)
     dw = data.device_witness(zctx)
     print("Ed25519 circuit witness program on the device:", dw.info(len(fills)))
@@ -104,7 +103,6 @@ def test_device_witness_of_the_reference_ed25519_circuit_and_proof_from_hbm(zctx
         assert np.array_equal(got[k], wn[k]), "signature %d" % k
     assert torch.equal(d, d2)
     assert [int(x) for x in pis[0]] == sha512.array_to_bits(msg) + sha512.array_to_bits(sigs[0][1])
-    prover = data.prover(zctx, HASH_GL)
     from zklc_amd.plonky2 import serialization as S
     raw = prover.prove_dev(d[1].data_ptr(), [int(x) for x in pis[1]])
     V.verify(json.loads(json.dumps(S.proof_from_bytes(raw, prover.common, HASH_GL))), prover.verifier_data(), data.common_data())
@@ -113,7 +111,6 @@ def test_device_witness_of_the_reference_ed25519_circuit_and_proof_from_hbm(zctx
     bad[40] ^= 1
     with pytest.raises(AssertionError):
         device_witness(dw, [E.fill_ecdsa_targets(targets, msg, bytes(bad), sigs[0][1])])
-    prover.close()
     dw.close()
 
 
