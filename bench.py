@@ -266,13 +266,30 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
             # (LDE of 234 columns 2^18 -> 2^21 + Merkle tree over 2^21 leaves), extrapolated from the two bounded samples above
             lde_s = 2 * alg / 1e9 / res["lde"]["cpu_baseline"]["value"]
             mk_s = 2 * N / 1e6 / res["merkle"]["cpu_baseline"]["value"]
-            gpu_ms = res["prove"]["ed25519_circuit_2p18x234"]["ms_per_proof"]
-            res["prove"]["ed25519_circuit_2p18x234"]["cpu_baseline"] = {
-                "value": 1.0 / (lde_s + mk_s), "unit": "proofs/s (upper bound)", "cores": threads, "kind": "port",
-                "sample": "wires commitment only (coset LDE %.1f s + Poseidon Merkle tree %.1f s, extrapolated from the lde / merkle "
-                          "samples above, oracle/c/goldilocks_oracle.c): a LOWER bound of the time of one CPU proof with this port; "
-                          "the reference's Rust prover cannot be built here" % (lde_s, mk_s),
-                "gpu_full_proof_vs_cpu_commit_only": (lde_s + mk_s) * 1e3 / gpu_ms}
+            try:
+                gpu_ms = res["prove"]["ed25519_circuit_2p18x234"]["ms_per_proof"]
+                fold = next((v["cpu_baseline"] for k, v in res["prove"].items()
+                             if k.startswith("recursion_fold_R(R,ed)") and isinstance(v, dict) and "cpu_baseline" in v), None)
+                ed_cb = {"cores": threads, "kind": "port",
+                         "measured": "the wires commitment of this shape: coset LDE %.1f s + Poseidon Merkle tree %.1f s, from the bounded lde / "
+                                     "merkle samples above (oracle/c/goldilocks_oracle.c)" % (lde_s, mk_s)}
+                if fold is not None:
+                    st = fold["stages_s"]
+                    ratio = st["proof"] / st["wires_commit"]
+                    ed_cb.update({"value": 1.0 / ((lde_s + mk_s) * ratio), "unit": "proofs/s (wires commitment measured, rest scaled)",
+                                  "scaled": "the other stages (Z / partial products, quotient, openings, FRI) by the ratio whole proof / wires "
+                                            "commitment = %.2f of the COMPLETE C proof measured at the fold shape; the u32 gates of this circuit "
+                                            "are not in the C prover" % ratio,
+                                  "sample": "wires commitment measured on bounded samples, other stages scaled from the complete CPU proof of the "
+                                            "fold shape", "seconds_per_proof": (lde_s + mk_s) * ratio})
+                else:
+                    ed_cb.update({"value": 1.0 / (lde_s + mk_s), "unit": "proofs/s (upper bound)",
+                                  "sample": "wires commitment only: a LOWER bound of the time of one CPU proof with this port",
+                                  "seconds_per_proof": lde_s + mk_s})
+                ed_cb["gpu_speedup"] = ed_cb["seconds_per_proof"] * 1e3 / gpu_ms
+                res["prove"]["ed25519_circuit_2p18x234"]["cpu_baseline"] = ed_cb
+            except Exception as e:      # a report, never a reason to lose the bench line
+                res["prove"]["ed25519_circuit_2p18x234"]["cpu_baseline_error"] = repr(e)[:300]
     if not args.no_bn254_extras:
         res["bn254_extras"] = run_bn254_extras(ctx, dev, reduce_max, barrier, world)
     return res
@@ -469,6 +486,24 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         out[key] = describe(rc.data, rc.prover, ms, "in-circuit verifier (recursive_proof) over real inner proofs")
         out[key]["host_ms_per_call"] = {k: round(v, 3) for k, v in host.items()}
         out[key]["host_python_untimed"] = {"first_call_s_circuit_build_upload_program": build_s}
+        if name == "fold_R(R,ed)" and rank == 0 and world == 1 and not args.no_cpu_baseline:
+            # the honest CPU number: ONE complete proof of this circuit (the step the fold repeats per signature) with the
+            # oracle's C + OpenMP prover on the host cores, same circuit, same witness; its bytes must be the GPU's
+            try:
+                from oracle import cport
+                threads_ = host_cores()
+                gpu_bytes = rc.prover.prove_bytes(wires, pis_)
+                cpu_bytes, secs = cport.plonky2_prove(rc.data, wires, pis_, nthreads=threads_)
+                out[key]["cpu_baseline"] = {
+                    "value": 1.0 / secs["proof"], "unit": "proofs/s", "cores": threads_, "kind": "port",
+                    "sample": "ONE complete proof of this circuit (wires commitment, Z / partial products, quotient with all 13 gate "
+                              "types, openings, FRI with proof of work and queries) with oracle/c/plonky2_prover_oracle.c, C + OpenMP, "
+                              "no SIMD intrinsics; circuit preprocessing (%.2f s) excluded as it is for the GPU" % secs["preprocess"],
+                    "stages_s": {k: round(v, 4) for k, v in secs.items() if k != "threads"},
+                    "proof_bytes_equal_gpu": cpu_bytes == gpu_bytes,
+                    "gpu_speedup": secs["proof"] * 1e3 / ms}
+            except Exception as e:      # the baseline is a report: it must not take the bench line down
+                out[key]["cpu_baseline_error"] = repr(e)[:300]
 
     # ---- 8(f).2: the other circuits of a block proof -- SHA-256 (prove_crypto/sha256.rs:62-83; header / bp_hash / valid_keys
     # hashes) and the keys / stakes circuit (prove_block_data/keys_stakes.rs:18-243) on the 100-validator fixture
@@ -1033,14 +1068,35 @@ def main():
                         "note": "SQ_INSTS_VALU of the kernel (profiles/poseidon_pmc_latest.json) x 64 lanes / the live kernel time; peak = the "
                                 "measured issue rate of v_mad_u64_u32 / v_add_co / v_addc (profiles/r02_valu_ubench.txt); fast-class "
                                 "instructions (v_mov, v_add_u32) issue ~1.7x faster, so the fraction can exceed 1"}
-            if "cpu_baseline" in edp:
-                cb = edp["cpu_baseline"]
-                out["cpu_baseline"] = {"value": cb["value"] / blk["approvals"], "unit": "proofs/s (upper bound)", "cores": cb["cores"],
-                                       "kind": "port",
-                                       "sample": "the wires commitment (coset LDE + Poseidon Merkle tree) of ONE of the %d Ed25519-circuit "
-                                                 "proofs of a block with oracle/c/goldilocks_oracle.c, from bounded samples (%s); a block "
-                                                 "needs at least %d times that on the CPU" % (blk["approvals"], cb["sample"][:60] + "...",
-                                                                                             blk["approvals"])}
+            try:
+                if "cpu_baseline" in edp:
+                    cb = edp["cpu_baseline"]
+                    fold = next((v["cpu_baseline"] for k, v in stages["prove"].items()
+                                 if k.startswith("recursion_fold_R(R,ed)") and isinstance(v, dict) and "cpu_baseline" in v), None)
+                    cnt = blk["dag_thread_counts"]      # a header-hash chain is 4 SHA-256 proofs + 5 recursions (header_bphash.py)
+                    n_small = (9 * cnt.get("prove_header_hash", 0) + cnt.get("prove_eq_array", 0) + cnt.get("recursive_proof", 0)
+                               + cnt.get("prove_bp_hash", 0) + blk["approvals"] + 3 + 1)
+                    if fold is not None:
+                        fold_s = 1.0 / fold["value"]
+                        block_s = blk["approvals"] * cb["seconds_per_proof"] + n_small * fold_s
+                        out["cpu_baseline"] = {
+                            "value": 1.0 / block_s, "unit": "proofs/s", "cores": cb["cores"], "kind": "port",
+                            "sample": "MEASURED: one complete CPU proof at the fold shape (oracle/c/plonky2_prover_oracle.c, C + OpenMP: %.2f s, "
+                                      "proof bytes equal to the GPU's: %s) and the wires commitment of the Ed25519 shape on bounded samples.  SCALED: "
+                                      "the other stages of the Ed25519-shape proof by the fold shape's stage ratio (%.1f s per proof); the block = %d "
+                                      "Ed25519-shape proofs + %d proofs of 2^12..2^14-row circuits, each counted at the measured fold-shape time.  The "
+                                      "reference's Rust prover cannot be built here; its only published time is 30 s per Groth16 proof "
+                                      "(gnark-plonky2-verifier/README.md:35-39)"
+                                      % (fold_s, fold.get("proof_bytes_equal_gpu"), cb["seconds_per_proof"], blk["approvals"], n_small),
+                            "seconds_per_block": block_s, "gpu_speedup": block_s / blk["seconds_per_block"]}
+                    else:
+                        out["cpu_baseline"] = {"value": cb["value"] / blk["approvals"], "unit": "proofs/s (upper bound)", "cores": cb["cores"],
+                                               "kind": "port",
+                                               "sample": "the wires commitment (coset LDE + Poseidon Merkle tree) of ONE of the %d Ed25519-circuit "
+                                                         "proofs of a block with oracle/c/goldilocks_oracle.c, from bounded samples; a block needs at "
+                                                         "least %d times that on the CPU" % (blk["approvals"], blk["approvals"])}
+            except Exception as e:
+                out["cpu_baseline"] = {"value": None, "error": repr(e)[:300]}
             del out["stages"]["prove"]["block_i"]
         print(json.dumps(out), flush=True)
     ctx.close()
