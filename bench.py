@@ -273,7 +273,11 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
                 ed_cb = {"cores": threads, "kind": "port",
                          "measured": "the wires commitment of this shape: coset LDE %.1f s + Poseidon Merkle tree %.1f s, from the bounded lde / "
                                      "merkle samples above (oracle/c/goldilocks_oracle.c)" % (lde_s, mk_s)}
-                if fold is not None:
+                meas = res["prove"]["ed25519_circuit_2p18x234"].get("cpu_baseline_measured")
+                if meas is not None:       # --cpu-baseline-ed25519: nothing scaled
+                    ed_cb.update(meas)
+                    ed_cb["measured"] = meas["sample"]
+                elif fold is not None:
                     st = fold["stages_s"]
                     ratio = st["proof"] / st["wires_commit"]
                     ed_cb.update({"value": 1.0 / ((lde_s + mk_s) * ratio), "unit": "proofs/s (wires commitment measured, rest scaled)",
@@ -450,6 +454,21 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     out[ed_name]["host_python_untimed"] = {"circuit_build_s": t1 - t0, "witness_program_compile_s": t2 - t1,
                                            "native_witness_s_per_signature": (t3 - t2) / len(fills), "native_witness_threads": len(fills)}
     c1_proofs = [ed_prover.prove_bytes(wn[k], [int(x) for x in pn[k]]) for k in range(len(fills))]
+    if args.cpu_baseline_ed25519 and rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # opt-in (1-3 minutes of host time, ~12 GB of host memory): ONE complete proof of the Ed25519 circuit on the host cores
+        try:
+            from oracle import cport
+            threads_ = host_cores()
+            cpu_bytes, secs = cport.plonky2_prove(ed_data, wn[0], [int(x) for x in pn[0]], nthreads=threads_)
+            out[ed_name]["cpu_baseline_measured"] = {
+                "value": 1.0 / secs["proof"], "unit": "proofs/s", "cores": threads_, "kind": "port", "seconds_per_proof": secs["proof"],
+                "sample": "ONE complete proof of the reference Ed25519 circuit (2^18 rows x 234 wires, 20 gate types, real NEAR "
+                          "signature) with oracle/c/plonky2_prover_oracle.c, C + OpenMP; circuit preprocessing (%.1f s) excluded"
+                          % secs["preprocess"],
+                "stages_s": {k: round(v, 3) for k, v in secs.items() if k != "threads"},
+                "proof_bytes_equal_gpu": cpu_bytes == c1_proofs[0]}
+        except Exception as e:
+            out[ed_name]["cpu_baseline_error"] = repr(e)[:300]
     del wn
 
     # ---- a7: `recursive_proof` (prove_crypto/recursion.rs:16-97).  The fold of signatures.rs:97-105 uses two circuit shapes --
@@ -909,6 +928,9 @@ def main():
     ap.add_argument("--verify-warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=8192, help="Block_i approval sets per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-ed25519", action="store_true",
+                    help="also time ONE complete CPU proof of the Ed25519 circuit with the oracle's C prover (minutes of host time); "
+                         "without it that shape's CPU time is the measured wires commitment, the other stages scaled")
     ap.add_argument("--no-stages", action="store_true", help="only the headline C2 measurement")
     ap.add_argument("--msm-log", type=int, default=22, help="log2 of the MSM size per GPU")
     ap.add_argument("--no-prove", action="store_true", help="skip the plonky2 proof stage")
@@ -1082,8 +1104,9 @@ def main():
                         out["cpu_baseline"] = {
                             "value": 1.0 / block_s, "unit": "proofs/s", "cores": cb["cores"], "kind": "port",
                             "sample": "MEASURED: one complete CPU proof at the fold shape (oracle/c/plonky2_prover_oracle.c, C + OpenMP: %.2f s, "
-                                      "proof bytes equal to the GPU's: %s) and the wires commitment of the Ed25519 shape on bounded samples.  SCALED: "
-                                      "the other stages of the Ed25519-shape proof by the fold shape's stage ratio (%.1f s per proof); the block = %d "
+                                      "proof bytes equal to the GPU's: %s) and the wires commitment of the Ed25519 shape on bounded samples.  SCALED "
+                                      "(unless --cpu-baseline-ed25519 measured the whole Ed25519-shape proof: stages.prove.ed25519_circuit_2p18x234."
+                                      "cpu_baseline says which): the other stages of that proof by the fold shape's stage ratio (%.1f s per proof); the block = %d "
                                       "Ed25519-shape proofs + %d proofs of 2^12..2^14-row circuits, each counted at the measured fold-shape time.  The "
                                       "reference's Rust prover cannot be built here; its only published time is 30 s per Groth16 proof "
                                       "(gnark-plonky2-verifier/README.md:35-39)"

@@ -9,9 +9,10 @@
  * `plonk/prover.rs` (`prove_with_partition_witness`), `plonk/vanishing_poly.rs`, `fri/oracle.rs`, `fri/prover.rs`,
  * `iop/challenger.rs`, `util/serialization.rs` -- in the order of operations of oracle/plonky2_prover.py, with the gate
  * evaluators of gnark-plonky2-verifier/plonk/gates/ (file:line list in oracle/plonky2_gates.py) for the gate set of the
- * reference's recursion circuits: Noop, Constant, PublicInput, Arithmetic, ArithmeticExtension, MulExtension, BaseSum,
- * Poseidon, PoseidonMds, RandomAccess, Reducing, ReducingExtension, Exponentiation, CosetInterpolation.  Circuits with other
- * gates (the u32 gates of the Ed25519 circuit) are refused: that shape is SCALED in the baseline, not measured.
+ * reference's recursion circuits -- Noop, Constant, PublicInput, Arithmetic, ArithmeticExtension, MulExtension, BaseSum,
+ * Poseidon, PoseidonMds, RandomAccess, Reducing, ReducingExtension, Exponentiation, CosetInterpolation -- and the in-tree gates
+ * of the Ed25519 / SHA circuits (crypto/plonky2_u32/src/gates: U32Arithmetic, U32AddMany, U32Subtraction, U32RangeCheck,
+ * Comparison, U32Interleave, UninterleaveToU32 / ToB32), i.e. every gate type of include/zklc.h.
  * PARITY against the Rust prover's bytes is UNPINNED like the Python restatement's (same deterministic choices: lowest
  * proof-of-work witness); every proof is accepted by oracle/plonky2_verifier.py, which the reference's golden proofs pin.
  *
@@ -276,7 +277,9 @@ typedef struct {
         num_public_inputs, hasher, num_gates, num_arities, arity_bits[8];
 } oparams;
 enum { G_NOOP = 0, G_CONSTANT, G_PUBLIC_INPUT, G_ARITHMETIC, G_ARITHMETIC_EXT, G_MUL_EXT, G_BASE_SUM, G_POSEIDON, G_POSEIDON_MDS,
-       G_RANDOM_ACCESS, G_REDUCING, G_REDUCING_EXT, G_EXPONENTIATION, G_COSET_INTERPOLATION };
+       G_RANDOM_ACCESS, G_REDUCING, G_REDUCING_EXT, G_EXPONENTIATION, G_COSET_INTERPOLATION,
+       G_U32_ARITHMETIC, G_U32_ADD_MANY, G_U32_SUBTRACTION, G_U32_RANGE_CHECK, G_COMPARISON,
+       G_U32_INTERLEAVE, G_UNINTERLEAVE_TO_U32, G_UNINTERLEAVE_TO_B32, G_NUM_TYPES };
 #define UNUSED_SELECTOR 0xFFFFFFFFULL
 
 /* ------------------------------------------------------------------------------------------------ gate evaluators (base field)
@@ -318,6 +321,12 @@ static u32 eval_poseidon(const u64 *w, u64 *out) {
     }
     for (int i = 0; i < 12; i++) *o++ = fsub(st[i], w[12 + i]);
     return (u32)(o - out);
+}
+
+static inline u64 range_product(u64 x, u32 base) {
+    u64 acc = 1;
+    for (u32 k = 0; k < base; k++) acc = fmul(acc, fsub(x, k));
+    return acc;
 }
 
 static void coset_partial(const u64 *w, const u64 *weights, const u64 *dom, u32 s, u32 e, e2 point, e2 *ev, e2 *prod) {
@@ -449,6 +458,131 @@ static int eval_gate(const ogate *g, const u64 *c, const u64 *w, const u64 *pih,
         o = put2(o, e2_sub(alg(w, start_val), ev));
         break;
     }
+    /* ---- the in-tree gates of the Ed25519 / SHA circuits (crypto/plonky2_u32/src/gates; list in oracle/plonky2_gates.py) */
+    case G_U32_ARITHMETIC: {
+        u32 n = g->p[0];
+        for (u32 i = 0; i < n; i++) {
+            const u64 *r = w + 6 * i, *l = w + 6 * n + 32 * i;
+            u64 m0 = r[0], m1 = r[1], add = r[2], lo = r[3], hi = r[4], inv = r[5];
+            u64 computed = fadd(fmul(m0, m1), add);
+            u64 hi_not_max = fsub(fmul(inv, fsub(0xFFFFFFFFULL, hi)), 1);
+            *o++ = fmul(hi_not_max, lo);
+            *o++ = fsub(fadd(fmul(hi, 1ULL << 32), lo), computed);
+            for (u32 j = 32; j-- > 0;) *o++ = range_product(l[j], 4);
+            u64 cl = 0, chh = 0;
+            for (u32 j = 16; j-- > 0;) cl = fadd(fmul(cl, 4), l[j]);
+            for (u32 j = 32; j-- > 16;) chh = fadd(fmul(chh, 4), l[j]);
+            *o++ = fsub(cl, lo);
+            *o++ = fsub(chh, hi);
+        }
+        break;
+    }
+    case G_U32_ADD_MANY: {
+        u32 na = g->p[0], n = g->p[1], per = na + 3;
+        for (u32 i = 0; i < n; i++) {
+            u64 comp = w[per * i + na];
+            for (u32 j = 0; j < na; j++) comp = fadd(comp, w[per * i + j]);
+            u64 res = w[per * i + na + 1], carry = w[per * i + na + 2];
+            *o++ = fsub(fadd(fmul(carry, 1ULL << 32), res), comp);
+            u64 cr = 0, cc = 0;
+            for (u32 j = 18; j-- > 0;) {
+                u64 l = w[per * n + 18 * i + j];
+                *o++ = range_product(l, 4);
+                if (j < 16) cr = fadd(fmul(cr, 4), l); else cc = fadd(fmul(cc, 4), l);
+            }
+            *o++ = fsub(cr, res);
+            *o++ = fsub(cc, carry);
+        }
+        break;
+    }
+    case G_U32_SUBTRACTION: {
+        u32 n = g->p[0];
+        for (u32 i = 0; i < n; i++) {
+            const u64 *r = w + 5 * i;
+            u64 x = r[0], y = r[1], bin = r[2], res = r[3], bout = r[4];
+            u64 initial = fsub(fsub(x, y), bin);
+            *o++ = fsub(res, fadd(initial, fmul(1ULL << 32, bout)));
+            u64 comb = 0;
+            for (u32 j = 16; j-- > 0;) {
+                u64 l = w[5 * n + 16 * i + j];
+                *o++ = range_product(l, 4);
+                comb = fadd(fmul(comb, 4), l);
+            }
+            *o++ = fsub(comb, res);
+            *o++ = fmul(bout, fsub(1, bout));
+        }
+        break;
+    }
+    case G_U32_RANGE_CHECK: {
+        u32 n = g->p[0];
+        for (u32 i = 0; i < n; i++) {
+            const u64 *aux = w + n + 16 * i;
+            u64 acc = 0;
+            for (u32 j = 16; j-- > 0;) acc = fadd(fmul(acc, 4), aux[j]);
+            *o++ = fsub(acc, w[i]);
+            for (u32 j = 0; j < 16; j++) *o++ = range_product(aux[j], 4);
+        }
+        break;
+    }
+    case G_COMPARISON: {
+        u32 nb = g->p[0], ncn = g->p[1], cb = (nb + ncn - 1) / ncn, size = 1u << cb;
+        const u64 *first = w + 4, *second = w + 4 + ncn;
+        u64 a = 0, b = 0;
+        for (u32 i = ncn; i-- > 0;) { a = fadd(fmul(a, size), first[i]); b = fadd(fmul(b, size), second[i]); }
+        *o++ = fsub(a, w[0]);
+        *o++ = fsub(b, w[1]);
+        u64 msd = 0;
+        for (u32 i = 0; i < ncn; i++) {
+            *o++ = range_product(first[i], size);
+            *o++ = range_product(second[i], size);
+            u64 diff = fsub(second[i], first[i]);
+            u64 dummy = w[4 + 2 * ncn + i], eq = w[4 + 3 * ncn + i], inter = w[4 + 4 * ncn + i];
+            *o++ = fsub(fmul(diff, dummy), fsub(1, eq));
+            *o++ = fmul(eq, diff);
+            *o++ = fsub(inter, fmul(eq, msd));
+            msd = fadd(inter, fmul(fsub(1, eq), diff));
+        }
+        *o++ = fsub(w[3], msd);
+        const u64 *bits = w + 4 + 5 * ncn;
+        for (u32 i = 0; i <= cb; i++) *o++ = fmul(bits[i], fsub(1, bits[i]));
+        u64 comb = 0;
+        for (u32 i = cb + 1; i-- > 0;) comb = fadd(fadd(comb, comb), bits[i]);
+        *o++ = fsub(fadd(size, w[3]), comb);
+        *o++ = fsub(w[2], bits[cb]);
+        break;
+    }
+    case G_U32_INTERLEAVE: {
+        u32 n = g->p[0];
+        for (u32 i = 0; i < n; i++) {
+            const u64 *bits = w + 2 * n + 32 * i;     /* big-endian */
+            u64 x = 0, xi = 0;
+            for (u32 j = 0; j < 32; j++) { x = fadd(fadd(x, x), bits[j]); xi = fadd(fmul(xi, 4), bits[j]); }
+            *o++ = fsub(x, w[2 * i]);
+            *o++ = fsub(xi, w[2 * i + 1]);
+            for (u32 j = 0; j < 32; j++) *o++ = range_product(bits[j], 2);
+        }
+        break;
+    }
+    case G_UNINTERLEAVE_TO_U32:
+    case G_UNINTERLEAVE_TO_B32: {
+        u32 n = g->p[0];
+        int b32 = g->type == G_UNINTERLEAVE_TO_B32;
+        for (u32 i = 0; i < n; i++) {
+            const u64 *bits = w + 3 * n + 64 * i;
+            u64 x = 0, ev = 0, od = 0;
+            for (u32 j = 0; j < 64; j++) x = fadd(fadd(x, x), bits[j]);
+            for (u32 j = 0; j < 32; j++) {
+                u64 coeff = b32 ? 1ULL << (2 * (31 - j)) : 1ULL << (31 - j);
+                ev = fadd(ev, fmul(coeff, bits[2 * j]));
+                od = fadd(od, fmul(coeff, bits[2 * j + 1]));
+            }
+            *o++ = fsub(x, w[3 * i]);
+            *o++ = fsub(ev, w[3 * i + 1]);
+            *o++ = fsub(od, w[3 * i + 2]);
+            for (u32 j = 0; j < 64; j++) *o++ = range_product(bits[j], 2);
+        }
+        break;
+    }
     default: return -1;
     }
     return (int)(o - out);
@@ -506,7 +640,7 @@ int zklc_oracle_plonky2_prove(const oparams *pr, const ogate *gates, const u64 *
     const u32 ngc = pr->num_gate_constraints;
     if (qdf != (1u << rb) || nch > 4 || ngc > 1024) return -1;
     for (u32 g = 0; g < pr->num_gates; g++)
-        if (gates[g].type > G_COSET_INTERPOLATION) return -1;
+        if (gates[g].type >= G_NUM_TYPES) return -1;
     double t[8] = {0}, t0 = now_s();
 
     /* ---- preprocessing: constants + sigmas commitment, circuit digest = hash(cap || hash_pad([]) || degree_bits) */

@@ -56,15 +56,35 @@ def test_c_prover_on_a_recursion_circuit_is_accepted_by_the_verifier(inner):
         V.verify(json.loads(json.dumps(S.proof_from_bytes(bytes(t), rcommon, S.HASH_GL))), rvd, rcommon)
 
 
-def test_c_prover_refuses_gates_outside_the_recursion_set():
-    from zklc_amd.plonky2 import CircuitBuilder, wide_ecc_config
-    from zklc_amd.plonky2 import ed25519_circuit as E
-    b = CircuitBuilder(wide_ecc_config())
-    g = E.Gadgets(b)
-    x, y = g.virtual_biguint(2), g.virtual_biguint(2)
-    g.add_biguint(x, y) if hasattr(g, "add_biguint") else g.add_nonnative(g.virtual_biguint(8), g.virtual_biguint(8))
-    data = b.build()
-    assert any(gt.code > 13 for gt in data.gates)
-    wires = np.zeros((data.config["num_wires"], data.n), dtype=np.uint64)
+@pytest.mark.parametrize("shape", ["recursion", "ed25519"])
+def test_c_prover_every_gate_type_bytes_equal_the_python_restatement(shape):
+    """the synthetic circuits of the GPU parity tests (every gate type of the two reference circuit shapes, 19 in total, random
+    satisfying witnesses, 2^6 rows): the C prover's bytes are the Python restatement's"""
+    from zklc_amd.plonky2 import synthetic as SY, gates as G, standard_recursion_config, wide_ecc_config
+    pgl.use_c_port()
+    if shape == "recursion":
+        cfg = standard_recursion_config()
+        mix = SY.recursion_shape_mix(cfg) + [(G.ExponentiationGate(20), 3)]
+    else:
+        cfg = wide_ecc_config()
+        mix = SY.ed25519_shape_mix(cfg)
+    data, wires, pis = SY.synthetic_circuit(6, cfg, mix, num_public_inputs=11, seed=3)
+    common = data.common_data()
+    oproof, ovd = OP.prove(common, data.constants, data.sigmas, wires, pis, V.HasherGL)
+    got, _, vd = cport.plonky2_prove(data, wires, pis, nthreads=2, verifier_data=True)
+    assert got == S.proof_to_bytes(json.loads(json.dumps(oproof)), common, S.HASH_GL)
+    assert vd == json.loads(json.dumps(ovd))
+
+
+def test_c_prover_refuses_unknown_gate_codes(inner):
+    data, wires, pis, common, proof, vd = inner
+
+    class Fake:
+        pass
+    fake = Fake()
+    fake.__dict__.update(data.__dict__)
+    g0 = Fake()
+    g0.code, g0.params = 99, [0, 0, 0, 0]
+    fake.gates = [g0] + list(data.gates[1:])
     with pytest.raises(ValueError):
-        cport.plonky2_prove(data, wires, [0] * data.num_public_inputs)
+        cport.plonky2_prove(fake, wires, pis)
