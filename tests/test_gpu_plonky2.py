@@ -128,6 +128,23 @@ def test_reference_sized_proofs_verify(zctx, shape, degree_bits, hasher):
         V.verify(json.loads(json.dumps(proof)), prover.verifier_data(), common)
 
 
+@pytest.mark.xfail(strict=False, reason="new in the last hours of round 2, after the round's GPU budget was spent: its first run on hardware "
+                                        "is the driver's; it becomes a hard assertion once it has been seen to pass")
+@pytest.mark.parametrize("shape,degree_bits", [("recursion", 12), ("ed25519", 13)])
+def test_gpu_proof_bytes_equal_the_c_prover_at_reference_sizes(zctx, shape, degree_bits):
+    """above ~2^8 rows the Python prover restatement is impractical and the tests relied on the verifier alone; the oracle's C
+    prover (oracle/c/plonky2_prover_oracle.c, bytes equal to the Python restatement on small circuits: tests/test_oracle_cprover.py)
+    gives byte-level parity at the reference's sizes: 2^12 x 135 (recursion shape) and a 2^13 x 234 slice of the Ed25519 shape"""
+    from oracle import cport
+    data, wires, pis = _synthetic(shape, degree_bits, seed=5, npi=16)
+    prover = data.prover(zctx, HASH_GL)
+    got = prover.prove_bytes(wires, pis)
+    want, secs, vd = cport.plonky2_prove(data, wires, pis, verifier_data=True)
+    assert prover.verifier_data() == vd
+    assert got == want
+    prover.close()
+
+
 def test_reference_sha512_circuit_proof(zctx):
     """the reference's SHA-512 circuit (crypto/plonky2_sha512/src/circuit.rs, restated in zklc_amd/plonky2/sha512.py) with a
     real witness -- SHA-512 of a 105-byte NEAR Ed25519 preimage -- proven on the GPU; the verifier restatement accepts the
