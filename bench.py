@@ -5,32 +5,26 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1], "C2"): the batched Ed25519 pre-verification
-of Block_i approval sets of the 100-validator shape
-(near_bft_finality/src/prove_block_data/signatures.rs:70-123).  One STEP = one
-launch of the verify kernel over `--blocks` Block_i approval sets (default 8192
-blocks x 100 validators = 819,200 signatures per GPU, every block with its own
-41-byte Approval message, 1 % of the signatures corrupted), inputs resident in
-HBM.  Multi-GPU: every rank verifies its own shard of blocks (weak scaling, no
-data-path collective -- the approval sets of different blocks are independent).
+Headline = BASELINE.json's metric on its configs[2]: **Block_i BFT-finality proofs/sec (100 validators)**.  One STEP = one full
+`prove_block_bft` (near_bft_finality/src/prove_bft/bft.rs:38-500) of the NEAR mainnet window shipped with the reference
+(tests/golden/block_window_HPi5.json: 100 validators, 73 approvals), end to end from the borsh bytes: batched Ed25519
+pre-verification, witness generation on the GPU, 73 proofs of the reference's Ed25519 circuit, their left fold and closing proof,
+keys / stakes, seven header-hash chains, bp_hash, the joining recursions and the Poseidon-BN128 wrap.  W untimed blocks (the first
+builds and uploads every circuit), then exactly K blocks between barriers, max over ranks; the final proof and its wrap are
+verified after the timed region (`final_proof_verified`).  Multi-GPU: every rank proves its own block (weak scaling, no data-path
+collective); `--scaling strong` proves ONE block with all ranks (signature shards, tree fold, header proofs on the other ranks).
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement)
-including `roofline` (HBM, algorithmic bytes 97 B/signature) and `cpu_baseline`
-(the oracle's C restatement on the host cores; kind = "port").
-
-After the timed headline region the same process measures the other stages of the
-path (their numbers ride along in `stages`, each with its own roofline block and,
-on one GPU, a bounded CPU sample of the oracle):
-  msm      BN254 G1 MSM, 2^22 points per GPU (C4); N > 1: index-sharded, partial sums
-           all-gathered over RCCL and added with a unit-scalar MSM (inside the timing)
-  lde      Goldilocks coset LDE 234 x (2^17 -> 2^20), bit-reversed output (C3)
-  merkle   Poseidon leaf hashing + Merkle tree, 2^20 leaves x 234 columns, cap height 4 (C3)
-  prove    full plonky2 proofs (zklc_plonky2_prove_dev, witness resident in HBM): the reference's per-signature Ed25519
-           circuit itself (2^18 rows x 234 wires, witness of a real NEAR approval signature), synthetic circuits of the
-           recursion shape (2^12 rows x 135 wires, the 13 gate types of the golden common_data) with the Poseidon and the
-           Poseidon-BN128 (wrap) hashers; plus one Block_i signature sub-DAG (100 validators: 100 Ed25519 proofs, the serial
-           fold of 100 recursion-shape proofs, 1 wrap; signatures.rs:70-139) with several proofs in flight -> Block_i proofs/s
-`--no-stages` skips them; `--no-prove` skips only the last one.
+Prints ONE JSON line on rank 0 (the driver contract of the task statement) with
+  roofline      the dominant kernel of a block proof (Poseidon leaf hashing), timed live with HIP events in the `merkle` stage:
+                algorithmic bytes against the HBM peak, PMC traffic, and `valu` = SQ_INSTS_VALU x 64 / time against the measured
+                integer issue ceiling (the resource that binds it)
+  cpu_baseline  the oracle's C + OpenMP prover on the host cores (kind = "port"): MEASURED one complete proof at the fold shape
+                (bytes compared with the GPU's) and the wires commitment of the Ed25519 shape on bounded samples, the rest of that
+                shape SCALED and labelled; `--cpu-baseline-ed25519` measures the whole Ed25519-shape proof instead (minutes)
+  stages        msm (BN254 G1 MSM 2^22, C4), lde and merkle (C3 shapes: 234 x 2^17 -> 2^20), prove (per-circuit proof times and the
+                Block_i breakdown), bn254_extras (G2 MSM, Fr NTT, pairing checks, a whole Groth16 prove at 2^22), ed25519_verify
+                (configs[1]: 8192 approval sets x 100 validators per launch), `--c5-validators N` (synthetic epoch)
+`--no-stages`, `--no-prove`, `--no-bn254-extras`, `--no-cpu-baseline` skip parts; `--host-witness` uses the host interpreter.
 """
 import argparse
 import json
