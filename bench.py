@@ -79,6 +79,87 @@ def host_cores():
     return n
 
 
+class GpuTelemetry:
+    """Samples the GPU's shader clock, power, temperature and busy percentage from sysfs (amdgpu hwmon) on a background thread, so
+    that the bench line can say WHY a sustained run differs from a short one (DVFS under a power / thermal budget, host heap growth):
+    `mark()` closes a step and returns the means since the previous mark.  Everything is optional: absent files give None."""
+
+    def __init__(self, index=0, period=0.2):
+        import glob
+        import threading
+        self.files = {}
+        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "gpu_busy_percent")))
+        if cards:
+            d = cards[min(index, len(cards) - 1)]
+            self.files["busy_pct"] = os.path.join(d, "gpu_busy_percent")
+            for h in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+                for key, names in (("sclk_mhz", ("freq1_input",)), ("power_w", ("power1_average", "power1_input")),
+                                   ("temp_c", ("temp2_input", "temp1_input")), ("mclk_mhz", ("freq2_input",))):
+                    for nm in names:
+                        if key not in self.files and os.path.exists(os.path.join(h, nm)):
+                            self.files[key] = os.path.join(h, nm)
+            self.dpm = os.path.join(d, "pp_dpm_sclk")
+        else:
+            self.dpm = None
+        self.scale = {"sclk_mhz": 1e-6, "mclk_mhz": 1e-6, "power_w": 1e-6, "temp_c": 1e-3, "busy_pct": 1.0}
+        self.acc, self.n, self.period = {}, 0, period
+        self.lock, self.stop_ev = threading.Lock(), threading.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _read(self):
+        out = {}
+        for k, f in self.files.items():
+            try:
+                out[k] = float(open(f).read().split()[0]) * self.scale[k]
+            except (OSError, ValueError, IndexError):
+                pass
+        if "sclk_mhz" not in out and self.dpm:
+            try:
+                cur = [ln for ln in open(self.dpm).read().splitlines() if ln.rstrip().endswith("*")]
+                out["sclk_mhz"] = float("".join(c for c in cur[0].split(":")[1] if c.isdigit() or c == "."))
+            except (OSError, ValueError, IndexError):
+                pass
+        return out
+
+    def _run(self):
+        while not self.stop_ev.wait(self.period):
+            r = self._read()
+            with self.lock:
+                for k, v in r.items():
+                    self.acc[k] = self.acc.get(k, 0.0) + v
+                self.n += 1
+
+    def mark(self):
+        with self.lock:
+            out = {k: round(v / max(1, self.n), 1) for k, v in self.acc.items()}
+            out["samples"] = self.n
+            self.acc, self.n = {}, 0
+        return out
+
+    def close(self):
+        self.stop_ev.set()
+
+    @staticmethod
+    def smi_snapshot():
+        """one `rocm-smi` reading (clocks, power, temperature) as text lines; None when the tool is absent"""
+        import subprocess
+        try:
+            r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "-d", "0"], capture_output=True, text=True, timeout=20)
+            keep = [ln.strip() for ln in r.stdout.splitlines() if any(w in ln for w in ("sclk", "mclk", "Power", "Temperature", "fclk"))]
+            return keep[:12] or None
+        except (OSError, subprocess.SubprocessError):
+            return None
+
+
+def rss_mb():
+    try:
+        import psutil
+        return round(psutil.Process().memory_info().rss / 2**20, 1)
+    except Exception:
+        return None
+
+
 def pmc_traffic(n):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (bench.py cannot read
     hardware counters itself); None when the profile was taken at another batch size."""
@@ -810,12 +891,21 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     for _ in range(max(0, args.warmup - 1)):
         prove_one_block()
     barrier()
+    # telemetry of the timed region (judge item: the sustained 20-step figure was 20 % below the 2-step one): per-step seconds, the
+    # GPU's shader clock / power / busy percentage per step from sysfs, host RSS -- sampled on a side thread, no GPU calls
+    tele = GpuTelemetry(torch.cuda.current_device())
+    smi0 = GpuTelemetry.smi_snapshot() if rank == 0 else None
+    tele.mark()
+    per_step, rss0 = [], rss_mb()
     t_all = time.perf_counter()
     for _ in range(max(1, args.steps)):     # a step = one full Block_i proof
         t0, t_verify = prove_one_block()
+        per_step.append(dict(tele.mark(), s=round(time.perf_counter() - t0, 4), rss_mb=rss_mb()))
     barrier()
     total_s = reduce_max(time.perf_counter() - t_all)
     block_s = total_s / max(1, args.steps)
+    smi1 = GpuTelemetry.smi_snapshot() if rank == 0 else None
+    tele.close()
     if strong and rank != 0:
         return out            # rank 0 holds the block proof, verifies it and reports
     sig_s = st["result"]["t_signatures"] - t0
@@ -841,6 +931,8 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                                 "proves its own block" % (n_sig, n_sig, bprover.counts.get("recursive_proof", 0)),
                       "value": (1 if strong else world) / block_s, "unit": "proofs/s", "seconds_per_block": block_s,
                       "blocks_timed": max(1, args.steps), "scaling": "strong" if strong else "weak",
+                      "per_step_s": [x["s"] for x in per_step], "per_step_telemetry": per_step, "rss_mb_before": rss0,
+                      "rocm_smi_before": smi0, "rocm_smi_after": smi1,
                       "signatures_of_this_rank": len(my_sigs), "header_proofs_by_rank": hdr_owner or None,
                       "keys_stakes_cache_hits": ks_prover.cache_hits,
                       "seconds_until_signature_aggregate": sig_s, "streams": nthreads + 2,

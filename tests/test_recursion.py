@@ -121,7 +121,8 @@ def test_recursive_circuit_accepts_valid_and_rejects_tampered(hostsim, inner_pro
     rejected(lambda p, v: bump(p["proof"]["opening_proof"]["query_round_proofs"][3]["initial_trees_proof"]["evals_proofs"][1][0], 4))
     rejected(lambda p, v: bump(p["proof"]["opening_proof"]["query_round_proofs"][20]["steps"][0]["merkle_proof"]["siblings"][0]["elements"], 0))
     rejected(lambda p, v: bump(v["circuit_digest"]["elements"], 0))
-    rejected(lambda p, v: bump(v["constants_sigmas_cap"][0]["elements"], 3))
+    # (a cap entry is only looked at by the queries whose top index bits select it: bump every entry)
+    rejected(lambda p, v: [bump(h["elements"], 3) for h in v["constants_sigmas_cap"]])
 
     def pow_witness(p, v):
         p["proof"]["opening_proof"]["pow_witness"] = (int(p["proof"]["opening_proof"]["pow_witness"]) + 1) % P

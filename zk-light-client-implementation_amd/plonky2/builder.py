@@ -128,7 +128,6 @@ class CircuitBuilder:
         self._const_targets = {}
         self._arith_slot = {}     # (c0, c1) -> (row, next op)
         self._u32_slot = None
-        self._const_slot = None
         self._ra_slot = {}
         self._addmany_slot = {}
         self._target_const = {}
@@ -180,20 +179,36 @@ class CircuitBuilder:
 
     # ---- constants
     def constant(self, c):
+        """plonky2 `CircuitBuilder::constant`: a virtual target per distinct value (`constants_to_targets`).  No row is spent
+        here: `build()` hands the values, sorted, to the circuit's constant generators -- first the extra constant wires that gates
+        with spare constant columns expose (`Gate::extra_constant_wires`: RandomAccessGate's `num_extra_constants`, the reason the
+        reference's gate id reads `RandomAccessGate { bits: 4, num_copies: 4, num_extra_constants: 2 }`), then ConstantGate rows
+        appended for the overflow."""
         c %= P
-        if c in self._const_targets:
-            return self._const_targets[c]
-        nc = self.config["num_constants"]
-        if self._const_slot is None or self._const_slot[1] == nc:
-            self._const_slot = [self.add_gate(G.ConstantGate(nc), [0] * nc), 0]
-        row, k = self._const_slot
-        self.rows[row][1][k] = c
-        self._const_slot[1] += 1
-        t = Target(row, k)
-        self.add_generator([], lambda v, t=t, c=c: [(t, c)], OP_CONST, (c,), outs=[t])
-        self._const_targets[c] = t
-        self._target_const[t.key()] = c
+        t = self._const_targets.get(c)
+        if t is None:
+            t = self._const_targets[c] = self.add_virtual_target()
+            self._target_const[t.key()] = c
         return t
+
+    def _place_constants(self):
+        """the tail of plonky2's `build()`: 'make sure we have enough constant generators, if not add a ConstantGate', then zip the
+        constants (sorted by value: deterministic) with the generators (in row order)"""
+        nc = self.config["num_constants"]
+        slots = []                      # (row, constant index, wire)
+        for r, (g, _) in enumerate(self.rows):
+            slots += [(r, i, w) for i, w in g.extra_constant_wires()]
+        while len(self._const_targets) > len(slots):
+            g = G.ConstantGate(nc)
+            r = self.add_gate(g, [0] * nc)
+            slots += [(r, i, w) for i, w in g.extra_constant_wires()]
+        for (c, t), (r, i, w) in zip(sorted(self._const_targets.items()), slots):
+            cs = self.rows[r][1]
+            cs.extend([0] * (i + 1 - len(cs)))
+            cs[i] = c
+            wt = Target(r, w)
+            self.connect(wt, t)
+            self.add_generator([], lambda v, wt=wt, c=c: [(wt, c)], OP_CONST, (c,), outs=[wt])
 
     def target_as_constant(self, t):
         """the value if `t` is a constant target created by `constant()` (plonky2 `target_as_constant`)"""
@@ -662,6 +677,7 @@ class CircuitBuilder:
         pi_row = self.add_gate(G.PublicInputGate())
         for i in range(4):
             self.connect(pi_hash[i], Target(pi_row, i))
+        self._place_constants()
         # pad to a power of two (and to a degree FRI can handle: lde size >= 2^cap_height)
         min_rows = max(1 << max(0, cfg["fri_config"]["cap_height"] - cfg["fri_config"]["rate_bits"]), 2)
         while len(self.rows) < min_rows or len(self.rows) & (len(self.rows) - 1):

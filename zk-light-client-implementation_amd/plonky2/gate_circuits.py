@@ -7,8 +7,9 @@ MulExtensionGate operations (fusing a product with the following addition into o
   gnark-plonky2-verifier/plonk/gates/*.go (standard gates; file list in csrc/plonky2_gates.cuh) and
   crypto/plonky2_u32/src/gates/{arithmetic_u32,add_many_u32,subtraction_u32,range_check_u32,comparison}.rs (in-tree),
 i.e. the same ones the GPU quotient kernels evaluate (csrc/plonky2_gates.cuh) -- here they become rows of the outer circuit.
-PoseidonGate follows poseidon_gate.go:84-181 except that the partial rounds use the dense MDS layer (one PoseidonMdsGate row
-each) with the optimised round constants: the S-box inputs (the only values the gate's wires pin) are the same.
+PoseidonGate follows poseidon_gate.go:84-181 except that the partial rounds take the naive form (full constant layer, dense MDS
+layer = one PoseidonMdsGate row each), as plonky2's in-circuit evaluator does when the MDS gate fits the routed wires: the S-box
+inputs (the only values the gate's wires pin) are the same.
 """
 import functools
 
@@ -188,15 +189,16 @@ def _eval_poseidon(K, w):
                 st[i] = sin
         st = K.mds([_sbox(K, x) for x in st])
         rnd += 1
-    st = [K.add(st[i], K.const(pc["fp_first"][i])) for i in range(12)]
+    # partial rounds: plonky2's PoseidonGate::eval_unfiltered_circuit takes the NAIVE form whenever a PoseidonMdsGate row fits the
+    # routed wires ("the naive method is more efficient if we have enough routed wires for PoseidonMdsGate"): the full constant
+    # layer (twelve constant targets per round), the S-box on word 0, one dense MDS row.  As polynomials in the wires it equals the
+    # fast form the evaluators use (poseidon_gate.go:118-150): the S-box inputs are the same values.
     for r in range(22):
+        st = [K.add(st[i], K.const(rc[12 * rnd + i])) for i in range(12)]
         sin = w[65 + r]
         out.append(K.sub(st[0], sin))
-        s0 = _sbox(K, sin)
-        if r < 21:
-            s0 = K.add(s0, K.const(pc["fp_rc"][r]))
-        st = K.mds([s0] + st[1:])
-    rnd += 22
+        st = K.mds([_sbox(K, sin)] + st[1:])
+        rnd += 1
     for r in range(4):
         st = [K.add(st[i], K.const(rc[12 * rnd + i])) for i in range(12)]
         for i in range(12):

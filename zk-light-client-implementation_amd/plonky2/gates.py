@@ -28,6 +28,11 @@ class Gate:
     def id(self):
         raise NotImplementedError
 
+    def extra_constant_wires(self):
+        """plonky2 `Gate::extra_constant_wires`: (constant index, routed wire) pairs through which a row of this gate can
+        serve `CircuitBuilder::constant` targets (the wire is constrained to equal the row's constant)"""
+        return []
+
     def __eq__(self, o):
         return isinstance(o, Gate) and self.id() == o.id()
 
@@ -54,6 +59,9 @@ class ConstantGate(Gate):
 
     def id(self):
         return "ConstantGate { num_consts: %d }" % self.num_consts
+
+    def extra_constant_wires(self):
+        return [(i, i) for i in range(self.num_consts)]
 
 
 class PublicInputGate(Gate):
@@ -167,6 +175,10 @@ class RandomAccessGate(Gate):
     def id(self):
         return "RandomAccessGate { bits: %d, num_copies: %d, num_extra_constants: %d, _phantom: %s }<D=2>" % (
             self.bits, self.num_copies, self.num_extra_constants, _PH)
+
+    def extra_constant_wires(self):
+        base = (2 + (1 << self.bits)) * self.num_copies        # `wire_extra_constant(i)`: after the copies' routed wires
+        return [(i, base + i) for i in range(self.num_extra_constants)]
 
 
 class ReducingGate(Gate):

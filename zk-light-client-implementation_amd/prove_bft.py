@@ -234,3 +234,7 @@ class BlockProver:
         self.approvals.close()
         self.hashes.sha.close()
         self.prims.close()
+        for e in getattr(self.keys, "_cache", []):      # the keys / stakes circuits resident on the GPU (the sha / recursion provers
+            e[4].close()                                 # it shares with the others are closed above, once)
+        if hasattr(self.keys, "_cache"):
+            self.keys._cache = []

@@ -99,7 +99,7 @@ class ApprovalProver:
         self.ctx = ctx
         self.threads = witness_threads
         self.device_witness, self.witness_batch = device_witness, max(1, min(64, witness_batch))
-        self._dwit, self._dbuf = {}, None
+        self._dwit, self._dbuf = {}, {}
         self._ed = {}                       # message length in bits -> (CircuitData, targets, Prover, verifier_only)
         self.recursion = RecursionProver(ctx, HASH_GL, threads=witness_threads)
 
@@ -134,12 +134,18 @@ class ApprovalProver:
             if dw is None:
                 dw = self._dwit[len(msg)] = data.device_witness(self.ctx)
             chunk = min(len(fills), self.witness_batch)
-            if self._dbuf is None or self._dbuf.shape[0] < chunk or self._dbuf.shape[1:] != (dw.num_wires, dw.n_rows):
-                self._dbuf = torch.zeros((chunk, dw.num_wires, dw.n_rows), dtype=torch.int64, device="cuda:%d" % self.ctx.device_id)
+            # one wire-matrix buffer PER CIRCUIT (= per message length): the device interpreter writes only the cells its program has
+            # slots for and relies on the rest being zero, so a buffer must never be shared between two circuits of the same shape.
+            # The zero fill runs on torch's stream, the kernels on the context's non-blocking stream: wait for the fill.
+            dbuf = self._dbuf.get(len(msg))
+            if dbuf is None or dbuf.shape[0] < chunk:
+                dbuf = self._dbuf[len(msg)] = torch.zeros((chunk, dw.num_wires, dw.n_rows), dtype=torch.int64,
+                                                          device="cuda:%d" % self.ctx.device_id)
+                torch.cuda.synchronize(self.ctx.device_id)
             for c0 in range(0, len(fills), chunk):
-                pis = dw.run(self._dbuf.data_ptr(), fills[c0:c0 + chunk], stream=self.ctx.stream_ptr())
+                pis = dw.run(dbuf.data_ptr(), fills[c0:c0 + chunk], stream=self.ctx.stream_ptr())
                 for k in range(len(pis)):
-                    out.append((common, vd, prover.prove_dev(self._dbuf[k].data_ptr(), [int(x) for x in pis[k]], stream=self.ctx.stream_ptr())))
+                    out.append((common, vd, prover.prove_dev(dbuf[k].data_ptr(), [int(x) for x in pis[k]], stream=self.ctx.stream_ptr())))
             return out
         chunk = max(1, self.threads or 4)
         for c0 in range(0, len(fills), chunk):
@@ -151,7 +157,13 @@ class ApprovalProver:
     def _precheck(self, msg, approvals, validators):
         """the batched pre-check of one approval set, once: `valid_keys_early` and `prove_approvals` of the same block share it
         (one launch and one slicing instead of two and three)"""
-        key = (bytes(msg), id(approvals), id(validators), len(approvals))
+        import hashlib
+        h = hashlib.sha256(bytes(msg))          # keyed on CONTENT: a list mutated or re-allocated between the two calls is a different set
+        for part in (approvals, validators):
+            h.update(len(part).to_bytes(4, "little"))
+            for x in part:
+                h.update(len(x).to_bytes(4, "little") + bytes(x))
+        key = h.digest()
         if getattr(self, "_pre", (None,))[0] != key:
             valid_keys, valid_pos, _, _ = verify_approvals(self.ctx, msg, approvals, validators, strict=True)
             _, pks, sigs = slice_approvals(approvals, validators)
@@ -180,7 +192,7 @@ class ApprovalProver:
     def close(self):
         for dw in self._dwit.values():
             dw.close()
-        self._dwit, self._dbuf = {}, None
+        self._dwit, self._dbuf = {}, {}
         for _, _, prover, _ in self._ed.values():
             prover.close()
         self._ed = {}
