@@ -80,62 +80,57 @@ def host_cores():
 
 
 class GpuTelemetry:
-    """Samples the GPU's shader clock, power, temperature and busy percentage from sysfs (amdgpu hwmon) on a background thread, so
-    that the bench line can say WHY a sustained run differs from a short one (DVFS under a power / thermal budget, host heap growth):
-    `mark()` closes a step and returns the means since the previous mark.  Everything is optional: absent files give None."""
+    """Samples shader clock, power, temperature and busy percentage of every amdgpu card in sysfs on a background thread, so that
+    the bench line can say WHY a sustained run differs from a short one (DVFS under a power / thermal budget, host stalls):
+    `mark()` closes a step and returns the means since the previous mark FOR THE BUSIEST CARD of that interval (a box may expose
+    cards this process does not use, and sysfs card order is not the HIP device order).  Absent files give no key."""
 
-    def __init__(self, index=0, period=0.2):
+    KEYS = (("sclk_mhz", ("freq1_input",), 1e-6), ("power_w", ("power1_average", "power1_input"), 1e-6),
+            ("temp_c", ("temp2_input", "temp1_input"), 1e-3), ("mclk_mhz", ("freq2_input",), 1e-6))
+
+    def __init__(self, period=0.2):
         import glob
         import threading
-        self.files = {}
-        cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "gpu_busy_percent")))
-        if cards:
-            d = cards[min(index, len(cards) - 1)]
-            self.files["busy_pct"] = os.path.join(d, "gpu_busy_percent")
+        self.cards = []
+        for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            if not os.path.exists(os.path.join(d, "gpu_busy_percent")):
+                continue
+            files = {"busy_pct": (os.path.join(d, "gpu_busy_percent"), 1.0)}
             for h in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
-                for key, names in (("sclk_mhz", ("freq1_input",)), ("power_w", ("power1_average", "power1_input")),
-                                   ("temp_c", ("temp2_input", "temp1_input")), ("mclk_mhz", ("freq2_input",))):
+                for key, names, scale in self.KEYS:
                     for nm in names:
-                        if key not in self.files and os.path.exists(os.path.join(h, nm)):
-                            self.files[key] = os.path.join(h, nm)
-            self.dpm = os.path.join(d, "pp_dpm_sclk")
-        else:
-            self.dpm = None
-        self.scale = {"sclk_mhz": 1e-6, "mclk_mhz": 1e-6, "power_w": 1e-6, "temp_c": 1e-3, "busy_pct": 1.0}
-        self.acc, self.n, self.period = {}, 0, period
+                        if key not in files and os.path.exists(os.path.join(h, nm)):
+                            files[key] = (os.path.join(h, nm), scale)
+            self.cards.append({"name": os.path.basename(os.path.dirname(d)), "files": files, "acc": {}, "n": 0})
+        self.period = period
         self.lock, self.stop_ev = threading.Lock(), threading.Event()
         self.thread = threading.Thread(target=self._run, daemon=True)
         self.thread.start()
 
-    def _read(self):
-        out = {}
-        for k, f in self.files.items():
-            try:
-                out[k] = float(open(f).read().split()[0]) * self.scale[k]
-            except (OSError, ValueError, IndexError):
-                pass
-        if "sclk_mhz" not in out and self.dpm:
-            try:
-                cur = [ln for ln in open(self.dpm).read().splitlines() if ln.rstrip().endswith("*")]
-                out["sclk_mhz"] = float("".join(c for c in cur[0].split(":")[1] if c.isdigit() or c == "."))
-            except (OSError, ValueError, IndexError):
-                pass
-        return out
-
     def _run(self):
         while not self.stop_ev.wait(self.period):
-            r = self._read()
-            with self.lock:
-                for k, v in r.items():
-                    self.acc[k] = self.acc.get(k, 0.0) + v
-                self.n += 1
+            for c in self.cards:
+                r = {}
+                for k, (f, scale) in c["files"].items():
+                    try:
+                        r[k] = float(open(f).read().split()[0]) * scale
+                    except (OSError, ValueError, IndexError):
+                        pass
+                with self.lock:
+                    for k, v in r.items():
+                        c["acc"][k] = c["acc"].get(k, 0.0) + v
+                    c["n"] += 1
 
     def mark(self):
         with self.lock:
-            out = {k: round(v / max(1, self.n), 1) for k, v in self.acc.items()}
-            out["samples"] = self.n
-            self.acc, self.n = {}, 0
-        return out
+            best = None
+            for c in self.cards:
+                m = {k: round(v / max(1, c["n"]), 1) for k, v in c["acc"].items()}
+                m["samples"], m["card"] = c["n"], c["name"]
+                if best is None or (m.get("busy_pct", 0), m.get("power_w", 0)) > (best.get("busy_pct", 0), best.get("power_w", 0)):
+                    best = m
+                c["acc"], c["n"] = {}, 0
+        return best or {"samples": 0}
 
     def close(self):
         self.stop_ev.set()
@@ -146,8 +141,8 @@ class GpuTelemetry:
         import subprocess
         try:
             r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "-d", "0"], capture_output=True, text=True, timeout=20)
-            keep = [ln.strip() for ln in r.stdout.splitlines() if any(w in ln for w in ("sclk", "mclk", "Power", "Temperature", "fclk"))]
-            return keep[:12] or None
+            keep = [ln.strip() for ln in r.stdout.splitlines() if any(w in ln for w in ("sclk", "mclk", "Power", "junction"))]
+            return keep[:8] or None
         except (OSError, subprocess.SubprocessError):
             return None
 
@@ -888,12 +883,19 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     t_setup = time.perf_counter()
     prove_one_block()                      # builds and uploads the circuits of every shape of the DAG (host Python, one-time)
     t_setup = time.perf_counter() - t_setup
+    # The circuits are tens of millions of long-lived Python objects (14 GB of heap): a full generational collection walks all of
+    # them and stalled ONE block in ~15 by 15 s (round 2's sustained 7.13 s against 5.96 s over two blocks; profiles/r03a_bench.json:
+    # nineteen steps of 6.0-6.3 s and one of 20.9 s).  Standard remedy for a long-running service: collect once, then move everything
+    # alive to the permanent generation, so that later collections only look at what a block allocates.
+    import gc
+    gc.collect()
+    gc.freeze()
     for _ in range(max(0, args.warmup - 1)):
         prove_one_block()
     barrier()
     # telemetry of the timed region (judge item: the sustained 20-step figure was 20 % below the 2-step one): per-step seconds, the
     # GPU's shader clock / power / busy percentage per step from sysfs, host RSS -- sampled on a side thread, no GPU calls
-    tele = GpuTelemetry(torch.cuda.current_device())
+    tele = GpuTelemetry()
     smi0 = GpuTelemetry.smi_snapshot() if rank == 0 else None
     tele.mark()
     per_step, rss0 = [], rss_mb()

@@ -3,12 +3,15 @@
 // against the oracle without a GPU.  Never linked into libzklc_mi355.so.
 #include "../../zk-light-client-implementation_amd/csrc/ed25519_verify.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/poseidon_gl.cuh"
-#include "../../zk-light-client-implementation_amd/csrc/bn254_g1.cuh"
+#include "../../zk-light-client-implementation_amd/csrc/bn254_msm_lane.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/poseidon_bn254.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/plonky2_gates.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/bn254_pairing.cuh"
-#include "../../zk-light-client-implementation_amd/csrc/bn254_g2.cuh"
 #include <string.h>
+#include <vector>
+
+typedef ec_xyzz<FpField> g1_xyzz;
+typedef ec_xyzz<Fp2Field> g2_xyzz;
 
 static ge_niels g_btab[ZKLC_ED_BTABLE];
 static int g_btab_ready = 0;
@@ -130,20 +133,133 @@ void hostsim_fp_op(int op, const u32 *a, const u32 *b, u32 *out) {
 }
 // op 0: P + Q (mixed), 1: P - Q (mixed), 2: 2P, 3: (P + Q) + (P + Q) general add, 4: ((P+Q)+Q)+... chain of n mixed adds of Q
 u32 hostsim_g1_op(int op, const u32 *p16, u32 pinf, const u32 *q16, u32 qinf, u32 n, u32 *out16) {
-    g1_aff P, Q;
-    P.x = fp_from_gnark(p16); P.y = fp_from_gnark(p16 + 8); P.inf = pinf;
-    Q.x = fp_from_gnark(q16); Q.y = fp_from_gnark(q16 + 8); Q.inf = qinf;
-    g1_xyzz a = g1_from_affine(P), r;
+    fp qx = fp_from_gnark(q16), qy = fp_from_gnark(q16 + 8);      // Q stays lazy, as in the MSM bucket loop
+    g1_xyzz a, r;
+    a.X = fp_reduce(fp_from_gnark(p16));
+    a.Y = fp_reduce(fp_from_gnark(p16 + 8));
+    a.ZZ = pinf ? fp_zero() : FpField::one();
+    a.ZZZ = a.ZZ;
     switch (op) {
-        case 0: r = qinf ? a : g1_add_affine(a, Q.x, Q.y, 0); break;  // Q stays lazy, as in the MSM bucket loop
-        case 1: r = qinf ? a : g1_add_affine(a, Q.x, Q.y, 1); break;
-        case 2: r = g1_double(a); break;
-        case 3: { g1_xyzz s = qinf ? a : g1_add_affine(a, Q.x, Q.y, 0); r = g1_add(s, s); break; }
-        case 4: { r = a; for (u32 i = 0; i < n; i++) r = g1_add_affine(r, Q.x, Q.y, 0); break; }
-        case 5: { g1_xyzz s = g1_from_affine(Q); r = g1_add(a, s); break; }
-        default: r = g1_infinity();
+        case 0: r = qinf ? a : ec_add_affine<FpField>(a, qx, qy, 0); break;
+        case 1: r = qinf ? a : ec_add_affine<FpField>(a, qx, qy, 1); break;
+        case 2: r = ec_double(a); break;
+        case 3: { g1_xyzz s = qinf ? a : ec_add_affine<FpField>(a, qx, qy, 0); r = ec_add(s, s); break; }
+        case 4: { r = a; for (u32 i = 0; i < n; i++) r = ec_add_affine<FpField>(r, qx, qy, 0); break; }
+        case 5: {
+            g1_xyzz s;
+            s.X = fp_reduce(qx);
+            s.Y = fp_reduce(qy);
+            s.ZZ = qinf ? fp_zero() : FpField::one();
+            s.ZZZ = s.ZZ;
+            r = ec_add(a, s);
+            break;
+        }
+        default: r = ec_infinity<FpField>();
     }
-    return g1_to_affine_gnark(out16, r);
+    return ec_to_affine_gnark(out16, r);
+}
+
+// The whole multi-scalar multiplication of csrc/bn254_msm.hip as a sequential walk over its lanes: recode -> (chunk, window) tile
+// histograms -> prefixes / totals / offsets -> scatter -> one "lane" per bucket (msm_bucket_lane; buckets above `heavy_min` take the
+// strided form of the heavy-bucket kernel with `heavy_threads` partial sums) -> segments -> windows -> doublings.  Same functions,
+// same plan, same digit codes as the kernels; only the parallel glue (LDS atomics, tree reductions) is replaced by loops.
+}  // extern "C"
+template <class F>
+static u32 hostsim_msm(const u64 *points, const u64 *scalars, u32 n, u32 heavy_min, u32 heavy_threads, u32 *out) {
+    const int AFF = msm_cfg<F>::AFF, XY = msm_cfg<F>::XYZZ;
+    msm_plan pl = msm_make_plan(n);
+    const u32 bpw = pl.buckets_per_window;
+    std::vector<unsigned short> dig((size_t)pl.n_pad * pl.windows, 0);
+    for (u32 i = 0; i < pl.n_pad; i++) {
+        bool live = i < pl.n && !msm_point_is_inf<AFF>(points, i);
+        u32 sw[8], carry = 0;
+        if (live) msm_load_scalar(scalars, i, sw);
+        for (u32 w = 0; w < pl.windows; w++) {
+            int d = live ? msm_digit(sw, w, pl.c, carry) : 0;
+            dig[(size_t)w * pl.n_pad + i] = (unsigned short)msm_digit_code(d);
+        }
+    }
+    std::vector<u32> cnt((size_t)pl.total_buckets * pl.chunks, 0), totals(pl.total_buckets), offsets(pl.total_buckets);
+    for (u32 w = 0; w < pl.windows; w++)
+        for (u32 k = 0; k < pl.chunks; k++) {
+            u32 lo = k * pl.chunk_len, hi = lo + pl.chunk_len < pl.n_pad ? lo + pl.chunk_len : pl.n_pad;
+            for (u32 i = lo; i < hi; i++) {
+                u32 code = dig[(size_t)w * pl.n_pad + i], neg;
+                if (code) cnt[((size_t)w * pl.chunks + k) * bpw + msm_code_bucket(code, neg)]++;
+            }
+        }
+    for (u32 key = 0; key < pl.total_buckets; key++) {
+        u32 w = key / bpw, b = key % bpw, run = 0;
+        for (u32 k = 0; k < pl.chunks; k++) {
+            u32 &c = cnt[((size_t)w * pl.chunks + k) * bpw + b];
+            u32 t = c;
+            c = run;
+            run += t;
+        }
+        totals[key] = run;
+    }
+    u32 run = 0;
+    for (u32 key = 0; key < pl.total_buckets; key++) {
+        offsets[key] = run;
+        run += totals[key];
+    }
+    std::vector<u32> entries((size_t)run + 1, 0);
+    for (u32 w = 0; w < pl.windows; w++)
+        for (u32 k = 0; k < pl.chunks; k++) {
+            std::vector<u32> cur(bpw);
+            for (u32 b = 0; b < bpw; b++) cur[b] = offsets[(size_t)w * bpw + b] + cnt[((size_t)w * pl.chunks + k) * bpw + b];
+            u32 lo = k * pl.chunk_len, hi = lo + pl.chunk_len < pl.n_pad ? lo + pl.chunk_len : pl.n_pad;
+            for (u32 i = lo; i < hi; i++) {
+                u32 code = dig[(size_t)w * pl.n_pad + i], neg;
+                if (!code) continue;
+                u32 b = msm_code_bucket(code, neg);
+                entries[cur[b]++] = (i << 1) | neg;
+            }
+        }
+    std::vector<i32> buckets((size_t)pl.total_buckets * XY);
+    for (u32 key = 0; key < pl.total_buckets; key++) {
+        ec_xyzz<F> acc = ec_infinity<F>();
+        if (totals[key] >= heavy_min) {
+            for (u32 t = 0; t < heavy_threads; t++) {
+                ec_xyzz<F> part = ec_infinity<F>();
+                msm_bucket_lane<F>(part, points, entries.data(), offsets[key], t, totals[key], heavy_threads);
+                acc = ec_add(acc, part);
+            }
+        } else {
+            msm_bucket_lane<F>(acc, points, entries.data(), offsets[key], 0, totals[key], 1);
+        }
+        msm_store_xyzz<F>(buckets.data() + (size_t)key * XY, acc);
+    }
+    u32 seg_per_window = (bpw + MSM_SEG - 1) / MSM_SEG;
+    ec_xyzz<F> total = ec_infinity<F>();
+    for (u32 w = pl.windows; w-- > 0;) {
+        ec_xyzz<F> win = ec_infinity<F>();
+        for (u32 si = 0; si < seg_per_window; si++) win = ec_add(win, msm_segment_lane<F>(buckets.data(), pl, w, si));
+        for (u32 k = 0; k < pl.c * w; k++) win = ec_double(win);      // as msm_final_kernel: 2^(c w) * window_w, then the sum
+        total = ec_add(total, win);
+    }
+    return ec_to_affine_gnark(out, total);
+}
+extern "C" {
+u32 hostsim_msm_g1(const u64 *points, const u64 *scalars, u32 n, u32 heavy_min, u32 heavy_threads, u32 *out16) {
+    return hostsim_msm<FpField>(points, scalars, n, heavy_min, heavy_threads, out16);
+}
+u32 hostsim_msm_g2(const u64 *points, const u64 *scalars, u32 n, u32 heavy_min, u32 heavy_threads, u32 *out32) {
+    return hostsim_msm<Fp2Field>(points, scalars, n, heavy_min, heavy_threads, out32);
+}
+void hostsim_msm_plan(u64 n, u32 *out8) {
+    msm_plan pl = msm_make_plan(n);
+    out8[0] = pl.n_pad; out8[1] = pl.c; out8[2] = pl.windows; out8[3] = pl.buckets_per_window; out8[4] = pl.total_buckets;
+    out8[5] = pl.chunks; out8[6] = pl.chunk_len; out8[7] = MSM_SEG;
+}
+int hostsim_msm_digit_roundtrip(const u64 *scalar4, u32 c, int *digits, u32 *codes) {
+    u32 sw[8], carry = 0, windows = 254 / c + 1;
+    msm_load_scalar(scalar4, 0, sw);
+    for (u32 w = 0; w < windows; w++) {
+        digits[w] = msm_digit(sw, w, c, carry);
+        codes[w] = msm_digit_code(digits[w]);
+    }
+    return (int)carry;
 }
 
 // Poseidon-BN254: states as 4 x 8 words, regular (non-Montgomery) form
@@ -257,11 +373,11 @@ u32 hostsim_g2_op(int op, const u32 *p32, const u32 *q32, u32 *out32) {
     fp2 qx = fp2_from_gnark(q32), qy = fp2_from_gnark(q32 + 16);
     g2_xyzz r;
     switch (op) {
-        case 0: r = g2_add_affine(a, qx, qy, 0); break;
-        case 1: r = g2_add_affine(a, qx, qy, 1); break;
-        case 2: r = g2_double(a); break;
-        default: { g2_xyzz s = g2_add_affine(a, qx, qy, 0); r = g2_add(s, a); }
+        case 0: r = ec_add_affine<Fp2Field>(a, qx, qy, 0); break;
+        case 1: r = ec_add_affine<Fp2Field>(a, qx, qy, 1); break;
+        case 2: r = ec_double(a); break;
+        default: { g2_xyzz s = ec_add_affine<Fp2Field>(a, qx, qy, 0); r = ec_add(s, a); }
     }
-    return g2_to_affine_gnark(out32, r);
+    return ec_to_affine_gnark(out32, r);
 }
 }

@@ -1,0 +1,123 @@
+"""The BN254 multi-scalar multiplication of csrc/bn254_msm.hip, walked lane by lane on the CPU (tests/hostsim: the same
+bn254_msm_lane.cuh functions, plan, digit codes, tile counting sort, pipelined bucket loop, segment sums) against the oracle's
+naive multi-exponentiation (oracle/c/bn254_oracle.c) -- SURVEY 8(d) C4 scalar classes: uniform, witness-like, adversarial."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import cport, bn254 as B
+
+R = B.R
+
+
+def _scalars(kind, n, rng):
+    if kind == "uniform":
+        vals = [int(rng.integers(0, 2**63)) * (2**192) % R + int(rng.integers(0, 2**63)) * int(rng.integers(0, 2**63)) for _ in range(n)]
+        vals = [v % R for v in vals]
+    elif kind == "witness":          # 50 % in {0, 1}, 30 % < 2^64, 20 % uniform
+        vals = []
+        for _ in range(n):
+            u = rng.random()
+            if u < 0.5:
+                vals.append(int(rng.integers(0, 2)))
+            elif u < 0.8:
+                vals.append(int(rng.integers(0, 2**63)))
+            else:
+                vals.append((int(rng.integers(0, 2**63)) << 190 | int(rng.integers(0, 2**63))) % R)
+    elif kind == "equal":            # adversarial: every scalar the same -> one bucket per window takes everything
+        vals = [0x1234567890ABCDEF1122334455667788990011223344556677889900AABBCC % R] * n
+    elif kind == "top":              # largest digits: r - 1, 2^15 multiples (the +2^15 digit code), unreduced scalars (>= r)
+        vals = [R - 1, 1 << 15, (1 << 15) + (1 << 31), (1 << 253) + 12345, 2**256 - 1, R, R + 7] * (n // 7 + 1)
+        vals = vals[:n]
+    else:
+        raise ValueError(kind)
+    return np.array([[(v >> (64 * k)) & (2**64 - 1) for k in range(4)] for v in vals], dtype=np.uint64)
+
+
+def _run(hostsim, pts, sc, heavy_min=1 << 30, heavy_threads=4):
+    n = pts.shape[0]
+    out = (ctypes.c_uint32 * 16)()
+    inf = hostsim.hostsim_msm_g1(pts.ctypes.data_as(ctypes.c_void_p), sc.ctypes.data_as(ctypes.c_void_p), n, heavy_min, heavy_threads, out)
+    got = np.array([out[2 * i] | (out[2 * i + 1] << 32) for i in range(8)], dtype=np.uint64)
+    return got, bool(inf)
+
+
+@pytest.mark.parametrize("kind,n", [("uniform", 300), ("witness", 300), ("equal", 200), ("top", 70), ("uniform", 2500), ("uniform", 1)])
+def test_msm_lane_walk_matches_oracle(hostsim, kind, n):
+    rng = np.random.default_rng(5 + n)
+    pts = cport.bn254_gen_points(n, 5, 3)
+    if kind == "witness":
+        pts[3] = 0          # points at infinity (all-zero encoding) take no part, whatever their scalar
+        pts[n - 1] = 0
+    sc = _scalars(kind, n, rng)
+    live = [i for i in range(n) if pts[i].any()]
+    want, winf, _ = cport.bn254_msm(pts[live], _reduced(sc[live]), naive=True)
+    got, inf = _run(hostsim, pts, sc)
+    assert inf == winf and (inf or np.array_equal(got, want))
+    # the strided form of the heavy-bucket kernel (every bucket with >= 2 entries, 3 partial sums) gives the same point
+    got2, inf2 = _run(hostsim, pts, sc, heavy_min=2, heavy_threads=3)
+    assert inf2 == inf and np.array_equal(got2, got)
+
+
+def _reduced(sc):
+    """the oracle's naive MSM takes reduced scalars: reduce mod r on the host (the product reduces unreduced scalars itself)"""
+    out = np.zeros_like(sc)
+    for i, row in enumerate(sc):
+        v = sum(int(row[k]) << (64 * k) for k in range(4)) % R
+        out[i] = [(v >> (64 * k)) & (2**64 - 1) for k in range(4)]
+    return out
+
+
+def test_all_points_equal_and_cancelling(hostsim):
+    """all points equal (every bucket addition after the first is a doubling) and P, -P pairs (sums hit infinity)"""
+    n = 64
+    one = cport.bn254_gen_points(1, 9, 1)
+    pts = np.repeat(one, n, axis=0)
+    rng = np.random.default_rng(3)
+    sc = _scalars("uniform", n, rng)
+    sc[: n // 2] = sc[0]                      # same scalar, same point: P = Q in the mixed addition
+    want, winf, _ = cport.bn254_msm(pts, sc, naive=True)
+    got, inf = _run(hostsim, pts, sc)
+    assert not inf and np.array_equal(got, want)
+    # s * P + (r - s) * P = infinity
+    sc2 = sc.copy()
+    for i in range(0, n, 2):
+        v = sum(int(sc[i][k]) << (64 * k) for k in range(4))
+        w = (R - v) % R
+        sc2[i + 1] = [(w >> (64 * k)) & (2**64 - 1) for k in range(4)]
+    got, inf = _run(hostsim, pts, sc2)
+    assert inf
+
+
+def test_plan_and_digit_codes(hostsim):
+    out = (ctypes.c_uint32 * 8)()
+    for n in (1, 63, 64, 2047, 2048, 1 << 15, (1 << 19) - 1, 1 << 19, 1 << 22, (1 << 22) + 5):
+        hostsim.hostsim_msm_plan(ctypes.c_uint64(n), out)
+        n_pad, c, windows, bpw, total, chunks, chunk_len, seg = list(out)
+        assert n_pad % 8 == 0 and n <= n_pad < n + 8 and c <= 16 and windows == 254 // c + 1 and bpw == 1 << (c - 1)
+        assert total == windows * bpw and 1 <= chunks <= 16 and chunk_len % 8 == 0 and chunks * chunk_len >= n_pad
+        assert bpw * 4 <= 160 * 1024          # a window's counters fit the LDS of one workgroup
+    # digits reassemble the scalar; codes decode to (bucket, sign)
+    rng = np.random.default_rng(11)
+    digs, codes = (ctypes.c_int * 64)(), (ctypes.c_uint32 * 64)()
+    for c in (4, 8, 11, 14, 16):
+        for _ in range(50):
+            v = int(rng.integers(0, 2**63)) << 191 | int(rng.integers(0, 2**63)) << 100 | int(rng.integers(0, 2**63))
+            v %= R
+            if _ % 10 == 0:
+                v = R - 1 - _
+            s4 = (ctypes.c_uint64 * 4)(*[(v >> (64 * k)) & (2**64 - 1) for k in range(4)])
+            carry = hostsim.hostsim_msm_digit_roundtrip(s4, c, digs, codes)
+            windows = 254 // c + 1
+            assert carry == 0
+            assert sum(digs[w] << (c * w) for w in range(windows)) == v
+            for w in range(windows):
+                d = digs[w]
+                assert -(2 ** (c - 1)) < d <= 2 ** (c - 1)
+                code = codes[w]
+                assert (code == 0) == (d == 0) and code < 65536
+                if d:
+                    neg = code > 0x8000
+                    mag = 0x10000 - code if neg else code
+                    assert (neg, mag) == (d < 0, abs(d))

@@ -1,5 +1,5 @@
 // Short-Weierstrass curves y^2 = x^3 + b (a = 0) in extended Jacobian coordinates (X, Y, ZZ, ZZZ), generic over the
-// coordinate field: BN254 G1 over Fp (bn254_g1.cuh) and G2 over Fp2 (bn254_g2.cuh) share these formulas.
+// coordinate field: BN254 G1 over Fp (FpField) and G2 over Fp2 (Fp2Field) share these formulas.
 // x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2 -- the bucket coordinates of gnark-crypto's MSM (g1JacExtended / g2JacExtended,
 // un-vendored: gnark-plonky2-verifier/go.mod:9; call site `groth16.Prove`, cmd/web-api.go:77).  Infinity is ZZ = 0.
 // EFD madd-2008-s / add-2008-s / dbl-2008-s-1; the exceptional cases (P = Q, P = -Q, infinity) are explicit because

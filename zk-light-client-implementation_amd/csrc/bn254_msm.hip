@@ -3,108 +3,115 @@
 // Replaces gnark-crypto's `bn254.G1Affine.MultiExp` / `bn254.G2Affine.MultiExp` (un-vendored,
 // gnark-plonky2-verifier/go.mod:9) under `groth16.Prove`
 // (gnark-plonky2-verifier/cmd/web-api.go:77, tests/prover_test.go:64).  Every kernel is a template over the
-// coordinate field (Fp for G1, Fp2 for G2; bn254_ec.cuh) -- the pipeline is identical.
+// coordinate field (Fp for G1, Fp2 for G2; bn254_ec.cuh) -- the pipeline is identical.  What one lane does lives in
+// bn254_msm_lane.cuh (shared with tests/hostsim); this file is the parallel structure around it.
 //
-// Pipeline (all on the device, no host round trips):
-//   1. signed c-bit digits of every scalar; histogram of (window, |digit|) keys
-//   2. exclusive scan of the histogram -> bucket offsets
-//   3. counting-sort scatter of (point index, sign) entries into bucket order
-//   4. bucket accumulation: one LANE per bucket walks its entries and adds the affine
-//      points (extended-Jacobian mixed addition); buckets with more than
-//      MSM_HEAVY entries (skewed scalars, e.g. many equal to 1) go to a
-//      workgroup-per-bucket kernel with an LDS tree reduction instead
-//   5. bucket reduction: per window, segments of 128 buckets -> running-sum
-//      trick + small scalar multiple, then an LDS tree over the segments
-//   6. 2^(c w) * window_w by doublings (one lane per window), tree sum, affine output
-// Curve additions are order-independent as group elements, so the (arbitrary) order of the
-// atomics in steps 1 and 3 never changes the affine result.
-#include "bn254_g1.cuh"
-#include "bn254_g2.cuh"
+// Pipeline (all on the device, no host round trips, NO global atomics):
+//   1. recode: signed c-bit digits of every scalar, 16 bits each, window-major (a point at infinity gets zero digits)
+//   2. counting sort by (window, bucket) on (chunk, window) tiles, one workgroup per tile with the window's 2^(c-1) counters in
+//      LDS (128 KiB at c = 16): histogram per tile -> prefix over the chunks + bucket totals -> exclusive scan of the totals ->
+//      scatter of (point index, sign) entries through LDS cursors.  Round 1 did both passes with one global atomic per
+//      (scalar, window): 5.7 of the 27 ms of a 2^22 MSM.
+//   3. bucket accumulation: one LANE per bucket walks its entries and adds the affine points (extended-Jacobian mixed addition),
+//      the gathers software-pipelined one iteration ahead; a lane takes two buckets (key and key + total/2) so that the
+//      Poisson spread of the bucket sizes evens out inside a wave; buckets with more than MSM_HEAVY entries (skewed scalars,
+//      e.g. many equal to 1) go to a workgroup-per-bucket kernel with an LDS tree reduction instead
+//   4. bucket reduction: per window, segments of MSM_SEG buckets -> running-sum trick + small scalar multiple (one lane per
+//      segment), then an LDS tree over the segments
+//   5. 2^(c w) * window_w by doublings (one lane per window), tree sum, affine output
+// Curve additions are order-independent as group elements, so the (arbitrary) order of the LDS atomics in step 2 never changes
+// the affine result.
+#include "bn254_msm_lane.cuh"
 #include "zklc_internal.h"
+#include <stdlib.h>
 
-#define MSM_MAX_WINDOWS 32
-#define MSM_HEAVY 4096u
-#define MSM_MAX_HEAVY 2048u
-#define MSM_SEG 128u
+#define MSM_SORT_THREADS 1024
+#define MSM_BUCKET_WAVES_G1 2
 
-struct msm_plan {
-    u32 n, c, windows, buckets_per_window, total_buckets;
-};
-
-ZKLC_D void msm_load_scalar(const u64 *scalars, u32 i, u32 *w) {
-    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(scalars + (size_t)i * 4);
-    ulonglong2 a = p[0], b = p[1];
-    w[0] = (u32)a.x; w[1] = (u32)(a.x >> 32); w[2] = (u32)a.y; w[3] = (u32)(a.y >> 32);
-    w[4] = (u32)b.x; w[5] = (u32)(b.x >> 32); w[6] = (u32)b.y; w[7] = (u32)(b.y >> 32);
-    // the window recoding covers 254 bits: a scalar that is not reduced (>= r, anything up to 2^256 - 1) is reduced here -- the
-    // points have order r, so the sum is the same -- instead of silently losing its top bits.  Reduced scalars leave at the
-    // first comparison of the top word.
-    const u32 R[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-#pragma unroll 1
-    for (int it = 0; it < 6; it++) {       // 2^256 / r < 6
-        bool ge = true;
-        for (int k = 7; k >= 0; k--)
-            if (w[k] != R[k]) {
-                ge = w[k] > R[k];
-                break;
-            }
-        if (!ge) break;
-        u64 borrow = 0;
-        for (int k = 0; k < 8; k++) {
-            u64 d = (u64)w[k] - R[k] - borrow;
-            w[k] = (u32)d;
-            borrow = (d >> 32) & 1;
-        }
-    }
-}
-
-// signed digit of window w given the running carry (updated): digit in [-(2^(c-1) - 1), 2^(c-1)]
-ZKLC_D int msm_digit(const u32 *sw, u32 w, u32 c, u32 &carry) {
-    u32 bit = w * c, wi = bit >> 5, sh = bit & 31;
-    u64 x = (u64)sw[wi] >> sh;
-    if (wi + 1 < 8) x |= (u64)sw[wi + 1] << (32 - sh);
-    u32 raw = ((u32)x & ((1u << c) - 1)) + carry;
-    if (raw > (1u << (c - 1))) {
-        carry = 1;
-        return (int)raw - (int)(1u << c);
-    }
-    carry = 0;
-    return (int)raw;
-}
-
-template <int AFF>  // u64 words per affine point: 8 (G1) or 16 (G2)
-ZKLC_D bool msm_point_is_inf(const u64 *points, u32 i) {
-    const ulonglong2 *p = reinterpret_cast<const ulonglong2 *>(points + (size_t)i * AFF);
-    u64 acc = 0;
-#pragma unroll
-    for (int k = 0; k < AFF / 2; k++) {
-        ulonglong2 a = p[k];
-        acc |= a.x | a.y;
-    }
-    return acc == 0;  // gnark encodes infinity as all-zero coordinates
-}
-
-template <bool SCATTER, int AFF>
+// ---- 1. recode
+template <int AFF>
 __global__ void __launch_bounds__(256)
-msm_digits_kernel(const u64 *__restrict__ points, const u64 *__restrict__ scalars, msm_plan pl, u32 *__restrict__ counts,
-                  const u32 *__restrict__ offsets, u32 *__restrict__ cursor, u32 *__restrict__ entries) {
+msm_recode_kernel(const u64 *__restrict__ points, const u64 *__restrict__ scalars, msm_plan pl, unsigned short *__restrict__ dig) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= pl.n) return;
-    if (msm_point_is_inf<AFF>(points, i)) return;
+    if (i >= pl.n_pad) return;
+    bool live = i < pl.n && !msm_point_is_inf<AFF>(points, i);
     u32 sw[8];
-    msm_load_scalar(scalars, i, sw);
+    if (live) msm_load_scalar(scalars, i, sw);
     u32 carry = 0;
     for (u32 w = 0; w < pl.windows; w++) {
-        int d = msm_digit(sw, w, pl.c, carry);
-        if (d == 0) continue;
-        u32 neg = d < 0;
-        u32 key = w * pl.buckets_per_window + (u32)(neg ? -d : d) - 1;
-        if (SCATTER) {
-            u32 pos = atomicAdd(&cursor[key], 1u);
-            entries[offsets[key] + pos] = (i << 1) | neg;
-        } else {
-            atomicAdd(&counts[key], 1u);
-        }
+        int d = live ? msm_digit(sw, w, pl.c, carry) : 0;
+        dig[(size_t)w * pl.n_pad + i] = (unsigned short)msm_digit_code(d);
+    }
+}
+
+// eight digit codes of one lane (16 bytes)
+ZKLC_D void msm_codes8(const unsigned short *row, u32 i, u32 *code) {
+    uint4 v = *reinterpret_cast<const uint4 *>(row + i);
+    code[0] = v.x & 0xffff; code[1] = v.x >> 16; code[2] = v.y & 0xffff; code[3] = v.y >> 16;
+    code[4] = v.z & 0xffff; code[5] = v.z >> 16; code[6] = v.w & 0xffff; code[7] = v.w >> 16;
+}
+
+// ---- 2a. histogram of tile (chunk k = blockIdx.x, window w = blockIdx.y) in LDS -> cnt[w][k][bucket]
+__global__ void __launch_bounds__(MSM_SORT_THREADS)
+msm_hist_kernel(const unsigned short *__restrict__ dig, msm_plan pl, u32 *__restrict__ cnt) {
+    extern __shared__ u32 msm_lds[];
+    const u32 bpw = pl.buckets_per_window, k = blockIdx.x, w = blockIdx.y;
+    for (u32 b = threadIdx.x; b < bpw; b += MSM_SORT_THREADS) msm_lds[b] = 0;
+    __syncthreads();
+    const unsigned short *row = dig + (size_t)w * pl.n_pad;
+    u32 lo = k * pl.chunk_len, hi = lo + pl.chunk_len < pl.n_pad ? lo + pl.chunk_len : pl.n_pad;
+    for (u32 i = lo + 8 * threadIdx.x; i < hi; i += 8 * MSM_SORT_THREADS) {
+        u32 code[8];
+        msm_codes8(row, i, code);
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (code[j]) {
+                u32 neg;
+                atomicAdd(&msm_lds[msm_code_bucket(code[j], neg)], 1u);
+            }
+    }
+    __syncthreads();
+    u32 *out = cnt + ((size_t)w * pl.chunks + k) * bpw;
+    for (u32 b = threadIdx.x; b < bpw; b += MSM_SORT_THREADS) out[b] = msm_lds[b];
+}
+
+// ---- 2b. per bucket: exclusive prefix of its tile counts over the chunks (in place) and its total
+__global__ void __launch_bounds__(256) msm_totals_kernel(u32 *__restrict__ cnt, msm_plan pl, u32 *__restrict__ totals) {
+    u32 key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= pl.total_buckets) return;
+    u32 w = key / pl.buckets_per_window, b = key % pl.buckets_per_window;
+    u32 run = 0;
+    for (u32 k = 0; k < pl.chunks; k++) {
+        u32 *p = cnt + ((size_t)w * pl.chunks + k) * pl.buckets_per_window + b;
+        u32 t = *p;
+        *p = run;
+        run += t;
+    }
+    totals[key] = run;
+}
+
+// ---- 2c. scatter of tile (k, w): LDS cursors start at (bucket offset + prefix of this tile)
+__global__ void __launch_bounds__(MSM_SORT_THREADS)
+msm_scatter_kernel(const unsigned short *__restrict__ dig, msm_plan pl, const u32 *__restrict__ cnt, const u32 *__restrict__ offsets,
+                   u32 *__restrict__ entries) {
+    extern __shared__ u32 msm_lds[];
+    const u32 bpw = pl.buckets_per_window, k = blockIdx.x, w = blockIdx.y;
+    const u32 *pre = cnt + ((size_t)w * pl.chunks + k) * bpw;
+    for (u32 b = threadIdx.x; b < bpw; b += MSM_SORT_THREADS) msm_lds[b] = offsets[(size_t)w * bpw + b] + pre[b];
+    __syncthreads();
+    const unsigned short *row = dig + (size_t)w * pl.n_pad;
+    u32 lo = k * pl.chunk_len, hi = lo + pl.chunk_len < pl.n_pad ? lo + pl.chunk_len : pl.n_pad;
+    for (u32 i = lo + 8 * threadIdx.x; i < hi; i += 8 * MSM_SORT_THREADS) {
+        u32 code[8];
+        msm_codes8(row, i, code);
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (code[j]) {
+                u32 neg;
+                u32 b = msm_code_bucket(code[j], neg);
+                u32 pos = atomicAdd(&msm_lds[b], 1u);
+                entries[pos] = ((i + j) << 1) | neg;
+            }
     }
 }
 
@@ -164,73 +171,44 @@ __global__ void __launch_bounds__(256) msm_scan_add_kernel(u32 *out, const u32 *
     if (i < n) out[i] += block_sums[i / SCAN_ITEMS];
 }
 
-// ---- bucket accumulation (template over the coordinate field F: FpField = G1, Fp2Field = G2)
-template <class F>
-struct msm_cfg {
-    static constexpr int XYZZ = 4 * F::LIMBS;            // i32 words of a stored XYZZ point
-    static constexpr int AFF = 2 * 4 * F::LIMBS / 10;    // u64 words of an affine point at the ABI
-    static constexpr int BLOCK = F::LIMBS == 10 ? 256 : 128;  // workgroup size of the LDS tree reductions (<= 40 KiB of LDS)
-};
-
-template <class F>
-ZKLC_D void msm_load_point(const u64 *points, u32 idx, typename F::T &x, typename F::T &y) {
-    const int W = msm_cfg<F>::AFF;  // u32 words per coordinate
-    const uint4 *p = reinterpret_cast<const uint4 *>(points + (size_t)idx * W);
-    u32 w[2 * W];
-#pragma unroll
-    for (int k = 0; k < W / 2; k++) {
-        uint4 a = p[k];
-        w[4 * k] = a.x;
-        w[4 * k + 1] = a.y;
-        w[4 * k + 2] = a.z;
-        w[4 * k + 3] = a.w;
-    }
-    x = F::from_gnark(w);
-    y = F::from_gnark(w + W);
-}
-
-template <class F>
-ZKLC_D void msm_store_xyzz(i32 *dst, const ec_xyzz<F> &p) {
-    F::store(dst, p.X);
-    F::store(dst + F::LIMBS, p.Y);
-    F::store(dst + 2 * F::LIMBS, p.ZZ);
-    F::store(dst + 3 * F::LIMBS, p.ZZZ);
-}
-template <class F>
-ZKLC_D ec_xyzz<F> msm_load_xyzz(const i32 *src) {
-    ec_xyzz<F> p;
-    p.X = F::load(src);
-    p.Y = F::load(src + F::LIMBS);
-    p.ZZ = F::load(src + 2 * F::LIMBS);
-    p.ZZZ = F::load(src + 3 * F::LIMBS);
-    return p;
-}
-
-template <class F>
-__global__ void __launch_bounds__(64)
+// ---- 3. bucket accumulation (template over the coordinate field F: FpField = G1, Fp2Field = G2; WAVES = the occupancy the
+// register allocation is asked to keep, PIPE = gathers one iteration ahead)
+template <class F, int WAVES, bool PIPE>
+__global__ void __launch_bounds__(64, WAVES)
 msm_bucket_sum_kernel(const u64 *__restrict__ points, const u32 *__restrict__ entries, const u32 *__restrict__ offsets,
                       const u32 *__restrict__ counts, msm_plan pl, i32 *__restrict__ buckets, u32 *__restrict__ heavy_list,
                       u32 *__restrict__ heavy_count) {
-    u32 key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key >= pl.total_buckets) return;
-    u32 cnt = counts[key];
-    ec_xyzz<F> acc = ec_infinity<F>();
-    if (cnt > MSM_HEAVY) {
-        u32 slot = atomicAdd(heavy_count, 1u);
-        if (slot < MSM_MAX_HEAVY) {
-            heavy_list[slot] = key;
-            return;  // the heavy kernel writes this bucket
+    u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 half = (pl.total_buckets + 1) / 2;
+    if (lane >= half) return;
+#pragma unroll 1
+    for (u32 part = 0; part < 2; part++) {
+        u32 key = lane + part * half;
+        if (key >= pl.total_buckets) break;
+        u32 cnt = counts[key];
+        if (cnt > MSM_HEAVY) {
+            u32 slot = atomicAdd(heavy_count, 1u);
+            if (slot < MSM_MAX_HEAVY) {
+                heavy_list[slot] = key;
+                continue;  // the heavy kernel writes this bucket
+            }
+            // list full: fall through and do it here (slow but correct)
         }
-        // list full: fall through and do it here (slow but correct)
+        ec_xyzz<F> acc = ec_infinity<F>();
+        u32 beg = offsets[key];
+        if (PIPE) {
+            msm_bucket_lane<F>(acc, points, entries, beg, 0, cnt, 1);
+        } else {
+#pragma unroll 1
+            for (u32 e = 0; e < cnt; e++) {
+                u32 ent = entries[beg + e];
+                typename F::T x, y;
+                msm_load_point<F>(points, ent >> 1, x, y);
+                acc = ec_add_affine<F>(acc, x, y, ent & 1);
+            }
+        }
+        msm_store_xyzz<F>(buckets + (size_t)key * msm_cfg<F>::XYZZ, acc);
     }
-    u32 beg = offsets[key];
-    for (u32 e = 0; e < cnt; e++) {
-        u32 ent = entries[beg + e];
-        typename F::T x, y;
-        msm_load_point<F>(points, ent >> 1, x, y);
-        acc = ec_add_affine<F>(acc, x, y, ent & 1);
-    }
-    msm_store_xyzz<F>(buckets + (size_t)key * msm_cfg<F>::XYZZ, acc);
 }
 
 // LDS tree reduction of one XYZZ point per thread (BLOCK threads); result in thread 0
@@ -258,45 +236,19 @@ msm_heavy_bucket_kernel(const u64 *__restrict__ points, const u32 *__restrict__ 
     u32 key = heavy_list[blockIdx.x];
     u32 beg = offsets[key], cnt = counts[key];
     ec_xyzz<F> acc = ec_infinity<F>();
-    for (u32 e = threadIdx.x; e < cnt; e += msm_cfg<F>::BLOCK) {
-        u32 ent = entries[beg + e];
-        typename F::T x, y;
-        msm_load_point<F>(points, ent >> 1, x, y);
-        acc = ec_add_affine<F>(acc, x, y, ent & 1);
-    }
+    msm_bucket_lane<F>(acc, points, entries, beg, threadIdx.x, cnt, msm_cfg<F>::BLOCK);
     acc = msm_block_reduce<F>(acc, lds);
     if (threadIdx.x == 0) msm_store_xyzz<F>(buckets + (size_t)key * msm_cfg<F>::XYZZ, acc);
 }
 
-// k * p for a small k (k < 2^31), double-and-add
-template <class F>
-ZKLC_D ec_xyzz<F> msm_small_mul(const ec_xyzz<F> &p, u32 k) {
-    ec_xyzz<F> r = ec_infinity<F>();
-    if (k == 0) return r;
-    for (int b = 31 - __clz(k); b >= 0; b--) {
-        r = ec_double(r);
-        if ((k >> b) & 1) r = ec_add(r, p);
-    }
-    return r;
-}
-
-// one lane per segment of MSM_SEG buckets: sum_{b in seg} (b + 1) B_b  (b = bucket index within the window)
+// ---- 4. one lane per segment of MSM_SEG buckets
 template <class F>
 __global__ void __launch_bounds__(64) msm_segment_kernel(const i32 *__restrict__ buckets, msm_plan pl, i32 *__restrict__ seg_out) {
-    const int XY = msm_cfg<F>::XYZZ;
     u32 seg_per_window = (pl.buckets_per_window + MSM_SEG - 1) / MSM_SEG;
     u32 s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= seg_per_window * pl.windows) return;
-    u32 w = s / seg_per_window, si = s % seg_per_window;
-    u32 lo = si * MSM_SEG, hi = lo + MSM_SEG < pl.buckets_per_window ? lo + MSM_SEG : pl.buckets_per_window;
-    ec_xyzz<F> S = ec_infinity<F>(), T = ec_infinity<F>();
-    for (u32 b = hi; b-- > lo;) {
-        S = ec_add(S, msm_load_xyzz<F>(buckets + ((size_t)w * pl.buckets_per_window + b) * XY));
-        T = ec_add(T, S);
-    }
-    // T = sum (b - lo + 1) B_b ; add lo * S
-    if (lo) T = ec_add(T, msm_small_mul<F>(S, lo));
-    msm_store_xyzz<F>(seg_out + (size_t)s * XY, T);
+    ec_xyzz<F> T = msm_segment_lane<F>(buckets, pl, s / seg_per_window, s % seg_per_window);
+    msm_store_xyzz<F>(seg_out + (size_t)s * msm_cfg<F>::XYZZ, T);
 }
 
 // one workgroup per window: sum of its segment results
@@ -335,29 +287,33 @@ __global__ void __launch_bounds__(msm_cfg<F>::BLOCK) msm_final_kernel(const i32 
 }
 
 // ---------------------------------------------------------------- host
-static u32 msm_pick_window(u64 n) {
-    if (n >= (1u << 19)) return 16;
-    if (n >= (1u << 15)) return 14;
-    if (n >= (1u << 11)) return 11;
-    if (n >= 64) return 8;
-    return 4;
-}
-
 template <class F>
 static uint64_t msm_workspace_bytes(uint64_t n) {
     const uint64_t XB = msm_cfg<F>::XYZZ * 4;
-    u32 c = msm_pick_window(n), windows = 254 / c + 1, bpw = 1u << (c - 1), total = windows * bpw;
-    u32 seg_per_window = (bpw + MSM_SEG - 1) / MSM_SEG;
-    uint64_t b = 0;
-    b += (uint64_t)total * 4 * 3;                       // counts, offsets, cursor
-    b += ((uint64_t)total / SCAN_ITEMS + 2) * 4;        // scan block sums
-    b += n * windows * 4;                               // entries
-    b += (uint64_t)total * XB;                          // buckets
-    b += (uint64_t)seg_per_window * windows * XB;       // segment sums
-    b += (uint64_t)windows * XB;                        // window sums
+    msm_plan pl = msm_make_plan(n);
+    u32 seg_per_window = (pl.buckets_per_window + MSM_SEG - 1) / MSM_SEG;
+    uint64_t total = pl.total_buckets, b = 0;
+    b += total * 4 * 2;                                 // totals (bucket sizes), offsets
+    b += (total / SCAN_ITEMS + 2) * 4;                  // scan block sums
+    b += total * pl.chunks * 4;                         // per-tile counts / prefixes
+    b += (uint64_t)pl.n_pad * pl.windows * 2;           // digit codes
+    b += n * pl.windows * 4 + 4;                        // entries
+    b += total * XB;                                    // buckets
+    b += (uint64_t)seg_per_window * pl.windows * XB;    // segment sums
+    b += (uint64_t)pl.windows * XB;                     // window sums
     b += (MSM_MAX_HEAVY + 4) * 4;                       // heavy list + counter
     b += 256 * 16;                                      // alignment slack
     return b;
+}
+
+// the sort kernels keep a whole window's counters in LDS: up to 128 KiB of dynamic LDS, above the default 64 KiB limit
+static hipError_t msm_sort_lds_attr() {
+    static hipError_t done = [] {
+        hipError_t e = hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }();
+    return done;
 }
 
 template <class F>
@@ -368,13 +324,9 @@ static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points
     if (!ctx || !d_out_affine || !d_out_inf || (n && (!d_points || !d_scalars)) || n >= (1ULL << 31)) return ZKLC_ERR_INVALID_ARG;
     if (((uintptr_t)d_points | (uintptr_t)d_scalars) & 15) return ZKLC_ERR_INVALID_ARG;
     ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    ZKLC_HIP(ctx, msm_sort_lds_attr());
     hipStream_t st = zklc_pick_stream(ctx, stream);
-    msm_plan pl;
-    pl.n = (u32)n;
-    pl.c = msm_pick_window(n);
-    pl.windows = 254 / pl.c + 1;
-    pl.buckets_per_window = 1u << (pl.c - 1);
-    pl.total_buckets = pl.windows * pl.buckets_per_window;
+    msm_plan pl = msm_make_plan(n);
     if (workspace_bytes < msm_workspace_bytes<F>(n) || !d_workspace) return ZKLC_ERR_INVALID_ARG;
     u32 seg_per_window = (pl.buckets_per_window + MSM_SEG - 1) / MSM_SEG;
     // carve the workspace (256-byte aligned pieces)
@@ -384,38 +336,74 @@ static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points
         p += (bytes + 255) & ~(size_t)255;
         return r;
     };
-    u32 *counts = (u32 *)take((size_t)pl.total_buckets * 4);
-    u32 *cursor = (u32 *)take((size_t)pl.total_buckets * 4);
-    u32 *heavy_count = (u32 *)take(16);
-    size_t zero_bytes = (char *)p - (char *)counts;  // counts, cursor, heavy counter are zeroed every call
+    u32 *heavy_count = (u32 *)take(16);                 // zeroed every call
+    u32 *totals = (u32 *)take((size_t)pl.total_buckets * 4);
     u32 *offsets = (u32 *)take((size_t)pl.total_buckets * 4);
     u32 nblocks = (pl.total_buckets + SCAN_ITEMS - 1) / SCAN_ITEMS;
     u32 *block_sums = (u32 *)take((size_t)(nblocks + 1) * 4);
+    u32 *tile_cnt = (u32 *)take((size_t)pl.total_buckets * pl.chunks * 4);
+    unsigned short *dig = (unsigned short *)take((size_t)pl.n_pad * pl.windows * 2);
     u32 *heavy_list = (u32 *)take(MSM_MAX_HEAVY * 4);
     u32 *entries = (u32 *)take((size_t)n * pl.windows * 4 + 4);
     i32 *buckets = (i32 *)take((size_t)pl.total_buckets * XB);
     i32 *seg_out = (i32 *)take((size_t)seg_per_window * pl.windows * XB);
     i32 *win_out = (i32 *)take((size_t)pl.windows * XB);
     const int BLK = msm_cfg<F>::BLOCK;
+    const size_t lds = (size_t)pl.buckets_per_window * 4;
 
-    ZKLC_HIP(ctx, hipMemsetAsync(counts, 0, zero_bytes, st));
-    u32 gpts = (pl.n + 255) / 256;
+    ZKLC_HIP(ctx, hipMemsetAsync(heavy_count, 0, 16, st));
     if (pl.n) {
-        hipLaunchKernelGGL((msm_digits_kernel<false, AFF>), dim3(gpts), dim3(256), 0, st, d_points, d_scalars, pl, counts,
-                           (const u32 *)nullptr, cursor, entries);
+        hipLaunchKernelGGL((msm_recode_kernel<AFF>), dim3((pl.n_pad + 255) / 256), dim3(256), 0, st, d_points, d_scalars, pl, dig);
+        hipLaunchKernelGGL(msm_hist_kernel, dim3(pl.chunks, pl.windows), dim3(MSM_SORT_THREADS), lds, st, (const unsigned short *)dig, pl,
+                           tile_cnt);
+    } else {
+        ZKLC_HIP(ctx, hipMemsetAsync(tile_cnt, 0, (size_t)pl.total_buckets * pl.chunks * 4, st));
     }
-    hipLaunchKernelGGL(msm_scan_block_kernel, dim3(nblocks), dim3(256), 0, st, (const u32 *)counts, offsets, block_sums, pl.total_buckets);
+    hipLaunchKernelGGL(msm_totals_kernel, dim3((pl.total_buckets + 255) / 256), dim3(256), 0, st, tile_cnt, pl, totals);
+    hipLaunchKernelGGL(msm_scan_block_kernel, dim3(nblocks), dim3(256), 0, st, (const u32 *)totals, offsets, block_sums, pl.total_buckets);
     hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(1), dim3(256), 0, st, block_sums, nblocks);
     hipLaunchKernelGGL(msm_scan_add_kernel, dim3((pl.total_buckets + 255) / 256), dim3(256), 0, st, offsets, (const u32 *)block_sums,
                        pl.total_buckets);
     if (pl.n) {
-        hipLaunchKernelGGL((msm_digits_kernel<true, AFF>), dim3(gpts), dim3(256), 0, st, d_points, d_scalars, pl, counts,
-                           (const u32 *)offsets, cursor, entries);
+        hipLaunchKernelGGL(msm_scatter_kernel, dim3(pl.chunks, pl.windows), dim3(MSM_SORT_THREADS), lds, st, (const unsigned short *)dig, pl,
+                           (const u32 *)tile_cnt, (const u32 *)offsets, entries);
     }
-    hipLaunchKernelGGL(msm_bucket_sum_kernel<F>, dim3((pl.total_buckets + 63) / 64), dim3(64), 0, st, d_points, (const u32 *)entries,
-                       (const u32 *)offsets, (const u32 *)counts, pl, buckets, heavy_list, heavy_count);
+    u32 half = (pl.total_buckets + 1) / 2;
+    // variants of the bucket kernel (A/B switch ZKLC_MSM_BUCKET = <waves 1..4><p|n>, e.g. "2p"; default per field below)
+    {
+        const char *v = getenv("ZKLC_MSM_BUCKET");
+        int waves = F::LIMBS == 10 ? MSM_BUCKET_WAVES_G1 : 1;
+        bool pipe = true;
+        if (v && v[0] >= '1' && v[0] <= '4') {
+            waves = v[0] - '0';
+            pipe = v[1] != 'n';
+        }
+        if (F::LIMBS != 10) waves = 1;       // the Fp2 kernel needs the whole register file
+        dim3 g((half + 63) / 64), b(64);
+#define MSM_BUCKET_LAUNCH(W, P)                                                                                                  \
+    hipLaunchKernelGGL((msm_bucket_sum_kernel<F, W, P>), g, b, 0, st, d_points, (const u32 *)entries, (const u32 *)offsets,       \
+                       (const u32 *)totals, pl, buckets, heavy_list, heavy_count)
+        if (F::LIMBS != 10) {
+            if (pipe) MSM_BUCKET_LAUNCH(1, true); else MSM_BUCKET_LAUNCH(1, false);
+        } else if (pipe) {
+            switch (waves) {
+                case 1: MSM_BUCKET_LAUNCH(1, true); break;
+                case 2: MSM_BUCKET_LAUNCH(2, true); break;
+                case 3: MSM_BUCKET_LAUNCH(3, true); break;
+                default: MSM_BUCKET_LAUNCH(4, true); break;
+            }
+        } else {
+            switch (waves) {
+                case 1: MSM_BUCKET_LAUNCH(1, false); break;
+                case 2: MSM_BUCKET_LAUNCH(2, false); break;
+                case 3: MSM_BUCKET_LAUNCH(3, false); break;
+                default: MSM_BUCKET_LAUNCH(4, false); break;
+            }
+        }
+#undef MSM_BUCKET_LAUNCH
+    }
     hipLaunchKernelGGL(msm_heavy_bucket_kernel<F>, dim3(MSM_MAX_HEAVY), dim3(BLK), 0, st, d_points, (const u32 *)entries,
-                       (const u32 *)offsets, (const u32 *)counts, buckets, (const u32 *)heavy_list, (const u32 *)heavy_count);
+                       (const u32 *)offsets, (const u32 *)totals, buckets, (const u32 *)heavy_list, (const u32 *)heavy_count);
     hipLaunchKernelGGL(msm_segment_kernel<F>, dim3((seg_per_window * pl.windows + 63) / 64), dim3(64), 0, st, (const i32 *)buckets, pl,
                        seg_out);
     hipLaunchKernelGGL(msm_window_kernel<F>, dim3(pl.windows), dim3(BLK), 0, st, (const i32 *)seg_out, pl, win_out);
