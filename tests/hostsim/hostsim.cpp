@@ -160,12 +160,14 @@ u32 hostsim_g1_op(int op, const u32 *p16, u32 pinf, const u32 *q16, u32 qinf, u3
 }
 
 // The whole multi-scalar multiplication of csrc/bn254_msm.hip as a sequential walk over its lanes: recode -> (chunk, window) tile
-// histograms -> prefixes / totals / offsets -> scatter -> one "lane" per bucket (msm_bucket_lane; buckets above `heavy_min` take the
-// strided form of the heavy-bucket kernel with `heavy_threads` partial sums) -> segments -> windows -> doublings.  Same functions,
+// histograms -> prefixes / totals / offsets -> scatter -> mode 0 (the product): converted points, one "lane" per SLICE of the sorted
+// entries (msm_slice_lane), then the combine of the buckets cut by slice boundaries (buckets cut into more than `heavy_min` slices
+// take the strided form of the heavy-combine kernel with `heavy_threads` partial sums); mode 1: one lane per bucket on the raw
+// points (msm_bucket_lane) -> segments -> windows -> doublings.  Same functions,
 // same plan, same digit codes as the kernels; only the parallel glue (LDS atomics, tree reductions) is replaced by loops.
 }  // extern "C"
 template <class F>
-static u32 hostsim_msm(const u64 *points, const u64 *scalars, u32 n, u32 heavy_min, u32 heavy_threads, u32 *out) {
+static u32 hostsim_msm(const u64 *points, const u64 *scalars, u32 n, u32 mode, u32 heavy_min, u32 heavy_threads, u32 *out) {
     const int AFF = msm_cfg<F>::AFF, XY = msm_cfg<F>::XYZZ;
     msm_plan pl = msm_make_plan(n);
     const u32 bpw = pl.buckets_per_window;
@@ -216,19 +218,45 @@ static u32 hostsim_msm(const u64 *points, const u64 *scalars, u32 n, u32 heavy_m
                 entries[cur[b]++] = (i << 1) | neg;
             }
         }
-    std::vector<i32> buckets((size_t)pl.total_buckets * XY);
-    for (u32 key = 0; key < pl.total_buckets; key++) {
-        ec_xyzz<F> acc = ec_infinity<F>();
-        if (totals[key] >= heavy_min) {
-            for (u32 t = 0; t < heavy_threads; t++) {
-                ec_xyzz<F> part = ec_infinity<F>();
-                msm_bucket_lane<F>(part, points, entries.data(), offsets[key], t, totals[key], heavy_threads);
-                acc = ec_add(acc, part);
+    std::vector<i32> buckets((size_t)pl.total_buckets * XY, 0);       // zeroed = infinity, as the product memsets it
+    if (mode == 0) {
+        // the product path: converted points, slices of the sorted entries, combine
+        const u32 E = run, slices = (u32)(((u64)n * pl.windows + MSM_SLICE - 1) / MSM_SLICE);
+        std::vector<i32> cpoints((size_t)n * 2 * F::LIMBS), partials(((size_t)slices + 1) * 2 * XY, 0x5a5a5a5a);
+        for (u32 i = 0; i < n; i++) msm_convert_point<F>(cpoints.data() + (size_t)i * 2 * F::LIMBS, points, i);
+        for (u32 lane = 0; lane < slices; lane++)
+            msm_slice_lane<F>(cpoints.data(), entries.data(), offsets.data(), pl.total_buckets, E, lane, buckets.data(), partials.data());
+        for (u32 key = 0; key < pl.total_buckets; key++) {
+            u32 la, lb, which;
+            if (!msm_combine_span<F>(offsets.data(), totals.data(), key, la, lb, which)) continue;
+            if (lb - la + 1 > heavy_min) {      // the heavy-combine kernel: strided partial sums, then their sum
+                ec_xyzz<F> acc = ec_infinity<F>();
+                for (u32 t = 0; t < heavy_threads; t++) {
+                    ec_xyzz<F> part = ec_infinity<F>();
+                    for (u32 j = la + t; j <= lb; j += heavy_threads)
+                        part = ec_add(part, msm_load_xyzz<F>(partials.data() + ((size_t)2 * j + (j == la ? which : 0u)) * XY));
+                    acc = ec_add(acc, part);
+                }
+                msm_store_xyzz<F>(buckets.data() + (size_t)key * XY, acc);
+            } else {
+                msm_combine_lane<F>(offsets.data(), totals.data(), key, partials.data(), buckets.data());
             }
-        } else {
-            msm_bucket_lane<F>(acc, points, entries.data(), offsets[key], 0, totals[key], 1);
         }
-        msm_store_xyzz<F>(buckets.data() + (size_t)key * XY, acc);
+    } else {
+        // one lane per bucket on the raw points (msm_bucket_lane; the strided form above `heavy_min` entries)
+        for (u32 key = 0; key < pl.total_buckets; key++) {
+            ec_xyzz<F> acc = ec_infinity<F>();
+            if (totals[key] >= heavy_min) {
+                for (u32 t = 0; t < heavy_threads; t++) {
+                    ec_xyzz<F> part = ec_infinity<F>();
+                    msm_bucket_lane<F>(part, points, entries.data(), offsets[key], t, totals[key], heavy_threads);
+                    acc = ec_add(acc, part);
+                }
+            } else {
+                msm_bucket_lane<F>(acc, points, entries.data(), offsets[key], 0, totals[key], 1);
+            }
+            msm_store_xyzz<F>(buckets.data() + (size_t)key * XY, acc);
+        }
     }
     u32 seg_per_window = (bpw + MSM_SEG - 1) / MSM_SEG;
     ec_xyzz<F> total = ec_infinity<F>();
@@ -241,11 +269,11 @@ static u32 hostsim_msm(const u64 *points, const u64 *scalars, u32 n, u32 heavy_m
     return ec_to_affine_gnark(out, total);
 }
 extern "C" {
-u32 hostsim_msm_g1(const u64 *points, const u64 *scalars, u32 n, u32 heavy_min, u32 heavy_threads, u32 *out16) {
-    return hostsim_msm<FpField>(points, scalars, n, heavy_min, heavy_threads, out16);
+u32 hostsim_msm_g1(const u64 *points, const u64 *scalars, u32 n, u32 mode, u32 heavy_min, u32 heavy_threads, u32 *out16) {
+    return hostsim_msm<FpField>(points, scalars, n, mode, heavy_min, heavy_threads, out16);
 }
-u32 hostsim_msm_g2(const u64 *points, const u64 *scalars, u32 n, u32 heavy_min, u32 heavy_threads, u32 *out32) {
-    return hostsim_msm<Fp2Field>(points, scalars, n, heavy_min, heavy_threads, out32);
+u32 hostsim_msm_g2(const u64 *points, const u64 *scalars, u32 n, u32 mode, u32 heavy_min, u32 heavy_threads, u32 *out32) {
+    return hostsim_msm<Fp2Field>(points, scalars, n, mode, heavy_min, heavy_threads, out32);
 }
 void hostsim_msm_plan(u64 n, u32 *out8) {
     msm_plan pl = msm_make_plan(n);

@@ -35,15 +35,16 @@ def _scalars(kind, n, rng):
     return np.array([[(v >> (64 * k)) & (2**64 - 1) for k in range(4)] for v in vals], dtype=np.uint64)
 
 
-def _run(hostsim, pts, sc, heavy_min=1 << 30, heavy_threads=4):
+def _run(hostsim, pts, sc, mode=0, heavy_min=1 << 30, heavy_threads=4):
     n = pts.shape[0]
     out = (ctypes.c_uint32 * 16)()
-    inf = hostsim.hostsim_msm_g1(pts.ctypes.data_as(ctypes.c_void_p), sc.ctypes.data_as(ctypes.c_void_p), n, heavy_min, heavy_threads, out)
+    inf = hostsim.hostsim_msm_g1(pts.ctypes.data_as(ctypes.c_void_p), sc.ctypes.data_as(ctypes.c_void_p), n, mode, heavy_min, heavy_threads, out)
     got = np.array([out[2 * i] | (out[2 * i + 1] << 32) for i in range(8)], dtype=np.uint64)
     return got, bool(inf)
 
 
-@pytest.mark.parametrize("kind,n", [("uniform", 300), ("witness", 300), ("equal", 200), ("top", 70), ("uniform", 2500), ("uniform", 1)])
+@pytest.mark.parametrize("kind,n", [("uniform", 300), ("witness", 300), ("equal", 200), ("top", 70), ("uniform", 2500), ("uniform", 1),
+                                    ("equal", 3000), ("witness", 5000)])
 def test_msm_lane_walk_matches_oracle(hostsim, kind, n):
     rng = np.random.default_rng(5 + n)
     pts = cport.bn254_gen_points(n, 5, 3)
@@ -55,9 +56,12 @@ def test_msm_lane_walk_matches_oracle(hostsim, kind, n):
     want, winf, _ = cport.bn254_msm(pts[live], _reduced(sc[live]), naive=True)
     got, inf = _run(hostsim, pts, sc)
     assert inf == winf and (inf or np.array_equal(got, want))
-    # the strided form of the heavy-bucket kernel (every bucket with >= 2 entries, 3 partial sums) gives the same point
-    got2, inf2 = _run(hostsim, pts, sc, heavy_min=2, heavy_threads=3)
+    # the workgroup form of the combine (every bucket cut into >= 2 slices, 3 strided partial sums) gives the same point
+    got2, inf2 = _run(hostsim, pts, sc, heavy_min=1, heavy_threads=3)
     assert inf2 == inf and np.array_equal(got2, got)
+    # and so does the one-lane-per-bucket walk on the raw points
+    got3, inf3 = _run(hostsim, pts, sc, mode=1, heavy_min=2, heavy_threads=3)
+    assert inf3 == inf and np.array_equal(got3, got)
 
 
 def _reduced(sc):

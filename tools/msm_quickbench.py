@@ -10,7 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import zklc_amd  # noqa: E402
 from oracle import cport  # noqa: E402
 
-logs = [int(x) for x in sys.argv[1:]] or [16, 18, 20, 22]
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+variants = next((a.split("=", 1)[1].split(",") for a in sys.argv[1:] if a.startswith("--variants=")), [None])
+logs = [int(x) for x in args] or [16, 18, 20, 22]
 nmax = 1 << max(logs)
 t0 = time.time()
 pts_h = cport.bn254_gen_points(nmax, 5, 3)
@@ -22,7 +24,9 @@ pts = torch.from_numpy(pts_h.view(np.int64)).cuda()
 sc = torch.from_numpy(sc_h.view(np.int64)).cuda()
 with zklc_amd.Context(0) as c:
     st = torch.cuda.Stream()
-    for lg in logs:
+    for lg, variant in [(lg, v) for lg in logs for v in variants]:
+        if variant is not None:
+            os.environ["ZKLC_MSM_WAVES"] = variant       # A/B switch of the slice kernel (waves per SIMD), read by the library at every call
         n = 1 << lg
         wb = c.bn254_g1_msm_workspace_bytes(n)
         ws = torch.empty(wb, dtype=torch.uint8, device="cuda")
@@ -39,7 +43,8 @@ with zklc_amd.Context(0) as c:
         e1.record(st)
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
-        print("MSM 2^%d: %.2f ms  %.2f Melem/s  workspace %.0f MB" % (lg, ms, n / ms / 1e3, wb / 1e6), flush=True)
+        print("MSM 2^%d%s: %.2f ms  %.2f Melem/s  workspace %.0f MB" % (lg, "" if variant is None else " [slice kernel, %s waves per SIMD]" % variant,
+                                                                         ms, n / ms / 1e3, wb / 1e6), flush=True)
         if lg <= 20:
             t0 = time.time()
             want, winf, used = cport.bn254_msm(pts_h[:n], sc_h[:n], nthreads=16)

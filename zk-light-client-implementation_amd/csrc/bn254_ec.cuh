@@ -120,27 +120,38 @@ ZKLC_HD ec_xyzz<F> ec_double_affine(const typename F::T &x, const typename F::T 
     return r;
 }
 
+// the exceptional cases of p + (x2, y2): p at infinity, P = Q (doubling) and P = -Q.  Kept out of line: the bucket loops of the MSM
+// meet them once per bucket (the first point) or never, and inlined they doubled the loop's code and put its result through scratch.
+template <class F>
+#if defined(__HIPCC__)
+__device__ __attribute__((noinline))
+#else
+static
+#endif
+void ec_add_affine_special(ec_xyzz<F> &r, const ec_xyzz<F> &p, const typename F::T &x2, const typename F::T &y2, u32 p_inf, u32 same_y) {
+    if (p_inf) {
+        r.X = F::reduce(x2);
+        r.Y = F::reduce(y2);
+        r.ZZ = F::one();
+        r.ZZZ = F::one();
+    } else if (same_y) {
+        r = ec_double_affine<F>(F::reduce(x2), F::reduce(y2));
+    } else {
+        r = ec_infinity<F>();
+    }
+}
+
 // p + (x2, y2), (x2, y2) affine and finite (lazy from_gnark values allowed); neg = 1 adds (x2, -y2)
 template <class F>
 ZKLC_HD ec_xyzz<F> ec_add_affine(const ec_xyzz<F> &p, const typename F::T &x2, const typename F::T &y2in, u32 neg) {
     typedef typename F::T T;
     T y2 = F::select(y2in, F::neg(y2in), neg);
-    if (ec_is_inf(p)) {
-        ec_xyzz<F> r;
-        r.X = F::reduce(x2);
-        r.Y = F::reduce(y2);
-        r.ZZ = F::one();
-        r.ZZZ = F::one();
-        return r;
-    }
     T U2 = F::mul(x2, p.ZZ);
     T S2 = F::mul(y2, p.ZZZ);
     T Pp = F::sub(U2, p.X);
     T R = F::sub(S2, p.Y);
-    if (F::is_zero(Pp)) {  // same x: P = +-Q
-        if (F::is_zero(R)) return ec_double_affine<F>(F::reduce(x2), F::reduce(y2));
-        return ec_infinity<F>();
-    }
+    u32 p_inf = ec_is_inf(p);
+    u32 special = p_inf | F::is_zero(Pp);  // same x: P = +-Q
     T PP = F::sqr(Pp);
     T PPP = F::mul(Pp, PP);
     T Q = F::mul(p.X, PP);
@@ -149,6 +160,12 @@ ZKLC_HD ec_xyzz<F> ec_add_affine(const ec_xyzz<F> &p, const typename F::T &x2, c
     r.Y = F::sub(F::mul(R, F::sub(Q, r.X)), F::mul(p.Y, PPP));
     r.ZZ = F::mul(p.ZZ, PP);
     r.ZZZ = F::mul(p.ZZZ, PPP);
+    if (special) {      // copies: only THEY have their address taken (the loop's own values stay in registers)
+        ec_xyzz<F> pc = p, rc;
+        T xc = x2, yc = y2;
+        ec_add_affine_special<F>(rc, pc, xc, yc, p_inf, F::is_zero(R));
+        r = rc;
+    }
     return r;
 }
 
@@ -156,18 +173,14 @@ ZKLC_HD ec_xyzz<F> ec_add_affine(const ec_xyzz<F> &p, const typename F::T &x2, c
 template <class F>
 ZKLC_HD ec_xyzz<F> ec_add(const ec_xyzz<F> &p, const ec_xyzz<F> &q) {
     typedef typename F::T T;
-    if (ec_is_inf(p)) return q;
-    if (ec_is_inf(q)) return p;
+    u32 p_inf = ec_is_inf(p), q_inf = ec_is_inf(q);
     T U1 = F::mul(p.X, q.ZZ);
     T U2 = F::mul(q.X, p.ZZ);
     T S1 = F::mul(p.Y, q.ZZZ);
     T S2 = F::mul(q.Y, p.ZZZ);
     T Pp = F::sub(U2, U1);
     T R = F::sub(S2, S1);
-    if (F::is_zero(Pp)) {
-        if (F::is_zero(R)) return ec_double(p);
-        return ec_infinity<F>();
-    }
+    u32 same_x = F::is_zero(Pp);
     T PP = F::sqr(Pp);
     T PPP = F::mul(Pp, PP);
     T Q = F::mul(U1, PP);
@@ -176,6 +189,12 @@ ZKLC_HD ec_xyzz<F> ec_add(const ec_xyzz<F> &p, const ec_xyzz<F> &q) {
     r.Y = F::sub(F::mul(R, F::sub(Q, r.X)), F::mul(S1, PPP));
     r.ZZ = F::mul(F::mul(p.ZZ, q.ZZ), PP);
     r.ZZZ = F::mul(F::mul(p.ZZZ, q.ZZZ), PPP);
+    if (p_inf | q_inf | same_x) {
+        if (p_inf) r = q;
+        else if (q_inf) r = p;
+        else if (F::is_zero(R)) r = ec_double(p);
+        else r = ec_infinity<F>();
+    }
     return r;
 }
 

@@ -12,10 +12,10 @@
 //      LDS (128 KiB at c = 16): histogram per tile -> prefix over the chunks + bucket totals -> exclusive scan of the totals ->
 //      scatter of (point index, sign) entries through LDS cursors.  Round 1 did both passes with one global atomic per
 //      (scalar, window): 5.7 of the 27 ms of a 2^22 MSM.
-//   3. bucket accumulation: one LANE per bucket walks its entries and adds the affine points (extended-Jacobian mixed addition),
-//      the gathers software-pipelined one iteration ahead; a lane takes two buckets (key and key + total/2) so that the
-//      Poisson spread of the bucket sizes evens out inside a wave; buckets with more than MSM_HEAVY entries (skewed scalars,
-//      e.g. many equal to 1) go to a workgroup-per-bucket kernel with an LDS tree reduction instead
+//   3. bucket accumulation over SLICES of the sorted entries: a lane adds exactly MSM_SLICE consecutive entries (extended-Jacobian
+//      mixed additions, the gathers software-pipelined one iteration ahead), whatever buckets they belong to -- whole buckets are
+//      stored, the pieces cut by slice boundaries are added by a one-lane-per-bucket pass (a workgroup for buckets cut into many
+//      slices: skewed scalars, e.g. many equal to 1).  Every lane does the same work for ANY digit distribution.
 //   4. bucket reduction: per window, segments of MSM_SEG buckets -> running-sum trick + small scalar multiple (one lane per
 //      segment), then an LDS tree over the segments
 //   5. 2^(c w) * window_w by doublings (one lane per window), tree sum, affine output
@@ -26,7 +26,7 @@
 #include <stdlib.h>
 
 #define MSM_SORT_THREADS 1024
-#define MSM_BUCKET_WAVES_G1 2
+#define MSM_SLICE_WAVES_G1 2
 
 // ---- 1. recode
 template <int AFF>
@@ -171,44 +171,44 @@ __global__ void __launch_bounds__(256) msm_scan_add_kernel(u32 *out, const u32 *
     if (i < n) out[i] += block_sums[i / SCAN_ITEMS];
 }
 
-// ---- 3. bucket accumulation (template over the coordinate field F: FpField = G1, Fp2Field = G2; WAVES = the occupancy the
-// register allocation is asked to keep, PIPE = gathers one iteration ahead)
-template <class F, int WAVES, bool PIPE>
-__global__ void __launch_bounds__(64, WAVES)
-msm_bucket_sum_kernel(const u64 *__restrict__ points, const u32 *__restrict__ entries, const u32 *__restrict__ offsets,
-                      const u32 *__restrict__ counts, msm_plan pl, i32 *__restrict__ buckets, u32 *__restrict__ heavy_list,
-                      u32 *__restrict__ heavy_count) {
+// ---- 3. bucket accumulation over SLICES of the sorted entries (bn254_msm_lane.cuh: msm_slice_lane), template over the coordinate
+// field F (FpField = G1, Fp2Field = G2); WAVES = the occupancy the register allocation is asked to keep
+template <class F>
+__global__ void __launch_bounds__(256) msm_convert_kernel(const u64 *__restrict__ points, u32 n, i32 *__restrict__ cpoints) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) msm_convert_point<F>(cpoints + (size_t)i * 2 * F::LIMBS, points, i);
+}
+
+#define MSM_SLICE_BLOCK 256
+template <class F, int WAVES>
+__global__ void __launch_bounds__(MSM_SLICE_BLOCK, WAVES)
+msm_slice_kernel(const i32 *__restrict__ cpoints, const u32 *__restrict__ entries, const u32 *__restrict__ offsets,
+                 const u32 *__restrict__ counts, msm_plan pl, i32 *__restrict__ buckets, i32 *__restrict__ partials) {
     u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
-    u32 half = (pl.total_buckets + 1) / 2;
-    if (lane >= half) return;
-#pragma unroll 1
-    for (u32 part = 0; part < 2; part++) {
-        u32 key = lane + part * half;
-        if (key >= pl.total_buckets) break;
-        u32 cnt = counts[key];
-        if (cnt > MSM_HEAVY) {
-            u32 slot = atomicAdd(heavy_count, 1u);
-            if (slot < MSM_MAX_HEAVY) {
-                heavy_list[slot] = key;
-                continue;  // the heavy kernel writes this bucket
-            }
-            // list full: fall through and do it here (slow but correct)
+    u32 T = pl.total_buckets;
+    u32 E = offsets[T - 1] + counts[T - 1];
+    msm_slice_lane<F>(cpoints, entries, offsets, T, E, lane, buckets, partials);
+}
+
+// one lane per bucket: the sum of the partials of a bucket cut by slice boundaries (usually two of them); buckets cut into more
+// than MSM_COMBINE_SERIAL slices (skewed scalars: many equal digits) go on the list of the workgroup-per-bucket kernel
+template <class F>
+__global__ void __launch_bounds__(64)
+msm_combine_kernel(const u32 *__restrict__ offsets, const u32 *__restrict__ counts, msm_plan pl, const i32 *__restrict__ partials,
+                   i32 *__restrict__ buckets, u32 *__restrict__ heavy_list, u32 *__restrict__ heavy_count) {
+    u32 key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= pl.total_buckets) return;
+    u32 la, lb, which;
+    if (!msm_combine_span<F>(offsets, counts, key, la, lb, which)) return;
+    if (lb - la + 1 > MSM_COMBINE_SERIAL) {
+        u32 slot = atomicAdd(heavy_count, 1u);
+        if (slot < MSM_MAX_HEAVY) {
+            heavy_list[slot] = key;
+            return;
         }
-        ec_xyzz<F> acc = ec_infinity<F>();
-        u32 beg = offsets[key];
-        if (PIPE) {
-            msm_bucket_lane<F>(acc, points, entries, beg, 0, cnt, 1);
-        } else {
-#pragma unroll 1
-            for (u32 e = 0; e < cnt; e++) {
-                u32 ent = entries[beg + e];
-                typename F::T x, y;
-                msm_load_point<F>(points, ent >> 1, x, y);
-                acc = ec_add_affine<F>(acc, x, y, ent & 1);
-            }
-        }
-        msm_store_xyzz<F>(buckets + (size_t)key * msm_cfg<F>::XYZZ, acc);
+        // list full: fall through and do it here (slow but correct)
     }
+    msm_combine_lane<F>(offsets, counts, key, partials, buckets);
 }
 
 // LDS tree reduction of one XYZZ point per thread (BLOCK threads); result in thread 0
@@ -226,19 +226,21 @@ ZKLC_D ec_xyzz<F> msm_block_reduce(ec_xyzz<F> acc, i32 *lds /* BLOCK * XYZZ word
 
 template <class F>
 __global__ void __launch_bounds__(msm_cfg<F>::BLOCK)
-msm_heavy_bucket_kernel(const u64 *__restrict__ points, const u32 *__restrict__ entries, const u32 *__restrict__ offsets,
-                        const u32 *__restrict__ counts, i32 *__restrict__ buckets, const u32 *__restrict__ heavy_list,
-                        const u32 *__restrict__ heavy_count) {
+msm_heavy_combine_kernel(const u32 *__restrict__ offsets, const u32 *__restrict__ counts, const i32 *__restrict__ partials,
+                         i32 *__restrict__ buckets, const u32 *__restrict__ heavy_list, const u32 *__restrict__ heavy_count) {
+    const int XY = msm_cfg<F>::XYZZ;
     __shared__ i32 lds[msm_cfg<F>::BLOCK * msm_cfg<F>::XYZZ];
     u32 nheavy = *heavy_count;
     if (nheavy > MSM_MAX_HEAVY) nheavy = MSM_MAX_HEAVY;
     if (blockIdx.x >= nheavy) return;
     u32 key = heavy_list[blockIdx.x];
-    u32 beg = offsets[key], cnt = counts[key];
+    u32 la, lb, which;
+    msm_combine_span<F>(offsets, counts, key, la, lb, which);
     ec_xyzz<F> acc = ec_infinity<F>();
-    msm_bucket_lane<F>(acc, points, entries, beg, threadIdx.x, cnt, msm_cfg<F>::BLOCK);
+    for (u32 j = la + threadIdx.x; j <= lb; j += msm_cfg<F>::BLOCK)
+        acc = ec_add(acc, msm_load_xyzz<F>(partials + ((size_t)2 * j + (j == la ? which : 0u)) * XY));
     acc = msm_block_reduce<F>(acc, lds);
-    if (threadIdx.x == 0) msm_store_xyzz<F>(buckets + (size_t)key * msm_cfg<F>::XYZZ, acc);
+    if (threadIdx.x == 0) msm_store_xyzz<F>(buckets + (size_t)key * XY, acc);
 }
 
 // ---- 4. one lane per segment of MSM_SEG buckets
@@ -299,6 +301,8 @@ static uint64_t msm_workspace_bytes(uint64_t n) {
     b += (uint64_t)pl.n_pad * pl.windows * 2;           // digit codes
     b += n * pl.windows * 4 + 4;                        // entries
     b += total * XB;                                    // buckets
+    b += n * 2 * F::LIMBS * 4;                          // converted points
+    b += ((n * pl.windows + MSM_SLICE - 1) / MSM_SLICE + 1) * 2 * XB;   // slice partials
     b += (uint64_t)seg_per_window * pl.windows * XB;    // segment sums
     b += (uint64_t)pl.windows * XB;                     // window sums
     b += (MSM_MAX_HEAVY + 4) * 4;                       // heavy list + counter
@@ -346,6 +350,9 @@ static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points
     u32 *heavy_list = (u32 *)take(MSM_MAX_HEAVY * 4);
     u32 *entries = (u32 *)take((size_t)n * pl.windows * 4 + 4);
     i32 *buckets = (i32 *)take((size_t)pl.total_buckets * XB);
+    i32 *cpoints = (i32 *)take((size_t)n * 2 * F::LIMBS * 4);
+    const u32 slices = (u32)(((uint64_t)n * pl.windows + MSM_SLICE - 1) / MSM_SLICE);
+    i32 *partials = (i32 *)take(((size_t)slices + 1) * 2 * XB);
     i32 *seg_out = (i32 *)take((size_t)seg_per_window * pl.windows * XB);
     i32 *win_out = (i32 *)take((size_t)pl.windows * XB);
     const int BLK = msm_cfg<F>::BLOCK;
@@ -368,42 +375,33 @@ static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points
         hipLaunchKernelGGL(msm_scatter_kernel, dim3(pl.chunks, pl.windows), dim3(MSM_SORT_THREADS), lds, st, (const unsigned short *)dig, pl,
                            (const u32 *)tile_cnt, (const u32 *)offsets, entries);
     }
-    u32 half = (pl.total_buckets + 1) / 2;
-    // variants of the bucket kernel (A/B switch ZKLC_MSM_BUCKET = <waves 1..4><p|n>, e.g. "2p"; default per field below)
-    {
-        const char *v = getenv("ZKLC_MSM_BUCKET");
-        int waves = F::LIMBS == 10 ? MSM_BUCKET_WAVES_G1 : 1;
-        bool pipe = true;
-        if (v && v[0] >= '1' && v[0] <= '4') {
-            waves = v[0] - '0';
-            pipe = v[1] != 'n';
-        }
+    // the bucket array starts as infinity (all-zero limbs): empty buckets are never written
+    ZKLC_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)pl.total_buckets * XB, st));
+    if (pl.n) {
+        hipLaunchKernelGGL(msm_convert_kernel<F>, dim3((pl.n + 255) / 256), dim3(256), 0, st, d_points, pl.n, cpoints);
+        // A/B switch ZKLC_MSM_WAVES = 1..3: waves per SIMD the slice kernel's register allocation keeps (default per field)
+        const char *v = getenv("ZKLC_MSM_WAVES");
+        int waves = (v && v[0] >= '1' && v[0] <= '3') ? v[0] - '0' : MSM_SLICE_WAVES_G1;
         if (F::LIMBS != 10) waves = 1;       // the Fp2 kernel needs the whole register file
-        dim3 g((half + 63) / 64), b(64);
-#define MSM_BUCKET_LAUNCH(W, P)                                                                                                  \
-    hipLaunchKernelGGL((msm_bucket_sum_kernel<F, W, P>), g, b, 0, st, d_points, (const u32 *)entries, (const u32 *)offsets,       \
-                       (const u32 *)totals, pl, buckets, heavy_list, heavy_count)
-        if (F::LIMBS != 10) {
-            if (pipe) MSM_BUCKET_LAUNCH(1, true); else MSM_BUCKET_LAUNCH(1, false);
-        } else if (pipe) {
-            switch (waves) {
-                case 1: MSM_BUCKET_LAUNCH(1, true); break;
-                case 2: MSM_BUCKET_LAUNCH(2, true); break;
-                case 3: MSM_BUCKET_LAUNCH(3, true); break;
-                default: MSM_BUCKET_LAUNCH(4, true); break;
-            }
+        dim3 g((slices + MSM_SLICE_BLOCK - 1) / MSM_SLICE_BLOCK), b(MSM_SLICE_BLOCK);
+#define MSM_SLICE_LAUNCH(W)                                                                                                   \
+    hipLaunchKernelGGL((msm_slice_kernel<F, W>), g, b, 0, st, (const i32 *)cpoints, (const u32 *)entries, (const u32 *)offsets, \
+                       (const u32 *)totals, pl, buckets, partials)
+        if constexpr (F::LIMBS != 10) {
+            MSM_SLICE_LAUNCH(1);
         } else {
             switch (waves) {
-                case 1: MSM_BUCKET_LAUNCH(1, false); break;
-                case 2: MSM_BUCKET_LAUNCH(2, false); break;
-                case 3: MSM_BUCKET_LAUNCH(3, false); break;
-                default: MSM_BUCKET_LAUNCH(4, false); break;
+                case 1: MSM_SLICE_LAUNCH(1); break;
+                case 3: MSM_SLICE_LAUNCH(3); break;
+                default: MSM_SLICE_LAUNCH(2); break;
             }
         }
-#undef MSM_BUCKET_LAUNCH
+#undef MSM_SLICE_LAUNCH
     }
-    hipLaunchKernelGGL(msm_heavy_bucket_kernel<F>, dim3(MSM_MAX_HEAVY), dim3(BLK), 0, st, d_points, (const u32 *)entries,
-                       (const u32 *)offsets, (const u32 *)totals, buckets, (const u32 *)heavy_list, (const u32 *)heavy_count);
+    hipLaunchKernelGGL(msm_combine_kernel<F>, dim3((pl.total_buckets + 63) / 64), dim3(64), 0, st, (const u32 *)offsets, (const u32 *)totals,
+                       pl, (const i32 *)partials, buckets, heavy_list, heavy_count);
+    hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(MSM_MAX_HEAVY), dim3(BLK), 0, st, (const u32 *)offsets, (const u32 *)totals,
+                       (const i32 *)partials, buckets, (const u32 *)heavy_list, (const u32 *)heavy_count);
     hipLaunchKernelGGL(msm_segment_kernel<F>, dim3((seg_per_window * pl.windows + 63) / 64), dim3(64), 0, st, (const i32 *)buckets, pl,
                        seg_out);
     hipLaunchKernelGGL(msm_window_kernel<F>, dim3(pl.windows), dim3(BLK), 0, st, (const i32 *)seg_out, pl, win_out);

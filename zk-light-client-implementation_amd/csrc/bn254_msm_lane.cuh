@@ -7,8 +7,7 @@
 #include "bn254_ec.cuh"
 
 #define MSM_MAX_WINDOWS 32
-#define MSM_HEAVY 4096u      // buckets with more entries go to the workgroup-per-bucket kernel
-#define MSM_MAX_HEAVY 2048u
+#define MSM_MAX_HEAVY 2048u  // buckets cut into more than MSM_COMBINE_SERIAL slices (skewed scalars): summed by a workgroup each
 #define MSM_SEG 16u          // buckets per running-sum segment (one lane each)
 
 struct msm_plan {
@@ -141,10 +140,9 @@ ZKLC_HD ec_xyzz<F> msm_load_xyzz(const i32 *src) {
     return p;
 }
 
-// acc += the `cnt` points listed in entries[beg ..) (entry = point index << 1 | negate), `step` apart (1: a lane owns the bucket;
-// the workgroup size in the heavy-bucket kernel).  Software-pipelined: the raw words of the NEXT point and the entry after it are
-// requested before the current addition starts, so the two dependent gathers (entry -> point) of an iteration overlap ~3 000
-// instructions of field arithmetic instead of stalling every wave of the SIMD at the same place.
+// acc += the `cnt` points listed in entries[beg ..) (entry = point index << 1 | negate), `step` apart.  Software-pipelined: the raw
+// words of the NEXT point and the entry after it are requested before the current addition starts.  (The strided form is what a
+// workgroup of the heavy-combine kernel would do on raw entries; the product path is msm_slice_lane below.)
 template <class F>
 ZKLC_HD void msm_bucket_lane(ec_xyzz<F> &acc, const u64 *points, const u32 *entries, u32 beg, u32 first, u32 cnt, u32 step) {
     if (first >= cnt) return;
@@ -167,6 +165,143 @@ ZKLC_HD void msm_bucket_lane(ec_xyzz<F> &acc, const u64 *points, const u32 *entr
         ent_cur = ent_next;
         ent_next = ent_next2;
     }
+}
+
+// ---- the product path of the bucket accumulation: SLICES of the sorted entry list
+// Lane L owns entries [L * MSM_SLICE, (L + 1) * MSM_SLICE) of the list sorted by (window, bucket), whatever buckets they belong to:
+// every lane performs exactly MSM_SLICE additions, so neither the Poisson spread of the bucket sizes (+22 % per wave with one lane
+// per bucket) nor the skew of the top window (254 = 15 * 16 + 14: its buckets are 4-8 x heavier and used to run as a long tail on
+// a few waves while the chip was idle -- round 3, profiles/r03f) costs anything.  Inside its slice a lane walks bucket segments:
+// a segment that is a WHOLE bucket is stored to the bucket array, the (at most two) segments cut by the slice boundaries go to
+// partials[2 * lane + (not the lane's first segment)]; msm_combine_lane adds the partials of a bucket.  Points are read in the
+// converted form (msm_convert_point: reduced internal limbs, x then y), so a segment starts by COPYING its first point -- chosen by
+// a flag, no branch: the generic addition is computed and discarded -- and the loop has no infinity case.
+#define MSM_SLICE 128u
+#define MSM_COMBINE_SERIAL 32u    // buckets cut into more slices than this are summed by a workgroup (heavy-combine kernel)
+
+template <class F>
+ZKLC_HD void msm_convert_point(i32 *dst, const u64 *points, u32 idx) {
+    typename F::T x, y;
+    msm_load_point<F>(points, idx, x, y);
+    F::store(dst, F::reduce(x));
+    F::store(dst + F::LIMBS, F::reduce(y));
+}
+
+template <class F>
+struct msm_cpoint {
+    i32 w[2 * F::LIMBS];
+};
+template <class F>
+ZKLC_HD void msm_fetch_cpoint(msm_cpoint<F> &r, const i32 *cpoints, u32 idx) {
+    const int W = 2 * F::LIMBS;
+#if defined(__HIPCC__)
+    const int4 *p = reinterpret_cast<const int4 *>(cpoints + (size_t)idx * W);
+#pragma unroll
+    for (int k = 0; k < W / 4; k++) {
+        int4 a = p[k];
+        r.w[4 * k] = a.x;
+        r.w[4 * k + 1] = a.y;
+        r.w[4 * k + 2] = a.z;
+        r.w[4 * k + 3] = a.w;
+    }
+#else
+    for (int k = 0; k < W; k++) r.w[k] = cpoints[(size_t)idx * W + k];
+#endif
+}
+
+template <class F>
+ZKLC_HD ec_xyzz<F> msm_select_xyzz(const ec_xyzz<F> &a, const ec_xyzz<F> &b, u32 take_b) {
+    ec_xyzz<F> r;
+    r.X = F::select(a.X, b.X, take_b);
+    r.Y = F::select(a.Y, b.Y, take_b);
+    r.ZZ = F::select(a.ZZ, b.ZZ, take_b);
+    r.ZZZ = F::select(a.ZZZ, b.ZZZ, take_b);
+    return r;
+}
+
+// offsets[0 .. T): exclusive scan of the bucket sizes; E = number of entries.  One call = one lane.
+template <class F>
+ZKLC_HD void msm_slice_lane(const i32 *cpoints, const u32 *entries, const u32 *offsets, u32 T, u32 E, u32 lane, i32 *buckets,
+                            i32 *partials) {
+    const int XY = msm_cfg<F>::XYZZ;
+    const u32 lo = lane * MSM_SLICE;
+    if (lo >= E) return;
+    const u32 hi = lo + MSM_SLICE < E ? lo + MSM_SLICE : E;
+    // the bucket holding entry lo: the largest key with offsets[key] <= lo (its successor starts beyond lo, so it is not empty)
+    u32 a = 0, b = T;
+    while (b - a > 1) {
+        u32 m = (a + b) >> 1;
+        if (offsets[m] <= lo) a = m; else b = m;
+    }
+    u32 key = a;
+    u32 seg_start_in_slice = offsets[key] >= lo;      // the first segment starts a bucket only if the bucket starts at lo
+    u32 end = key + 1 < T ? offsets[key + 1] : E;
+    u32 seg_end = end < hi ? end : hi;
+    u32 first_seg = 1, fresh = 1;
+    ec_xyzz<F> acc;
+    acc.X = acc.Y = acc.ZZ = acc.ZZZ = F::one();      // any finite value: discarded by the first (fresh) step
+    u32 ent_cur = entries[lo];
+    msm_cpoint<F> raw_cur;
+    msm_fetch_cpoint<F>(raw_cur, cpoints, ent_cur >> 1);
+    u32 ent_next = lo + 1 < hi ? entries[lo + 1] : 0;
+    for (u32 e = lo; e < hi; e++) {
+        msm_cpoint<F> raw_next = raw_cur;
+        u32 ent_next2 = 0;
+        if (e + 1 < hi) {
+            msm_fetch_cpoint<F>(raw_next, cpoints, ent_next >> 1);
+            if (e + 2 < hi) ent_next2 = entries[e + 2];
+        }
+        typename F::T x = F::load(raw_cur.w), y = F::load(raw_cur.w + F::LIMBS);
+        y = F::select(y, F::neg(y), ent_cur & 1);
+        ec_xyzz<F> started;                            // the segment's first point as an accumulator
+        started.X = x;
+        started.Y = y;
+        started.ZZ = started.ZZZ = F::one();
+        ec_xyzz<F> sum = ec_add_affine<F>(acc, x, y, 0);
+        acc = msm_select_xyzz<F>(sum, started, fresh);
+        fresh = 0;
+        if (e + 1 == seg_end) {                        // segment complete (a few lanes of a wave per iteration)
+            u32 whole = seg_start_in_slice & (seg_end == end);
+            i32 *dst = whole ? buckets + (size_t)key * XY : partials + ((size_t)2 * lane + (first_seg ^ 1)) * XY;
+            msm_store_xyzz<F>(dst, acc);
+            first_seg = 0;
+            fresh = 1;
+            seg_start_in_slice = 1;
+            if (e + 1 < hi) {
+                do {                                   // next non-empty bucket (it exists: entry e + 1 belongs to one)
+                    key++;
+                    end = key + 1 < T ? offsets[key + 1] : E;
+                } while (end <= e + 1);
+                seg_end = end < hi ? end : hi;
+            }
+        }
+        raw_cur = raw_next;
+        ent_cur = ent_next;
+        ent_next = ent_next2;
+    }
+}
+
+// bucket `key`: nothing to do when it lies inside one slice (stored whole) or is empty (the bucket array starts zeroed = infinity);
+// otherwise the sum of its partials.  Returns 1 if the bucket is cut into more than MSM_COMBINE_SERIAL slices (left to the
+// heavy-combine kernel), 0 otherwise.
+template <class F>
+ZKLC_HD u32 msm_combine_span(const u32 *offsets, const u32 *counts, u32 key, u32 &la, u32 &lb, u32 &first_which) {
+    u32 cnt = counts[key];
+    if (cnt == 0) return 0;
+    u32 b0 = offsets[key], end = b0 + cnt;
+    la = b0 / MSM_SLICE;
+    lb = (end - 1) / MSM_SLICE;
+    first_which = b0 != la * MSM_SLICE;               // not the first segment of slice la unless the bucket starts the slice
+    return lb > la;
+}
+template <class F>
+ZKLC_HD void msm_combine_lane(const u32 *offsets, const u32 *counts, u32 key, const i32 *partials, i32 *buckets) {
+    const int XY = msm_cfg<F>::XYZZ;
+    u32 la, lb, which;
+    if (!msm_combine_span<F>(offsets, counts, key, la, lb, which)) return;
+    ec_xyzz<F> acc = msm_load_xyzz<F>(partials + ((size_t)2 * la + which) * XY);
+    for (u32 j = la + 1; j <= lb; j++) acc = ec_add(acc, msm_load_xyzz<F>(partials + (size_t)2 * j * XY));
+    msm_store_xyzz<F>(buckets + (size_t)key * XY, acc);
 }
 
 // k * p for a small k (k < 2^31), double-and-add
