@@ -256,7 +256,7 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
     d_ws2 = torch.empty(wb2, dtype=torch.uint8, device=dev)
     d_final = torch.zeros(8, dtype=torch.int64, device=dev)
 
-    def msm_step():
+    def msm_step(d_pts=d_pts, d_sc=d_sc, n=n):
         ctx.bn254_g1_msm_dev(d_pts, d_sc, n, d_out, d_inf, d_ws, wb, stream=stream)
         if world > 1 and dist.get_backend() == "nccl":
             with torch.cuda.stream(stream):
@@ -281,6 +281,34 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
         assert np.array_equal(got, want), "GPU MSM differs from the oracle"
         msm["cpu_baseline"] = {"value": n / dt / 1e6, "unit": "Melem/s", "cores": used, "kind": "port",
                                "sample": "the same 2^%d-point MSM once, oracle/c/bn254_oracle.c (also the parity check)" % args.msm_log}
+    if world > 1 and dist.get_backend() == "nccl":
+        # STRONG form (distributed.msm_sharded): ONE 2^msm_log instance, index-sharded over the ranks; every rank reduces its
+        # shard to one point, the partials are all-gathered (world x 72 bytes over RCCL) and added locally.  Rank 0 also computes the
+        # whole instance alone: the sharded result must be the same affine point.
+        import importlib
+        DIST = importlib.import_module("zk-light-client-implementation_amd.distributed")
+        pts_all = cport.bn254_gen_points(n, 5, 3)
+        rng1 = np.random.default_rng(1)
+        sc_all = rng1.integers(0, 2**63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng1.integers(0, 2, size=(n, 4), dtype=np.uint64)
+        sc_all[:, 3] &= np.uint64((1 << 60) - 1)
+        lo_, hi_ = DIST.shard_range(n, rank, world)
+        d_ps = torch.from_numpy(pts_all[lo_:hi_].view(np.int64).copy()).to(dev)
+        d_ss = torch.from_numpy(sc_all[lo_:hi_].view(np.int64).copy()).to(dev)
+        step_s = lambda: msm_step(d_ps, d_ss, hi_ - lo_)
+        ms_s, wall_s = _time_stream(step_s, stream, 3, barrier)
+        ms_s, wall_s = reduce_max(ms_s), reduce_max(wall_s)
+        sharded = d_final.cpu().numpy().view(np.uint64).copy()
+        same = None
+        if rank == 0:
+            d_pa, d_sa = torch.from_numpy(pts_all.view(np.int64)).to(dev), torch.from_numpy(sc_all.view(np.int64)).to(dev)
+            ctx.bn254_g1_msm_dev(d_pa, d_sa, n, d_out, d_inf, d_ws, wb, stream=stream)
+            torch.cuda.synchronize()
+            same = bool(np.array_equal(d_out[:8].cpu().numpy().view(np.uint64), sharded))
+            del d_pa, d_sa
+        msm["strong"] = {"metric": "BN254 G1 MSM, ONE 2^%d instance index-sharded over %d GPUs (all-gather of the partial sums)" % (args.msm_log, world),
+                         "value": n / (wall_s * 1e-3) / 1e6, "unit": "Melem/s", "ms": wall_s, "kernel_ms": ms_s,
+                         "equals_single_gpu_result": same}
+        del d_ps, d_ss, pts_all, sc_all
     res["msm"] = msm
     del d_pts, d_sc, d_ws, pts_h, sc_h
     torch.cuda.empty_cache()
@@ -653,9 +681,15 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     # and the keys / stakes proof on the other ranks, the joins and the wrap on rank 0
     import importlib
     DIST = importlib.import_module("zk-light-client-implementation_amd.distributed")
-    strong = args.scaling == "strong" and world > 1
-    sig_lo, sig_hi = DIST.shard_range(n_sig, rank, world) if strong else (0, n_sig)
-    my_sigs = list(range(sig_lo, sig_hi))
+    # M = the mode of the block pipeline below (switched by set_mode between the weak and the strong section of a multi-GPU run)
+    M = {}
+
+    def set_mode(strong_):
+        M["strong"] = bool(strong_) and world > 1
+        lo_, hi_ = DIST.shard_range(n_sig, rank, world) if M["strong"] else (0, n_sig)
+        M["my_sigs"] = list(range(lo_, hi_))
+        M["hdr_owner"] = DIST.assign_jobs(list(hdr_jobs), world) if M["strong"] else {}
+        M["ks_rank"] = world - 1 if M["strong"] else rank
     workers = [(ctx, ed_prover)] + [(c_, ed_data.prover(c_, HASH_GL)) for c_ in
                                     (zklc_amd.Context(torch.cuda.current_device()) for _ in range(nthreads - 2))]
     nbuf = 2
@@ -734,6 +768,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         try:
             # a small first chunk (one signature per proving stream) so that proving starts after one witness time, not after a
             # full chunk's
+            my_sigs = M["my_sigs"]
             n_mine = len(my_sigs)
             bounds = [0, min(n_mine, max(1, nthreads - 1))]
             while bounds[-1] < n_mine:
@@ -778,7 +813,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     def fold_worker(valid_keys):
         try:
             agg = None
-            for i in my_sigs:
+            for i in M["my_sigs"]:
                 st["ed_done"][i].wait()
                 if st["errors"]:
                     return
@@ -790,7 +825,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                 for k in st["fold_host"]:
                     st["fold_host"][k] += rp.last_host_ms[k]
                 agg = (rc.common, rc.verifier_only, proof)
-            if strong:
+            if M["strong"]:
                 st["result"]["local_agg"] = agg        # a (common, verifier_only, proof bytes) triple, or None without signatures
                 return
             rc, proof = rp.recursive_proof(agg, None, list(hashlib.sha256(valid_keys).digest()), raw=True)
@@ -802,20 +837,19 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     bft_args = (hx(win["ep2_last_block"]["bytes"]), hx(win["ep2_last_block"]["hash"]), hx(win["ep1_first_block"]["bytes"]),
                 hx(win["ep1_first_block"]["hash"]), win_blocks)
     hdr_jobs = bprover.header_jobs(*bft_args)
-    hdr_owner = DIST.assign_jobs(list(hdr_jobs), world) if strong else {}
-    ks_rank = world - 1 if strong else rank
+    set_mode(args.scaling == "strong")
 
     def header_worker():
         try:
-            st["result"]["headers"] = {name: bprover.prove_header_job(hdr_jobs[name]) for name in hdr_jobs if hdr_owner[name] == rank}
+            st["result"]["headers"] = {name: bprover.prove_header_job(hdr_jobs[name]) for name in hdr_jobs if M["hdr_owner"][name] == rank}
         except Exception as e:  # pragma: no cover
             fail(e)
 
     def dag_worker():
         try:
             remote = None
-            if strong:       # the header proofs of the other ranks arrive through stub.hdr_future; rank 0's own are made here
-                remote = lambda name: None if hdr_owner[name] == 0 else stub.hdr_future.result()[name]
+            if M["strong"]:       # the header proofs of the other ranks arrive through stub.hdr_future; rank 0's own are made here
+                remote = lambda name: None if M["hdr_owner"][name] == 0 else stub.hdr_future.result()[name]
             bi, _ = bprover.prove_block_bft(*bft_args, validators, header_proofs=remote)
             st["result"]["block"] = bi
             # bin/prove_block.rs:279-287: recursive_proof::<F, Cbn128, C, D>((..bi..), None, Some(&bi_proof.public_inputs))
@@ -841,6 +875,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         sig_threads = [threading.Thread(target=witness_producer)]
         sig_threads += [threading.Thread(target=ed_worker, args=(c_, pr)) for c_, pr in workers]
         sig_threads += [threading.Thread(target=fold_worker, args=(valid_keys,))]
+        strong, ks_rank = M["strong"], M["ks_rank"]
         dag_threads = [threading.Thread(target=dag_worker)] if (not strong or rank == 0) else []
         side_threads = [threading.Thread(target=ks_worker, args=(valid_keys,))] if rank == ks_rank else []
         if strong and rank != 0:
@@ -908,6 +943,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     block_s = total_s / max(1, args.steps)
     smi1 = GpuTelemetry.smi_snapshot() if rank == 0 else None
     tele.close()
+    strong = M["strong"]
     if strong and rank != 0:
         return out            # rank 0 holds the block proof, verifies it and reports
     sig_s = st["result"]["t_signatures"] - t0
@@ -935,7 +971,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                       "blocks_timed": max(1, args.steps), "scaling": "strong" if strong else "weak",
                       "per_step_s": [x["s"] for x in per_step], "per_step_telemetry": per_step, "rss_mb_before": rss0,
                       "rocm_smi_before": smi0, "rocm_smi_after": smi1,
-                      "signatures_of_this_rank": len(my_sigs), "header_proofs_by_rank": hdr_owner or None,
+                      "signatures_of_this_rank": len(M["my_sigs"]), "header_proofs_by_rank": M["hdr_owner"] or None,
                       "keys_stakes_cache_hits": ks_prover.cache_hits,
                       "seconds_until_signature_aggregate": sig_s, "streams": nthreads + 2,
                       "approvals": n_sig, "witness_on": "gpu" if dev_wit else "host", "witness_batch": wchunk,
@@ -952,6 +988,29 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                               "uploaded by an untimed first block and reused (the reference rebuilds every circuit on every call); "
                               "dag_thread_seconds includes the wait for the signature aggregate inside prove_approvals; the "
                               "reference CPU prover cannot be built here (no Rust toolchain) and publishes no time for this step"}
+    if world > 1 and not strong and not args.no_strong_section:
+        # the STRONG form of the block measured in the same run, so that one SCALE run holds both: all ranks prove
+        # ONE block per step (signature shards, local folds, a binary-tree fold over the ranks, the header proofs on the other ranks,
+        # the joins and the wrap on rank 0).  One untimed block builds the tree fold's circuit shapes.
+        set_mode(True)
+        prove_one_block()
+        barrier()
+        ns = max(2, args.steps // 4)
+        t_s = time.perf_counter()
+        for _ in range(ns):
+            prove_one_block()
+        barrier()
+        strong_s = reduce_max(time.perf_counter() - t_s) / ns
+        if rank == 0:
+            assert st["result"]["block"][2]["public_inputs"] == want, "strong mode: block proof public inputs"
+            sw_rc, sw_raw = st["result"]["wrap"]
+            V.verify(json.loads(json.dumps(S.proof_from_bytes(sw_raw, sw_rc.common, HASH_BN128))), sw_rc.verifier_only, sw_rc.common)
+            out["block_i"]["strong"] = {"value": 1.0 / strong_s, "unit": "proofs/s", "seconds_per_block": strong_s, "blocks_timed": ns,
+                                        "scaling": "strong", "final_proof_verified": True,
+                                        "speedup_vs_one_rank_weak_block": block_s / strong_s,
+                                        "header_proofs_by_rank": dict(M["hdr_owner"]),
+                                        "note": "one block over all ranks; the weak figure above (every rank its own block) is the headline"}
+        set_mode(False)
     if args.c5_validators and not strong:
         # BASELINE configs[4] (C5), the part the unmodified circuits can express: a synthetic epoch of N validators who all sign the
         # same Approval message -> batched GPU pre-verification, N Ed25519-circuit proofs (witnesses on the GPU), the left fold and
@@ -967,7 +1026,8 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         assert int(okv.sum()) == nv
         vkeys = b"".join(bytes([i & 0xFF]) + pk_l[i] for i in range(nv))
         fills = [E.fill_ecdsa_targets(ed_targets, c2_msg, sg, pk_) for sg, pk_ in zip(sg_l, pk_l)]
-        n_sig, my_sigs = nv, list(range(nv))
+        n_sig = nv
+        M["my_sigs"] = list(range(nv))
         reset()
         t_ = time.perf_counter()
         th = [threading.Thread(target=witness_producer)] + [threading.Thread(target=ed_worker, args=(c_, pr)) for c_, pr in workers] + \
@@ -1027,6 +1087,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: every rank proves its own block per step; strong: all ranks prove ONE block per step (signature shards, "
                          "tree fold over the ranks, header proofs on the other ranks)")
+    ap.add_argument("--no-strong-section", action="store_true", help="multi-GPU runs: skip the extra strong-scaling blocks after the weak region")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo lets several ranks share one GPU)")
     ap.add_argument("--c5-validators", type=int, default=0, help="also run the C5 stage: a synthetic epoch of this many validators "
                     "(1000 in BASELINE configs[4]; ~85 s on one MI355X), reported under stages.prove.c5_synthetic_epoch")

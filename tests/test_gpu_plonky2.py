@@ -260,6 +260,27 @@ def test_prove_approvals_on_the_reference_small_fixture(zctx, approval_prover):
     wrap.close()
 
 
+def test_tree_aggregation_matches_the_left_fold(zctx, approval_prover):
+    """SURVEY 8f.4 on ONE GPU: `prove_approvals(.., tree=True)` aggregates the signature proofs pairwise instead of by the serial chain
+    of signatures.rs:97-105.  Five real approvals of the 100-validator mainnet fixture (tree: ((p0 p1)(p2 p3)) p4 -- the shapes R(ed, ed),
+    R(R, R), R(R, ed)): the tree-folded closing proof is accepted by the verifier restatement and carries the SAME public inputs
+    (sha256(valid_keys)) and valid_keys as the left fold's, which is proven and verified beside it."""
+    import hashlib
+    from conftest import load_golden, near_set_arrays
+    j = load_golden("ed25519_near_c2_100.json")
+    msg, approvals, validators = near_set_arrays(j)
+    present = [i for i, a in enumerate(approvals) if len(a) == 66][:5]
+    keep = sorted(present)
+    approvals5 = [approvals[i] if i in keep else b"\x00" for i in range(len(approvals))]
+    results = {}
+    for tree in (False, True):
+        (rc, proof), valid_keys = approval_prover.prove_approvals(msg, approvals5, validators, tree=tree)
+        V.verify(json.loads(json.dumps(proof)), rc.verifier_only, rc.common)
+        results[tree] = (proof["public_inputs"], valid_keys, rc.data.n)
+    assert results[True][0] == results[False][0] == list(hashlib.sha256(results[True][1]).digest())
+    assert results[True][1] == results[False][1] and len(results[True][1]) == 33 * 5
+
+
 def test_two_message_lengths_on_one_approval_prover(zctx, approval_prover):
     """the Endorsement (41-byte) and Skip (17-byte) circuits have the same shape (2^18 x 234): an ApprovalProver that alternates between
     them keeps one device wire matrix PER circuit (cells one program writes and the other does not would otherwise go stale) -- the

@@ -99,20 +99,83 @@ def _comm_device(device):
     return device if dist.get_backend() == "nccl" else None
 
 
+def encode_obj(obj):
+    """Length-framed wire form of what the ranks exchange -- proof triples (common_data dict, verifier_only dict, proof as
+    `to_bytes` bytes or in the proof.json schema) and dicts / lists of them: [u32 n][JSON text of n bytes][u32 k][k x (u64 len, raw
+    bytes)].  The JSON holds the structure (dict, list, tuple as {"__t": [..]}, int, str, None); byte strings travel raw and are
+    referenced as {"__b": index}.  Decoding builds plain data only: nothing a peer sends is ever executed (no pickle)."""
+    import json
+    import struct
+    blobs = []
+
+    def enc(x):
+        if isinstance(x, (bytes, bytearray, memoryview)):
+            blobs.append(bytes(x))
+            return {"__b": len(blobs) - 1}
+        if isinstance(x, tuple):
+            return {"__t": [enc(v) for v in x]}
+        if isinstance(x, list):
+            return [enc(v) for v in x]
+        if isinstance(x, dict):
+            assert all(isinstance(k, str) and not k.startswith("__") for k in x), "dict keys must be plain strings"
+            return {k: enc(v) for k, v in x.items()}
+        if x is None or isinstance(x, (bool, int, str, float)):
+            return x
+        if hasattr(x, "item"):          # numpy scalar
+            return x.item()
+        raise TypeError("encode_obj: unsupported type %r" % type(x))
+    text = json.dumps(enc(obj), separators=(",", ":")).encode()
+    out = [struct.pack("<I", len(text)), text, struct.pack("<I", len(blobs))]
+    for bl in blobs:
+        out += [struct.pack("<Q", len(bl)), bl]
+    return b"".join(out)
+
+
+def decode_obj(raw):
+    import json
+    import struct
+    raw = bytes(raw)
+    n, = struct.unpack_from("<I", raw, 0)
+    tree = json.loads(raw[4:4 + n].decode())
+    off = 4 + n
+    k, = struct.unpack_from("<I", raw, off)
+    off += 4
+    blobs = []
+    for _ in range(k):
+        ln, = struct.unpack_from("<Q", raw, off)
+        off += 8
+        if off + ln > len(raw):
+            raise ValueError("decode_obj: truncated frame")
+        blobs.append(raw[off:off + ln])
+        off += ln
+    if off != len(raw):
+        raise ValueError("decode_obj: trailing bytes")
+
+    def dec(x):
+        if isinstance(x, dict):
+            if set(x) == {"__b"}:
+                return blobs[x["__b"]]
+            if set(x) == {"__t"}:
+                return tuple(dec(v) for v in x["__t"])
+            return {k: dec(v) for k, v in x.items()}
+        if isinstance(x, list):
+            return [dec(v) for v in x]
+        return x
+    return dec(tree)
+
+
 def send_obj(obj, dst, group=None, device=None):
-    """point-to-point transfer of a picklable object (a proof triple is ~150-200 KB): length, then the bytes"""
-    import pickle
+    """point-to-point transfer of a proof triple or a dict of them (~150-200 KB each): length, then the frame of encode_obj"""
     import torch
     import torch.distributed as dist
     dev = _comm_device(device)
-    raw = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
+    raw = encode_obj(obj)
     dist.send(torch.tensor([len(raw)], dtype=torch.int64, device=dev), dst, group=group)
-    dist.send(torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev) if dev is not None
-              else torch.frombuffer(bytearray(raw), dtype=torch.uint8), dst, group=group)
+    payload = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    dist.send(payload.to(dev) if dev is not None else payload, dst, group=group)
 
 
 def recv_obj(src, group=None, device=None):
-    import pickle
     import torch
     import torch.distributed as dist
     dev = _comm_device(device)
@@ -120,7 +183,7 @@ def recv_obj(src, group=None, device=None):
     dist.recv(n, src, group=group)
     buf = torch.zeros(int(n[0]), dtype=torch.uint8, device=dev)
     dist.recv(buf, src, group=group)
-    return pickle.loads(buf.cpu().numpy().tobytes())
+    return decode_obj(buf.cpu().numpy().tobytes())
 
 
 def tree_fold(local, combine, group=None, device=None):

@@ -174,20 +174,42 @@ class ApprovalProver:
         """the `valid_keys` bytes prove_approvals will return: they only need the batched pre-check"""
         return self._precheck(msg, approvals, validators)[0]
 
-    def prove_approvals(self, msg, approvals, validators):
-        """-> ((RecursiveCircuit, proof), valid_keys); raises InvalidSignature like the reference's panic (:119-121)"""
+    def prove_approvals(self, msg, approvals, validators, tree=False):
+        """-> ((RecursiveCircuit, proof), valid_keys); raises InvalidSignature like the reference's panic (:119-121).
+        tree=True (opt-in: a different proof tree than the reference's, same statement and public inputs) aggregates the
+        signature proofs pairwise -- depth log2(n) instead of the serial chain of n - 1 fold steps of signatures.rs:97-105, every
+        level's recursions independent of each other -- and closes with the same sha256(valid_keys) proof."""
         import hashlib
         valid_keys, valid_pos, pks, sigs = self._precheck(msg, approvals, validators)
         self._pre = (None,)                                   # one block's worth: the lists may be mutated or reused afterwards
         if not valid_pos:
             raise ValueError("no approvals present")         # the reference indexes agg_data_proof[0] (:131) and panics
         proofs = self.ed25519_proofs(msg, [s.tobytes() for s in sigs], [p.tobytes() for p in pks])
-        agg = proofs[0]
-        for nxt in proofs[1:]:        # proofs travel as `to_bytes` bytes between the steps (signatures.rs:225-230)
-            rc, proof = self.recursion.recursive_proof(agg, nxt, raw=True)
-            agg = (rc.common, rc.verifier_only, proof)
+        agg = self.tree_fold(proofs) if tree else self.left_fold(proofs)
         rc, proof = self.recursion.recursive_proof(agg, None, list(hashlib.sha256(valid_keys).digest()))
         return (rc, proof), valid_keys
+
+    def left_fold(self, proofs):
+        """signatures.rs:97-105: agg = recursive_proof(agg, sig_i); proofs travel as `to_bytes` bytes between the steps (:225-230)"""
+        agg = proofs[0]
+        for nxt in proofs[1:]:
+            rc, proof = self.recursion.recursive_proof(agg, nxt, raw=True)
+            agg = (rc.common, rc.verifier_only, proof)
+        return agg
+
+    def tree_fold(self, proofs):
+        """pairwise aggregation in signature order (an odd node moves up unchanged): ((p0 p1)(p2 p3)) .. -- the circuit shapes settle on
+        R(ed, ed), R(R, R) and the few mixed ones an odd count needs, each built once (RecursionProver's cache)"""
+        level = list(proofs)
+        while len(level) > 1:
+            nxt = []
+            for i in range(0, len(level) - 1, 2):
+                rc, proof = self.recursion.recursive_proof(level[i], level[i + 1], raw=True)
+                nxt.append((rc.common, rc.verifier_only, proof))
+            if len(level) % 2:
+                nxt.append(level[-1])
+            level = nxt
+        return level[0]
 
     def close(self):
         for dw in self._dwit.values():
