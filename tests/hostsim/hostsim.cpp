@@ -297,6 +297,12 @@ void hostsim_poseidon_bn254_permute(u32 *st32) {
     poseidon_bn254_permute(s);
     for (int i = 0; i < 4; i++) fr_to_regular(st32 + 8 * i, s[i]);
 }
+void hostsim_poseidon_bn254_permute_coop(u32 *st32) {      // the four-lane form of the permutation, lane by lane
+    fr s[4];
+    for (int i = 0; i < 4; i++) s[i] = fr_from_regular(st32 + 8 * i);
+    poseidon_bn254_permute_coop_ref(s);
+    for (int i = 0; i < 4; i++) fr_to_regular(st32 + 8 * i, s[i]);
+}
 void hostsim_poseidon_bn254_hash(const u64 *in, u32 len, u32 *out8) { poseidon_bn254_hash_or_noop(in, 1, len, out8); }
 void hostsim_poseidon_bn254_two_to_one(const u32 *l, const u32 *r, u32 *out8) { poseidon_bn254_two_to_one(l, r, out8); }
 
