@@ -7,6 +7,7 @@
 #include "../../zk-light-client-implementation_amd/csrc/poseidon_bn254.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/plonky2_gates.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/bn254_pairing.cuh"
+#include "../../zk-light-client-implementation_amd/csrc/bn254_fr_ntt_tile.cuh"
 #include <string.h>
 #include <vector>
 
@@ -398,6 +399,31 @@ void hostsim_fp_wred(const i32 *limbs, i32 *out_limbs, u32 *out_words) {
     fp r = fp_wred(a);
     for (int i = 0; i < 10; i++) out_limbs[i] = r.v[i];
     fp_freeze_words(out_words, r);
+}
+// The two-pass Fr NTT of csrc/bn254_fr_ntt.hip walked sequentially: the table block, then pass A tile by tile (loads through the
+// bit reversal, the stages butterfly by butterfly, the inter-pass twiddle), then pass B -- the same ZKLC_HD functions as the kernels.
+// data: n = 2^log_n elements in gnark-crypto's layout (4 x u64 Montgomery), transformed in place.
+void hostsim_fr_ntt_two_pass(u64 *data, u32 log_n, u32 inverse, u32 coset) {
+    frn_plan p = frn_make_plan(log_n);
+    const u32 N1 = 1u << p.t1, N2 = 1u << p.t2;
+    std::vector<i32> tab((size_t)frn_table_elems(p) * 10), mid((size_t)N1 * N2 * 10), tile((size_t)N1 * 10);
+    frn_table_consts(tab.data(), log_n, inverse);
+    for (u32 e = 4; e < frn_table_elems(p); e++) frn_store(tab.data() + (size_t)e * 10, frn_table_entry(tab.data(), p, e));
+    for (u32 j2 = 0; j2 < N2; j2++) {
+        for (u32 j1 = 0; j1 < N1; j1++)
+            frn_tile_store(tile.data(), N1, frn_bitrev(j1, p.t1), frn_pass_a_in(data, tab.data(), p, j1, j2, coset && !inverse));
+        for (u32 t = 0; t < p.t1; t++)
+            for (u32 b = 0; b < N1 / 2; b++) frn_tile_butterfly(tile.data(), p.t1, t, b, tab.data() + (size_t)frn_off_loc1(p) * 10);
+        for (u32 k1 = 0; k1 < N1; k1++)
+            frn_store(mid.data() + ((size_t)j2 * N1 + k1) * 10, frn_pass_a_out(frn_tile_load(tile.data(), N1, k1), tab.data(), p, k1, j2));
+    }
+    for (u32 k1 = 0; k1 < N1; k1++) {
+        for (u32 j2 = 0; j2 < N2; j2++)
+            frn_tile_store(tile.data(), N2, frn_bitrev(j2, p.t2), frn_load(mid.data() + ((size_t)j2 * N1 + k1) * 10));
+        for (u32 t = 0; t < p.t2; t++)
+            for (u32 b = 0; b < N2 / 2; b++) frn_tile_butterfly(tile.data(), p.t2, t, b, tab.data() + (size_t)frn_off_loc2(p) * 10);
+        for (u32 k2 = 0; k2 < N2; k2++) frn_pass_b_out(data, frn_tile_load(tile.data(), N2, k2), tab.data(), p, k1, k2, coset && inverse);
+    }
 }
 u32 hostsim_g2_op(int op, const u32 *p32, const u32 *q32, u32 *out32) {
     g2_xyzz a;

@@ -206,7 +206,7 @@ def _fr_vals(arr):
     return [FR.from_mont_words(r) for r in arr]
 
 
-@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 6, 10])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 3, 6, 10, 12, 13])     # 12, 13: the two-pass LDS path (2^12 .. 2^22, natural order)
 def test_fr_ntt_matches_definition(zctx, log_n):
     from oracle import bn254_fr as FR
     import random
@@ -226,6 +226,24 @@ def test_fr_ntt_matches_definition(zctx, log_n):
         assert [out_br[br[i]] for i in range(n)] == FR.ntt(a)
         in_br = _fr_vals(zctx.bn254_fr_ntt(_fr_arr([a[br[i]] for i in range(n)]), flags=2))
         assert in_br == FR.ntt(a)
+
+
+def test_fr_ntt_two_pass_equals_stage_path_2p16_2p22(zctx):
+    """the two-pass transform against round 1's one-launch-per-stage path (a bit-reversed OUTPUT takes that path: undo the
+    reversal) at 2^16 (8 + 8) and 2^22 (11 + 11, the Groth16 size), forward / inverse, with and without the coset"""
+    rng = np.random.default_rng(9)
+    for log_n in (16, 22):
+        n = 1 << log_n
+        a = rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64)
+        a[:, 3] &= np.uint64((1 << 60) - 1)
+        idx = np.arange(n, dtype=np.uint64)
+        br = np.zeros(n, dtype=np.int64)
+        for b in range(log_n):
+            br |= (((idx >> np.uint64(b)) & np.uint64(1)) << np.uint64(log_n - 1 - b)).astype(np.int64)
+        for flags, coset in ((0, 0), (0, 1), (1, 0), (1, 1)):
+            fast = zctx.bn254_fr_ntt(a.copy(), flags=flags, coset=coset)
+            slow_br = zctx.bn254_fr_ntt(a.copy(), flags=flags | 4, coset=coset)     # OUT_BITREV: the stage path
+            assert np.array_equal(fast, slow_br[br]), (log_n, flags, coset)
 
 
 def test_fr_ntt_roundtrip_and_coset_property_2p18(zctx):

@@ -66,6 +66,7 @@ extern "C" void zklc_destroy(zklc_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     zklc_ed25519_fini(ctx);
     zklc_gl_fini(ctx);
+    zklc_bn254_fr_ntt_fini(ctx);
     for (auto &b : ctx->stage)
         if (b.p) (void)hipFree(b.p);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

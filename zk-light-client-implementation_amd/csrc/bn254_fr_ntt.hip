@@ -7,34 +7,13 @@
 // lazy Montgomery form of bn254_fr.cuh.  Definition: values[k] = sum_j coeffs[j] w^(jk), w = g28^(2^28 / n) with
 // g28 = 0x2a3c09f0a58a7e8500e0a7eb8ef62abc402d111e41112ed49bd61b6e725b19f0 (gnark-crypto's rootOfUnity; order 2^28 is
 // checked in oracle/bn254_fr.py); coset generator 5 (fr.Generator / FrMultiplicativeGen).
-// One launch per radix-2 stage on a limb-form working copy (decimation in time after a bit-reversal gather); the
-// transform is a small part of a Groth16 proof next to the MSMs, so no LDS tiling yet.
-#include "bn254_fr.cuh"
+// Natural-order transforms of 2^12 .. 2^22 points (what `computeH` runs) take the two-pass form of bn254_fr_ntt_tile.cuh: two
+// launches, each an LDS-resident sub-transform per workgroup, tables resident per context.  The other cases (smaller or larger
+// sizes, bit-reversed input / output) keep round 1's one-launch-per-stage path below.
+#include "bn254_fr_ntt_tile.cuh"
 #include "zklc_internal.h"
+#include <stdlib.h>
 
-#define FR_ROOT28_WORDS {0x725b19f0u, 0x9bd61b6eu, 0x41112ed4u, 0x402d111eu, 0x8ef62abcu, 0x00e0a7ebu, 0xa58a7e85u, 0x2a3c09f0u}
-
-ZKLC_D fr frn_pow(fr a, u64 e) {
-    const fr one = FR_ONE;
-    fr r = one;
-#pragma unroll 1
-    while (e) {
-        if (e & 1) r = fr_mul(r, a);
-        a = fr_sqr(a);
-        e >>= 1;
-    }
-    return r;
-}
-ZKLC_D void frn_store(i32 *dst, const fr &a) {
-#pragma unroll
-    for (int k = 0; k < 10; k++) dst[k] = a.v[k];
-}
-ZKLC_D fr frn_load(const i32 *src) {
-    fr a;
-#pragma unroll
-    for (int k = 0; k < 10; k++) a.v[k] = src[k];
-    return a;
-}
 ZKLC_D fr frn_load_gnark(const u64 *p) {
     u32 w[8];
 #pragma unroll
@@ -129,6 +108,93 @@ __global__ void __launch_bounds__(256) frn_mul_sub_scale_kernel(u64 *__restrict_
     for (int k = 0; k < 4; k++) a[i * 4 + k] = (u64)w[2 * k] | ((u64)w[2 * k + 1] << 32);
 }
 
+// ---------------------------------------------------------------- two-pass path (bn254_fr_ntt_tile.cuh)
+__global__ void frn_table_consts_kernel(i32 *tab, u32 log_n, u32 inverse) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) frn_table_consts(tab, log_n, inverse);
+}
+__global__ void __launch_bounds__(256) frn_table_entries_kernel(i32 *tab, frn_plan p) {
+    u32 e = 4 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < frn_table_elems(p)) frn_store(tab + (size_t)e * 10, frn_table_entry(tab, p, e));
+}
+
+#define FRN_TILE_THREADS 256
+// the T stages of an Nt = 2^T point tile in LDS (a barrier per stage)
+ZKLC_D void frn_tile_stages(i32 *tile, u32 T, const i32 *loc) {
+    const u32 half_n = (1u << T) >> 1;
+    for (u32 t = 0; t < T; t++) {
+        __syncthreads();
+        for (u32 b = threadIdx.x; b < half_n; b += FRN_TILE_THREADS) frn_tile_butterfly(tile, T, t, b, loc);
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(FRN_TILE_THREADS)
+frn_pass_a_kernel(const u64 *__restrict__ data, i32 *__restrict__ mid, const i32 *__restrict__ tab, frn_plan p, u32 coset_in) {
+    extern __shared__ i32 frn_lds[];
+    const u32 N1 = 1u << p.t1, j2 = blockIdx.x;
+    for (u32 j1 = threadIdx.x; j1 < N1; j1 += FRN_TILE_THREADS)
+        frn_tile_store(frn_lds, N1, frn_bitrev(j1, p.t1), frn_pass_a_in(data, tab, p, j1, j2, coset_in));
+    frn_tile_stages(frn_lds, p.t1, tab + (size_t)frn_off_loc1(p) * 10);
+    i32 *row = mid + (size_t)j2 * N1 * 10;                    // T[j2][k1], element-major (ten consecutive words per element)
+    for (u32 k1 = threadIdx.x; k1 < N1; k1 += FRN_TILE_THREADS)
+        frn_store(row + (size_t)k1 * 10, frn_pass_a_out(frn_tile_load(frn_lds, N1, k1), tab, p, k1, j2));
+}
+
+__global__ void __launch_bounds__(FRN_TILE_THREADS)
+frn_pass_b_kernel(const i32 *__restrict__ mid, u64 *__restrict__ data, const i32 *__restrict__ tab, frn_plan p, u32 coset_out) {
+    extern __shared__ i32 frn_lds[];
+    const u32 N1 = 1u << p.t1, N2 = 1u << p.t2, k1 = blockIdx.x;
+    for (u32 j2 = threadIdx.x; j2 < N2; j2 += FRN_TILE_THREADS)
+        frn_tile_store(frn_lds, N2, frn_bitrev(j2, p.t2), frn_load(mid + ((size_t)j2 * N1 + k1) * 10));
+    frn_tile_stages(frn_lds, p.t2, tab + (size_t)frn_off_loc2(p) * 10);
+    for (u32 k2 = threadIdx.x; k2 < N2; k2 += FRN_TILE_THREADS)
+        frn_pass_b_out(data, frn_tile_load(frn_lds, N2, k2), tab, p, k1, k2, coset_out);
+}
+
+// the resident table block of (log_n, direction), built on first use on `st`
+static int32_t frn_tables(zklc_ctx *ctx, hipStream_t st, const frn_plan &p, bool inverse, const i32 **out) {
+    void *&slot = ctx->fr_ntt_tab[inverse ? 1 : 0][p.log_n];
+    if (!slot) {
+        ZKLC_HIP(ctx, hipMalloc(&slot, (size_t)frn_table_elems(p) * 40));
+        hipLaunchKernelGGL(frn_table_consts_kernel, dim3(1), dim3(64), 0, st, (i32 *)slot, p.log_n, (u32)inverse);
+        u32 ne = frn_table_elems(p) - 4;
+        hipLaunchKernelGGL(frn_table_entries_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, (i32 *)slot, p);
+        ZKLC_HIP(ctx, hipGetLastError());
+        // other streams of this context may use the block right after this call returns
+        ZKLC_HIP(ctx, hipStreamSynchronize(st));
+    }
+    *out = (const i32 *)slot;
+    return ZKLC_OK;
+}
+void zklc_bn254_fr_ntt_fini(zklc_ctx *ctx) {
+    for (auto &dir : ctx->fr_ntt_tab)
+        for (auto &t : dir)
+            if (t) {
+                (void)hipFree(t);
+                t = nullptr;
+            }
+}
+
+static int32_t frn_two_pass(zklc_ctx *ctx, hipStream_t st, uint64_t *d_data, uint32_t log_n, bool inverse, uint32_t coset, i32 *mid) {
+    static hipError_t attr = [] {
+        hipError_t e = hipFuncSetAttribute((const void *)frn_pass_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute((const void *)frn_pass_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    }();
+    ZKLC_HIP(ctx, attr);
+    frn_plan p = frn_make_plan(log_n);
+    const i32 *tab;
+    int32_t rc = frn_tables(ctx, st, p, inverse, &tab);
+    if (rc) return rc;
+    const u32 N1 = 1u << p.t1, N2 = 1u << p.t2;
+    hipLaunchKernelGGL(frn_pass_a_kernel, dim3(N2), dim3(FRN_TILE_THREADS), (size_t)N1 * 40, st, (const u64 *)d_data, mid, tab, p,
+                       (u32)(coset && !inverse));
+    hipLaunchKernelGGL(frn_pass_b_kernel, dim3(N1), dim3(FRN_TILE_THREADS), (size_t)N2 * 40, st, (const i32 *)mid, d_data, tab, p,
+                       (u32)(coset && inverse));
+    ZKLC_HIP(ctx, hipGetLastError());
+    return ZKLC_OK;
+}
+
 extern "C" int32_t zklc_bn254_fr_mul_sub_scale_dev(zklc_ctx *ctx, void *stream, uint64_t *d_a, const uint64_t *d_b, const uint64_t *d_c,
                                                    const uint64_t *scale, uint64_t n) {
     if (!ctx || !d_a || !d_b || !d_c || !scale) return ZKLC_ERR_INVALID_ARG;
@@ -153,6 +219,10 @@ extern "C" int32_t zklc_bn254_fr_ntt_dev(zklc_ctx *ctx, void *stream, uint64_t *
     hipStream_t st = zklc_pick_stream(ctx, stream);
     u32 n = 1u << log_n, half = n >> 1;
     i32 *work = (i32 *)d_workspace;
+    // A/B switch ZKLC_FR_NTT=stages keeps the one-launch-per-stage path at every size
+    static const bool two_pass = [] { const char *v = getenv("ZKLC_FR_NTT"); return !(v && v[0] == 's'); }();
+    if (two_pass && !in_br && !out_br && log_n >= FRN_FAST_MIN_LOG && log_n <= FRN_FAST_MAX_LOG)
+        return frn_two_pass(ctx, st, d_data, log_n, inverse, coset, work);
     i32 *tw = work + (size_t)n * 10;
     i32 *consts = tw + (size_t)(half ? half : 1) * 10;
     hipLaunchKernelGGL(frn_consts_kernel, dim3(1), dim3(64), 0, st, consts, log_n);

@@ -30,6 +30,8 @@ struct zklc_ctx {
     void *gl_scale_hi = nullptr, *gl_scale_lo = nullptr;
     uint64_t gl_scale_shift = 0;
     int gl_scale_hi_n = 0;
+    // BN254 Fr NTT: resident table block per (direction, log n) of the two-pass transform (bn254_fr_ntt_tile.cuh)
+    void *fr_ntt_tab[2][29] = {};
     // grow-only staging buffers for the host-pointer entry points (slot 7 = kernel scratch)
     zklc_devbuf stage[8];
 };
@@ -73,6 +75,7 @@ inline hipStream_t zklc_pick_stream(zklc_ctx *, void *s) { return (hipStream_t)s
 int32_t zklc_ed25519_init(zklc_ctx *ctx);
 void zklc_ed25519_fini(zklc_ctx *ctx);
 void zklc_gl_fini(zklc_ctx *ctx);
+void zklc_bn254_fr_ntt_fini(zklc_ctx *ctx);
 
 // Merkle commit with an explicit leaf layout: element q of leaf i at d_mat[q * stride + i * leaf_stride]
 // (poly-major LDE matrices: leaf_stride 1; row-major FRI leaves: stride 1, leaf_stride = width)
