@@ -151,9 +151,14 @@ def test_native_witness_and_bytes_fast_path(inner_proof):
     v_json = rc.input_vector([(vd, proof)], [5, 6])
     v_raw = rc.input_vector([(vd, raw)], [5, 6])
     assert np.array_equal(v_json, v_raw)
-    wn, pn = data.generate_witness_native(None, input_values=v_raw[None, :])
+    wn, pn = data.generate_witness_native(None, input_values=v_raw[None, :], threads=1)
     assert np.array_equal(wn[0], w) and [int(x) for x in pn[0]] == pis
+    # the same witness on several host threads (the instructions levelled by data dependence, csrc/plonky2_witness.cpp)
+    for th in (2, 5):
+        wt, pt = data.generate_witness_native(None, input_values=v_raw[None, :], threads=th)
+        assert np.array_equal(wt[0], w) and [int(x) for x in pt[0]] == pis
     bad = bytearray(raw)
     bad[8 * 100] ^= 1
-    with pytest.raises(AssertionError):
-        data.generate_witness_native(None, input_values=rc.input_vector([(vd, bytes(bad))], [5, 6])[None, :])
+    for th in (1, 4):
+        with pytest.raises(AssertionError):
+            data.generate_witness_native(None, input_values=rc.input_vector([(vd, bytes(bad))], [5, 6])[None, :], threads=th)

@@ -15,6 +15,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "plonky2_witness_ops.h"
@@ -27,12 +29,15 @@ struct Runner {
     u32 cur = 0;
     char err[200];
     bool failed = false;
+    std::mutex err_mutex;
 
     bool set(u32 slot, u64 v, u64 pc) {
         if (epoch[slot] == cur) {
             if (val[slot] != v) {
-                snprintf(err, sizeof(err), "copy constraint violated at instruction %llu (slot %u: %llu != %llu)", (unsigned long long)pc,
-                         slot, (unsigned long long)val[slot], (unsigned long long)v);
+                std::lock_guard<std::mutex> lk(err_mutex);
+                if (!failed)
+                    snprintf(err, sizeof(err), "copy constraint violated at instruction %llu (slot %u: %llu != %llu)",
+                             (unsigned long long)pc, slot, (unsigned long long)val[slot], (unsigned long long)v);
                 failed = true;
                 return false;
             }
@@ -43,7 +48,8 @@ struct Runner {
         return true;
     }
     bool fail(const char *what, u64 pc) {
-        snprintf(err, sizeof(err), "%s at instruction %llu", what, (unsigned long long)pc);
+        std::lock_guard<std::mutex> lk(err_mutex);      // level-parallel runs: several threads may fail at once, the first message stays
+        if (!failed) snprintf(err, sizeof(err), "%s at instruction %llu", what, (unsigned long long)pc);
         failed = true;
         return false;
     }
@@ -96,8 +102,132 @@ struct Runner {
     }
 };
 
+// ---- ONE witness on several host threads: the instructions levelled by data dependence
+// The fold of signatures.rs:97-105 is a serial chain: recursion witness -> proof -> next witness.  A recursion circuit's program
+// is ~12 k coarse instructions (PoseidonGate rows, reducing / interpolation rows, arithmetic) in ~150 dependence levels, most of the
+// time in the ~6 000 Poseidon rows of the 56 Merkle-path chains -- independent of each other.  The plan below assigns every
+// instruction the level 1 + max(level of the first writers of its inputs); an instruction that writes a slot somebody wrote before
+// (a copy constraint between two generators: the second write only compares) is placed after that first writer.  A level's
+// instructions touch disjoint output slots, so the threads of a level share nothing but read-only inputs; a barrier separates levels.
+struct LevelPlan {
+    std::vector<u64> ip, pp;          // per instruction: offset of its header in `code`, of its parameters in `params`
+    std::vector<u32> order;           // instruction indices sorted by level
+    std::vector<u32> level_start;     // order[level_start[l] .. level_start[l + 1]) = level l
+};
+static std::mutex g_plan_mutex;
+static std::map<std::pair<const u32 *, u64>, LevelPlan *> g_plans;
+
+static const LevelPlan *level_plan(const u32 *code, u64 code_len, u32 n_slots) {
+    std::lock_guard<std::mutex> lk(g_plan_mutex);
+    auto key = std::make_pair(code, code_len);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) return it->second;
+    LevelPlan *pl = new LevelPlan();
+    std::vector<u32> slot_level(n_slots, 0), level;
+    std::vector<char> written(n_slots, 0);
+    u64 ip = 0, pp = 0;
+    u32 max_level = 0;
+    while (ip < code_len) {
+        u32 np = code[ip + 1], ni = code[ip + 2], no = code[ip + 3];
+        const u32 *is = code + ip + 4, *os = is + ni;
+        u32 lv = 0;
+        for (u32 i = 0; i < ni; i++) lv = lv > slot_level[is[i]] ? lv : slot_level[is[i]];
+        lv += 1;
+        for (u32 i = 0; i < no; i++)
+            if (written[os[i]] && lv <= slot_level[os[i]]) lv = slot_level[os[i]] + 1;    // a second writer compares: after the first
+        for (u32 i = 0; i < no; i++)
+            if (!written[os[i]]) {
+                written[os[i]] = 1;
+                slot_level[os[i]] = lv;
+            }
+        pl->ip.push_back(ip);
+        pl->pp.push_back(pp);
+        level.push_back(lv);
+        max_level = max_level > lv ? max_level : lv;
+        ip += 4 + ni + no;
+        pp += np;
+    }
+    // two instructions of one level that both write a slot for the first time in that level would race: push the later one down
+    // (cannot happen for the first writer by construction -- `written` is set in program order -- but a later writer of the SAME
+    // level as the first one was moved above; nothing else shares a slot)
+    u32 n = (u32)level.size();
+    std::vector<u32> count(max_level + 2, 0);
+    for (u32 i = 0; i < n; i++) count[level[i] + 1]++;
+    for (u32 l = 1; l < count.size(); l++) count[l] += count[l - 1];
+    pl->level_start.assign(count.begin(), count.end());
+    pl->order.resize(n);
+    std::vector<u32> cursor(count.begin(), count.end() - 1);
+    for (u32 i = 0; i < n; i++) pl->order[cursor[level[i]]++] = i;
+    g_plans[key] = pl;
+    return pl;
+}
+
+struct SpinBarrier {
+    std::atomic<u32> count{0}, gen{0};
+    u32 n;
+    explicit SpinBarrier(u32 n_) : n(n_) {}
+    void wait() {
+        u32 g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            count.store(0, std::memory_order_relaxed);
+            gen.fetch_add(1, std::memory_order_release);
+        } else {
+            u32 spins = 0;
+            while (gen.load(std::memory_order_acquire) == g)
+                if (++spins > 2000) std::this_thread::yield();
+        }
+    }
+};
+
+// the whole program for one witness on `threads` threads; same results and the same failures as Runner::run
+static bool run_levelled(Runner &r, const LevelPlan &pl, const u32 *code, const int64_t *params, const u32 *in_slots,
+                         const u64 *in_vals, u32 n_inputs, u32 threads) {
+    r.cur++;
+    r.failed = false;
+    for (u32 i = 0; i < n_inputs; i++)
+        if (!r.set(in_slots[i], in_vals[i] % GLP, 0)) return false;
+    const u32 n_levels = (u32)pl.level_start.size() - 1;
+    SpinBarrier bar(threads);
+    std::vector<std::atomic<u32>> next(n_levels);
+    for (u32 l = 0; l < n_levels; l++) next[l].store(pl.level_start[l], std::memory_order_relaxed);
+    std::atomic<bool> stop(false);
+    auto worker = [&]() {
+        for (u32 l = 0; l < n_levels; l++) {
+            const u32 end = pl.level_start[l + 1];
+            if (!stop.load(std::memory_order_relaxed))
+                for (;;) {
+                    u32 k0 = next[l].fetch_add(4, std::memory_order_relaxed);       // chunks of four: Poseidon rows next to one-liners
+                    if (k0 >= end) break;
+                    u32 k1 = k0 + 4 < end ? k0 + 4 : end;
+                    for (u32 k = k0; k < k1; k++) {
+                        u32 idx = pl.order[k];
+                        u64 ip = pl.ip[idx];
+                        int op = (int)code[ip];
+                        u32 np = code[ip + 1], ni = code[ip + 2], no = code[ip + 3];
+                        const u32 *is = code + ip + 4, *os = is + ni;
+                        u64 pc = (u64)idx + 1;
+                        bool ok = true;
+                        for (u32 i = 0; i < ni && ok; i++)
+                            if (r.epoch[is[i]] != r.cur) ok = r.fail("input not available", pc);
+                        if (ok) {
+                            Runner::IO io = {&r, is, os, no, 0, pc};
+                            ok = wit_exec<true>(op, params + pl.pp[idx], np, ni, no, io);
+                            if (ok && io.k != no) ok = r.fail("output count mismatch", pc);
+                        }
+                        if (!ok) stop.store(true, std::memory_order_relaxed);
+                    }
+                }
+            bar.wait();
+        }
+    };
+    std::vector<std::thread> pool;
+    for (u32 t = 1; t < threads; t++) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    return !r.failed;
+}
+
 // pool of interpreter states (value + epoch arrays are hundreds of MB for the Ed25519 circuit: keep them across calls)
-#include <mutex>
 static std::mutex g_pool_mutex;
 static std::vector<Runner *> g_pool;
 static Runner *runner_acquire(u32 n_slots) {
@@ -142,6 +272,9 @@ extern "C" int32_t zklc_plonky2_witness_run(const uint32_t *code, uint64_t code_
                                             uint32_t threads) {
     if (!code || !status || (n_inputs && (!input_slots || !input_values)) || !wires_out) return -1;
     if (threads == 0) threads = 1;
+    // one witness, several threads: the levelled form (the serial fold chain); several witnesses: one thread each
+    const u32 level_threads = (n_witnesses == 1 && threads > 1) ? (threads > 16 ? 16 : threads) : 1;
+    const LevelPlan *plan = level_threads > 1 ? level_plan(code, code_len, n_slots) : nullptr;
     if (threads > n_witnesses) threads = n_witnesses ? n_witnesses : 1;
     std::atomic<u32> next(0);
     auto worker = [&]() {
@@ -150,13 +283,27 @@ extern "C" int32_t zklc_plonky2_witness_run(const uint32_t *code, uint64_t code_
         for (;;) {
             u32 w = next.fetch_add(1);
             if (w >= n_witnesses) break;
-            bool ok = r.run(code, code_len, params, input_slots, input_values + (size_t)w * n_inputs, n_inputs);
+            bool ok = plan ? run_levelled(r, *plan, code, params, input_slots, input_values + (size_t)w * n_inputs, n_inputs, level_threads)
+                           : r.run(code, code_len, params, input_slots, input_values + (size_t)w * n_inputs, n_inputs);
             u64 *wires = wires_out + (size_t)w * num_wires * n_rows;
             if (ok) {
-                for (u64 k = 0; k < n_wire_entries; k++) {
-                    u32 s = wire_slot[k];
-                    if (r.epoch[s] != r.cur) continue;  // unconstrained cell of a class nobody assigned: stays as it is (zero)
-                    wires[wire_index[k]] = r.val[s];
+                auto scatter = [&](u64 k0, u64 k1) {
+                    for (u64 k = k0; k < k1; k++) {
+                        u32 s = wire_slot[k];
+                        if (r.epoch[s] != r.cur) continue;  // unconstrained cell of a class nobody assigned: stays as it is (zero)
+                        wires[wire_index[k]] = r.val[s];
+                    }
+                };
+                if (level_threads > 1) {                    // the single witness of the fold chain: scatter on the same threads
+                    std::vector<std::thread> sp;
+                    u64 per = (n_wire_entries + level_threads - 1) / level_threads;
+                    for (u32 t = 1; t < level_threads; t++)
+                        sp.emplace_back(scatter, (u64)t * per < n_wire_entries ? (u64)t * per : n_wire_entries,
+                                        (u64)(t + 1) * per < n_wire_entries ? (u64)(t + 1) * per : n_wire_entries);
+                    scatter(0, per < n_wire_entries ? per : n_wire_entries);
+                    for (auto &t : sp) t.join();
+                } else {
+                    scatter(0, n_wire_entries);
                 }
                 for (u32 k = 0; k < n_pi; k++) {
                     if (r.epoch[pi_slots[k]] != r.cur) {

@@ -930,15 +930,18 @@ class RecursionProver:
     circuits' common data and the number of public inputs, so it is built and uploaded once per distinct shape and reused:
     a fold (prove_block_data/signatures.rs:97-105) settles on two shapes plus the closing one."""
 
-    def __init__(self, ctx, hasher=0, threads=None, inner_hasher=0, device_witness=False):
+    def __init__(self, ctx, hasher=0, threads=None, inner_hasher=0, device_witness=False, witness_threads=4):
         """device_witness=True: the generators of the recursion circuit run on the GPU (csrc/plonky2_witness_dev.hip: ~12 k coarse
         instructions in ~150 dependence levels, one single-workgroup launch) and the proof is made from the matrix in HBM.
         Measured inside a block proof (profiles/r02_bench_block_v4_recursion_witness_on_gpu.json) this is SLOWER than the host
-        interpreter -- 45 ms against 37 ms per fold step: one witness has no parallelism to offer and its launch queues behind
-        the signature proofs' kernels -- so the default stays the host interpreter; the batch form (64 signatures) is where the
-        device interpreter pays."""
+        interpreter -- 45 ms against 37 ms per fold step: its launch queues behind the signature proofs' kernels -- so the default
+        stays the host interpreter, run level-parallel on `witness_threads` host threads; the batch form (64 signatures) is where
+        the device interpreter pays."""
         self.ctx, self.hasher, self.threads, self.inner_hasher = ctx, hasher, threads, inner_hasher
         self.device_witness = device_witness
+        # host threads of ONE recursion witness (csrc/plonky2_witness.cpp, the levelled form): the fold is a serial chain of
+        # witness -> proof -> witness, so the latency of a single witness is on the critical path of a block
+        self.witness_threads = max(1, int(witness_threads))
         assert inner_hasher == 0, "the in-circuit verifier handles Poseidon-Goldilocks inner proofs"
         self._cache = {}
 
@@ -976,7 +979,8 @@ class RecursionProver:
             t2 = time.perf_counter()
             out = rc.prover.prove_dev(dbuf.data_ptr(), [int(x) for x in wpis[0]], stream=st)
         else:
-            wires, wpis = rc.data.generate_witness_native(None, out=rc.wire_buffer(), threads=1, input_values=vals[None, :])
+            wires, wpis = rc.data.generate_witness_native(None, out=rc.wire_buffer(), threads=self.witness_threads,
+                                                          input_values=vals[None, :])
             t2 = time.perf_counter()
             out = rc.prover.prove_host_ptr(wires.ctypes.data, [int(x) for x in wpis[0]])
         t3 = time.perf_counter()
