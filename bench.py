@@ -739,9 +739,12 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     bprover = BlockProver(dag_ctx, stub)
     rpw_block = RecursionProver(dag_ctx, HASH_BN128)
     lock = threading.Lock()
-    st = {}
+    cur = {"st": None}       # the state of the block whose fold / DAG stage ran last (results are read from it after the timed region)
 
-    def reset():
+    def new_state():
+        """per-block state of the pipeline: the signature stage (witness producer + Ed25519 provers) fills ed_proofs / ed_done, the
+        fold + DAG stage consumes them"""
+        st = {}
         st["ed_done"] = [threading.Event() for _ in range(n_sig)]
         st["ed_proofs"] = [None] * n_sig
         st["free_slots"], st["ready"] = queue.Queue(), queue.Queue()
@@ -751,10 +754,15 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         st["errors"], st["tw"] = [], [0.0]
         st["fold_host"] = {"inputs": 0.0, "witness": 0.0, "prove": 0.0}
         st["result"] = {}
+        return st
+
+    def begin_dag_stage(st):
+        """the fold / DAG / keys-stakes stage of a block owns the stub's futures and the block prover's counters"""
         stub.future, stub.ks_future, stub.hdr_future = Future(), Future(), Future()
         bprover.counts, bprover.seconds = {}, {}
+        cur["st"] = st
 
-    def fail(e):
+    def fail(st, e):
         st["errors"].append(e)
         for fut in (stub.future, stub.ks_future, stub.hdr_future):
             if not fut.done():
@@ -764,7 +772,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         for _ in range(nthreads):
             st["ready"].put(None)
 
-    def witness_producer():
+    def witness_producer(st):
         try:
             # a small first chunk (one signature per proving stream) so that proving starts after one witness time, not after a
             # full chunk's
@@ -789,9 +797,9 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
             for _ in range(nthreads):
                 st["ready"].put(None)
         except Exception as e:  # pragma: no cover
-            fail(e)
+            fail(st, e)
 
-    def ed_worker(c_, pr):
+    def ed_worker(st, c_, pr):
         try:
             while True:
                 item = st["ready"].get()
@@ -808,9 +816,9 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                     if st["slot_left"][sl] == 0:
                         st["free_slots"].put(sl)
         except Exception as e:  # pragma: no cover
-            fail(e)
+            fail(st, e)
 
-    def fold_worker(valid_keys):
+    def fold_worker(st, valid_keys):
         try:
             agg = None
             for i in M["my_sigs"]:
@@ -832,20 +840,20 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
             st["result"]["t_signatures"] = time.perf_counter()
             stub.future.set_result((rc, proof, valid_keys))
         except Exception as e:  # pragma: no cover
-            fail(e)
+            fail(st, e)
 
     bft_args = (hx(win["ep2_last_block"]["bytes"]), hx(win["ep2_last_block"]["hash"]), hx(win["ep1_first_block"]["bytes"]),
                 hx(win["ep1_first_block"]["hash"]), win_blocks)
     hdr_jobs = bprover.header_jobs(*bft_args)
     set_mode(args.scaling == "strong")
 
-    def header_worker():
+    def header_worker(st):
         try:
             st["result"]["headers"] = {name: bprover.prove_header_job(hdr_jobs[name]) for name in hdr_jobs if M["hdr_owner"][name] == rank}
         except Exception as e:  # pragma: no cover
-            fail(e)
+            fail(st, e)
 
-    def dag_worker():
+    def dag_worker(st):
         try:
             remote = None
             if M["strong"]:       # the header proofs of the other ranks arrive through stub.hdr_future; rank 0's own are made here
@@ -855,31 +863,82 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
             # bin/prove_block.rs:279-287: recursive_proof::<F, Cbn128, C, D>((..bi..), None, Some(&bi_proof.public_inputs))
             st["result"]["wrap"] = rpw_block.recursive_proof(bi, None, list(bi[2]["public_inputs"]), raw=True)
         except Exception as e:  # pragma: no cover
-            fail(e)
+            fail(st, e)
 
-    def ks_worker(valid_keys):
+    def ks_worker(st, valid_keys):
         try:
             t_ = time.perf_counter()
             stub.ks_future.set_result(ks_prover.prove_valid_keys_stakes_in_validators_list(
                 valid_keys, hashlib.sha256(valid_keys).digest(), validators))
             st["result"]["keys_stakes_s"] = time.perf_counter() - t_
         except Exception as e:  # pragma: no cover
-            fail(e)
+            fail(st, e)
+
+    def start_signature_stage(st):
+        """a3 (the batched pre-check of signatures.rs:79), then the witness producer and the Ed25519 provers of one block"""
+        st["t0"] = time.perf_counter()
+        valid_keys, valid_pos, _, _ = SG.verify_approvals(ctx, c2_msg, approvals, validators)
+        assert len(valid_pos) == n_sig, "fixture approvals must verify"
+        st["valid_keys"], st["t_verify"] = valid_keys, time.perf_counter() - st["t0"]
+        ths = [threading.Thread(target=witness_producer, args=(st,))]
+        ths += [threading.Thread(target=ed_worker, args=(st, c_, pr)) for c_, pr in workers]
+        for th in ths:
+            th.start()
+        return ths
+
+    def start_dag_stage(st):
+        """the fold chain, the keys / stakes proof and the rest of the DAG of one block (weak mode: all on this rank)"""
+        begin_dag_stage(st)
+        ths = [threading.Thread(target=fold_worker, args=(st, st["valid_keys"])), threading.Thread(target=dag_worker, args=(st,)),
+               threading.Thread(target=ks_worker, args=(st, st["valid_keys"]))]
+        for th in ths:
+            th.start()
+        return ths
+
+    def prove_blocks_overlapped(k_blocks, on_block_done=None):
+        """k full Block_i proofs as a two-stage pipeline over consecutive blocks (a light client proves a stream of blocks): the
+        signature stage of block b + 1 starts as soon as the last signature proof of block b is out, while the tail of block b --
+        its last fold steps, the closing proof, the joining recursions and the BN128 wrap, ~0.4 s during which the GPU would
+        otherwise sit nearly idle -- completes beside it.  The fold / DAG stages of consecutive blocks share their provers, so
+        they run one after the other.  Every block is complete when this returns."""
+        prev_dag, prev_st = [], None
+        for _ in range(k_blocks):
+            st = new_state()
+            sig = start_signature_stage(st)
+            for th in prev_dag:                   # block b - 1 must be finished before block b's fold / DAG stage takes the provers
+                th.join()
+            if prev_st is not None:
+                if prev_st["errors"]:
+                    raise prev_st["errors"][0]
+                if on_block_done:
+                    on_block_done(prev_st)
+            prev_dag, prev_st = start_dag_stage(st), st
+            for th in sig:
+                th.join()
+        for th in prev_dag:
+            th.join()
+        if prev_st["errors"]:
+            raise prev_st["errors"][0]
+        if on_block_done:
+            on_block_done(prev_st)
+        return prev_st
 
     def prove_one_block():
-        reset()
+        st = new_state()
+        begin_dag_stage(st)
         t0 = time.perf_counter()
         valid_keys, valid_pos, _, _ = SG.verify_approvals(ctx, c2_msg, approvals, validators)   # a3: the pre-check of signatures.rs:79
         assert len(valid_pos) == n_sig, "fixture approvals must verify"
         t_verify = time.perf_counter() - t0
-        sig_threads = [threading.Thread(target=witness_producer)]
-        sig_threads += [threading.Thread(target=ed_worker, args=(c_, pr)) for c_, pr in workers]
-        sig_threads += [threading.Thread(target=fold_worker, args=(valid_keys,))]
+        st["t0"], st["t_verify"], st["valid_keys"] = t0, t_verify, valid_keys
+        sig_threads = [threading.Thread(target=witness_producer, args=(st,))]
+        sig_threads += [threading.Thread(target=ed_worker, args=(st, c_, pr)) for c_, pr in workers]
+        sig_threads += [threading.Thread(target=fold_worker, args=(st, valid_keys))]
         strong, ks_rank = M["strong"], M["ks_rank"]
-        dag_threads = [threading.Thread(target=dag_worker)] if (not strong or rank == 0) else []
-        side_threads = [threading.Thread(target=ks_worker, args=(valid_keys,))] if rank == ks_rank else []
+        dag_threads = [threading.Thread(target=dag_worker, args=(st,))] if (not strong or rank == 0) else []
+        side_threads = [threading.Thread(target=ks_worker, args=(st, valid_keys))] if rank == ks_rank else []
         if strong and rank != 0:
-            side_threads.append(threading.Thread(target=header_worker))
+            side_threads.append(threading.Thread(target=header_worker, args=(st,)))
         for th in sig_threads + dag_threads + side_threads:
             th.start()
         if strong:
@@ -934,10 +993,24 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     smi0 = GpuTelemetry.smi_snapshot() if rank == 0 else None
     tele.mark()
     per_step, rss0 = [], rss_mb()
+    overlap = not M["strong"] and not args.no_block_overlap
     t_all = time.perf_counter()
-    for _ in range(max(1, args.steps)):     # a step = one full Block_i proof
-        t0, t_verify = prove_one_block()
-        per_step.append(dict(tele.mark(), s=round(time.perf_counter() - t0, 4), rss_mb=rss_mb()))
+    if overlap:
+        # exactly K complete Block_i proofs; consecutive blocks overlap by the tail of the earlier one (prove_blocks_overlapped).
+        # per_step_s = time between consecutive block completions (the first one counts from the start of the region)
+        last_done = [t_all]
+
+        def block_done(st_):
+            now = time.perf_counter()
+            per_step.append(dict(tele.mark(), s=round(now - last_done[0], 4), latency_s=round(now - st_["t0"], 4), rss_mb=rss_mb()))
+            last_done[0] = now
+        st = prove_blocks_overlapped(max(1, args.steps), block_done)
+        t0, t_verify = st["t0"], st["t_verify"]
+    else:
+        for _ in range(max(1, args.steps)):     # a step = one full Block_i proof
+            t0, t_verify = prove_one_block()
+            per_step.append(dict(tele.mark(), s=round(time.perf_counter() - t0, 4), rss_mb=rss_mb()))
+        st = cur["st"]
     barrier()
     total_s = reduce_max(time.perf_counter() - t_all)
     block_s = total_s / max(1, args.steps)
@@ -970,6 +1043,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                       "value": (1 if strong else world) / block_s, "unit": "proofs/s", "seconds_per_block": block_s,
                       "blocks_timed": max(1, args.steps), "scaling": "strong" if strong else "weak",
                       "per_step_s": [x["s"] for x in per_step], "per_step_telemetry": per_step, "rss_mb_before": rss0,
+                      "blocks_overlapped": overlap,
                       "rocm_smi_before": smi0, "rocm_smi_after": smi1,
                       "signatures_of_this_rank": len(M["my_sigs"]), "header_proofs_by_rank": M["hdr_owner"] or None,
                       "keys_stakes_cache_hits": ks_prover.cache_hits,
@@ -1002,8 +1076,9 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         barrier()
         strong_s = reduce_max(time.perf_counter() - t_s) / ns
         if rank == 0:
-            assert st["result"]["block"][2]["public_inputs"] == want, "strong mode: block proof public inputs"
-            sw_rc, sw_raw = st["result"]["wrap"]
+            sst = cur["st"]
+            assert sst["result"]["block"][2]["public_inputs"] == want, "strong mode: block proof public inputs"
+            sw_rc, sw_raw = sst["result"]["wrap"]
             V.verify(json.loads(json.dumps(S.proof_from_bytes(sw_raw, sw_rc.common, HASH_BN128))), sw_rc.verifier_only, sw_rc.common)
             out["block_i"]["strong"] = {"value": 1.0 / strong_s, "unit": "proofs/s", "seconds_per_block": strong_s, "blocks_timed": ns,
                                         "scaling": "strong", "final_proof_verified": True,
@@ -1028,16 +1103,18 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         fills = [E.fill_ecdsa_targets(ed_targets, c2_msg, sg, pk_) for sg, pk_ in zip(sg_l, pk_l)]
         n_sig = nv
         M["my_sigs"] = list(range(nv))
-        reset()
+        st5 = new_state()
+        begin_dag_stage(st5)
         t_ = time.perf_counter()
-        th = [threading.Thread(target=witness_producer)] + [threading.Thread(target=ed_worker, args=(c_, pr)) for c_, pr in workers] + \
-             [threading.Thread(target=fold_worker, args=(vkeys,))]
+        th = [threading.Thread(target=witness_producer, args=(st5,))] + \
+             [threading.Thread(target=ed_worker, args=(st5, c_, pr)) for c_, pr in workers] + \
+             [threading.Thread(target=fold_worker, args=(st5, vkeys))]
         for x in th:
             x.start()
         for x in th:
             x.join()
-        if st["errors"]:
-            raise st["errors"][0]
+        if st5["errors"]:
+            raise st5["errors"][0]
         rc5, proof5, _ = stub.future.result()
         dt5 = reduce_max(time.perf_counter() - t_)
         from oracle import plonky2_verifier as V5
@@ -1087,6 +1164,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: every rank proves its own block per step; strong: all ranks prove ONE block per step (signature shards, "
                          "tree fold over the ranks, header proofs on the other ranks)")
+    ap.add_argument("--no-block-overlap", action="store_true", help="prove the timed blocks strictly one after the other (no overlap of "
+                    "a block's tail with the next block's signature proofs)")
     ap.add_argument("--no-strong-section", action="store_true", help="multi-GPU runs: skip the extra strong-scaling blocks after the weak region")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo lets several ranks share one GPU)")
     ap.add_argument("--c5-validators", type=int, default=0, help="also run the C5 stage: a synthetic epoch of this many validators "
