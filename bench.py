@@ -178,6 +178,22 @@ def poseidon_pmc():
         return None
 
 
+def pmc_json(name):
+    """a committed rocprofv3 PMC summary (profiles/<name>, written by tools/pmc_*.sh on the GPU box); None when absent"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except (OSError, ValueError):
+        return None
+
+
+def valu_block(wave_instructions, ms, what):
+    """the binding resource of the integer kernels: SQ_INSTS_VALU x 64 lanes / time against the measured issue ceiling"""
+    ach = wave_instructions * 64 / (ms * 1e-3) / 1e12
+    return {"bound": "valu-int", "achieved": ach, "peak": VALU_INT_PEAK_TLOPS, "unit": "T lane-instr/s", "frac": ach / VALU_INT_PEAK_TLOPS,
+            "note": "SQ_INSTS_VALU (%s) x 64 lanes / the live time; peak = the measured issue rate of v_mad_u64_u32 / v_mad_i64_i32 / carry "
+                    "adds (profiles/r02_valu_ubench.txt, profiles/r03d_fp_ubench.txt)" % what}
+
+
 def cpu_baseline(pk, sg, ms, budget_s=12.0):
     """Oracle C restatement (oracle/c/ed25519_oracle.c) on all host cores, bounded sample."""
     from oracle import cport
@@ -273,6 +289,11 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
            "roofline": {"bound": "hbm", "achieved": 96.0 * n / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": 96.0 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "note": "algorithmic bytes = 96 B/element (64 B point + 32 B scalar); integer-VALU-bound"}}
+    pm = pmc_json("msm_pmc_latest.json")
+    if pm is not None and pm.get("log_n") == args.msm_log:
+        msm["roofline"]["traffic"] = pm.get("hbm_bytes_per_msm")
+        msm["roofline"]["valu"] = valu_block(pm["valu_wave_instructions_per_msm"], ms, "all kernels of one multi-exponentiation, "
+                                                                                       "profiles/msm_pmc_latest.json")
     if with_cpu:
         t0 = time.perf_counter()
         want, winf, used = cport.bn254_msm(pts_h, sc_h, nthreads=threads)
@@ -328,6 +349,11 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
                   "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                                "note": "algorithmic bytes = 8*(n + N) per polynomial (read coefficients once, write evaluations once)"}}
+    pl_ = pmc_json("lde_pmc_latest.json")
+    if pl_ is not None:
+        res["lde"]["roofline"]["traffic"] = pl_.get("hbm_bytes_per_lde")
+        res["lde"]["roofline"]["valu"] = valu_block(pl_["valu_wave_instructions_per_lde"], ms, "all passes of one extension, "
+                                                                                                "profiles/lde_pmc_latest.json")
     words = ctx.gl_merkle_tree_words(log_n + rate, cap)
     tree = torch.empty(words, dtype=torch.int64, device=dev)
     ms, wall = _time_stream(lambda: ctx.gl_merkle_commit_dev(lde, N, log_n + rate, batch, cap, tree, stream=stream), stream, 3, barrier)
