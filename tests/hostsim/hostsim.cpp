@@ -264,7 +264,13 @@ static u32 hostsim_msm(const u64 *points, const u64 *scalars, u32 n, u32 mode, u
     for (u32 w = pl.windows; w-- > 0;) {
         ec_xyzz<F> win = ec_infinity<F>();
         for (u32 si = 0; si < seg_per_window; si++) win = ec_add(win, msm_segment_lane<F>(buckets.data(), pl, w, si));
-        for (u32 k = 0; k < pl.c * w; k++) win = ec_double(win);      // as msm_final_kernel: 2^(c w) * window_w, then the sum
+        if (F::LIMBS == 10 && mode == 0) {                            // as msm_final_kernel for G1: the doublings by a quad of lanes
+            ec_xyzz<F> q4[4] = {win, win, win, win};
+            for (u32 k = 0; k < pl.c * w; k++) ec_double_quad_ref<F>(q4);
+            win = q4[0];
+        } else {
+            for (u32 k = 0; k < pl.c * w; k++) win = ec_double(win);  // 2^(c w) * window_w, then the sum
+        }
         total = ec_add(total, win);
     }
     return ec_to_affine_gnark(out, total);

@@ -28,11 +28,19 @@ for name in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
             vals = [v[cname] for v in disp.values() if cname in v]
             d[cname + "_per_launch"] = sum(vals) / len(vals)
         d["launches_per_msm"] = max(1, round(len(disp) / 4))      # the quick bench runs 4 multi-exponentiations
-tot_f = sum(d.get("FETCH_SIZE_per_launch", 0) * d["launches_per_msm"] for d in out["kernels"].values())
-tot_w = sum(d.get("WRITE_SIZE_per_launch", 0) * d["launches_per_msm"] for d in out["kernels"].values())
-out["hbm_bytes_per_msm"] = 2 * tot_f * 1024 + tot_w * 1024
+GATHER = ("msm_slice_kernel",)      # 80-byte point records straddle two 64-byte lines: 16 windows x 2^22 x 128 B = 8.6 GB predicted,
+                                    # the raw counter reads 8.7 GB -> the x2 of wide streaming reads does not apply to this kernel
+def fetch_bytes(k, d):
+    return d.get("FETCH_SIZE_per_launch", 0) * 1024 * (1 if k.startswith(GATHER) else 2)
+for k, d in out["kernels"].items():
+    d["hbm_bytes_per_launch"] = fetch_bytes(k, d) + d.get("WRITE_SIZE_per_launch", 0) * 1024
+out["hbm_bytes_per_msm"] = sum(d["hbm_bytes_per_launch"] * d["launches_per_msm"] for d in out["kernels"].values())
+out["hbm_bytes_per_msm_raw_counters"] = sum((d.get("FETCH_SIZE_per_launch", 0) + d.get("WRITE_SIZE_per_launch", 0)) * 1024 * d["launches_per_msm"]
+                                            for d in out["kernels"].values())
 out["valu_wave_instructions_per_msm"] = sum(d.get("SQ_INSTS_VALU_per_launch", 0) * d["launches_per_msm"] for d in out["kernels"].values())
-out["note"] = "traffic = 2 x FETCH_SIZE (gfx950 correction for wide reads, MI355X_MICROARCH.md; 64-byte gathers may be over-counted by it) + WRITE_SIZE, KiB -> bytes, all kernels of one 2^22 multi-exponentiation"
+out["note"] = ("traffic = FETCH_SIZE (x2 for the streaming kernels: gfx950 correction for wide reads, MI355X_MICROARCH.md; x1 for the "
+               "gathers of msm_slice_kernel, calibrated on its known 128 B per gathered point) + WRITE_SIZE, KiB -> bytes, all kernels of "
+               "one 2^22 multi-exponentiation")
 json.dump(out, open("gpurun_out/%s_msm_pmc.json" % tag, "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "kernels"}))
 PY

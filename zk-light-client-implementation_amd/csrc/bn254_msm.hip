@@ -267,13 +267,54 @@ __global__ void __launch_bounds__(msm_cfg<F>::BLOCK) msm_window_kernel(const i32
     if (threadIdx.x == 0) msm_store_xyzz<F>(win_out + (size_t)w * XY, acc);
 }
 
-// result = sum_w 2^(c w) W_w ; affine output in gnark Montgomery words + infinity flag
+// quad broadcast of a base-field element (DPP quad_perm [SRC, SRC, SRC, SRC])
+template <int SRC>
+ZKLC_D fp msm_quad_bcast(const fp &v) {
+    fp r;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int k = 0; k < 10; k++) r.v[k] = __builtin_amdgcn_mov_dpp(v.v[k], SRC * 0x55, 0xf, 0xf, false);
+#else
+    r = v;
+#endif
+    return r;
+}
+// one doubling by the four lanes of a quad (bn254_msm_lane.cuh: ecq_stage*); every lane holds the point before and after
+ZKLC_D void msm_double_quad(ec_xyzz<FpField> &p, u32 role) {
+    fp r1 = ecq_stage1<FpField>(p, role);
+    fp V = msm_quad_bcast<0>(r1), XX = msm_quad_bcast<1>(r1);
+    fp r2 = ecq_stage2<FpField>(p, V, XX, role);
+    fp W = msm_quad_bcast<0>(r2), S = msm_quad_bcast<1>(r2), ZZ3 = msm_quad_bcast<2>(r2), MM = msm_quad_bcast<3>(r2);
+    fp M = fp_add(fp_dbl(XX), XX);
+    fp X3 = fp_sub(MM, fp_dbl(S));
+    fp r3 = ecq_stage3<FpField>(p, W, S, M, X3, role);
+    fp ZZZ3 = msm_quad_bcast<0>(r3), WY = msm_quad_bcast<1>(r3), MS = msm_quad_bcast<2>(r3);
+    p.X = X3;
+    p.Y = fp_sub(MS, WY);
+    p.ZZ = ZZ3;
+    p.ZZZ = ZZZ3;
+}
+
+// result = sum_w 2^(c w) W_w ; affine output in gnark Montgomery words + infinity flag.  G1: a quad of lanes per window shares
+// every doubling (msm_double_quad); G2 (and more windows than quads): one lane per window.
 template <class F>
 __global__ void __launch_bounds__(msm_cfg<F>::BLOCK) msm_final_kernel(const i32 *__restrict__ win_out, msm_plan pl, u64 *__restrict__ out_affine, u32 *__restrict__ out_inf) {
     const int XY = msm_cfg<F>::XYZZ;
     __shared__ i32 lds[msm_cfg<F>::BLOCK * msm_cfg<F>::XYZZ];
     ec_xyzz<F> acc = ec_infinity<F>();
-    if (threadIdx.x < pl.windows) {
+    bool quads = false;
+    if constexpr (F::LIMBS == 10) {
+        quads = 4 * pl.windows <= (u32)msm_cfg<F>::BLOCK;
+        if (quads && threadIdx.x < 4 * pl.windows) {
+            u32 w = threadIdx.x >> 2, role = threadIdx.x & 3;
+            ec_xyzz<F> p = msm_load_xyzz<F>(win_out + (size_t)w * XY);
+            u32 dbl = pl.c * w;
+#pragma unroll 1
+            for (u32 k = 0; k < dbl; k++) msm_double_quad(p, role);
+            if (role == 0) acc = p;
+        }
+    }
+    if (!quads && threadIdx.x < pl.windows) {
         acc = msm_load_xyzz<F>(win_out + (size_t)threadIdx.x * XY);
         u32 dbl = pl.c * threadIdx.x;
         for (u32 k = 0; k < dbl; k++) acc = ec_double(acc);

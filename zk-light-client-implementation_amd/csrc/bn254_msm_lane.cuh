@@ -304,6 +304,50 @@ ZKLC_HD void msm_combine_lane(const u32 *offsets, const u32 *counts, u32 key, co
     msm_store_xyzz<F>(buckets + (size_t)key * XY, acc);
 }
 
+// ---- a doubling spread over the FOUR lanes of a quad (the serial tail of the MSM: 2^(c w) * window_w is c w dependent doublings,
+// 240 of them for the top window -- 1.7 of the 10.8 ms of a 2^22 multi-exponentiation when one lane does each of them).
+// dbl-2008-s-1 has nine products in three dependent layers: {U^2, X^2}, {U V, X V, V ZZ, M^2}, {W ZZZ, W Y, M (S - X3)}; lane `role`
+// of the quad computes product `role` of each layer (operands picked by selects: one multiplication per lane and layer), the quad
+// broadcasts the results (DPP on the device) and every lane keeps the whole point.  Three multiplication-times per doubling
+// instead of nine.  These stage functions are shared with tests/hostsim, which walks the four lanes.
+template <class F>
+ZKLC_HD typename F::T ecq_select4(const typename F::T &a, const typename F::T &b, const typename F::T &c, const typename F::T &d,
+                                  u32 role) {
+    return F::select(F::select(a, b, role & 1), F::select(c, d, role & 1), role >> 1);
+}
+template <class F>
+ZKLC_HD typename F::T ecq_stage1(const ec_xyzz<F> &p, u32 role) {                   // lanes 0, 2: V = U^2; lanes 1, 3: XX = X^2
+    return F::sqr(F::select(F::dbl(p.Y), p.X, role & 1));
+}
+template <class F>
+ZKLC_HD typename F::T ecq_stage2(const ec_xyzz<F> &p, const typename F::T &V, const typename F::T &XX, u32 role) {
+    typedef typename F::T T;
+    T U = F::dbl(p.Y), M = F::add(F::dbl(XX), XX);                                  // 3 X^2 (a = 0)
+    return F::mul(ecq_select4<F>(U, p.X, V, M, role), ecq_select4<F>(V, V, p.ZZ, M, role));   // W, S, ZZ3, M^2
+}
+template <class F>
+ZKLC_HD typename F::T ecq_stage3(const ec_xyzz<F> &p, const typename F::T &W, const typename F::T &S, const typename F::T &M,
+                                 const typename F::T &X3, u32 role) {
+    return F::mul(ecq_select4<F>(W, W, M, W, role), ecq_select4<F>(p.ZZZ, p.Y, F::sub(S, X3), p.ZZZ, role));   // ZZZ3, W Y, M (S - X3)
+}
+// the same doubling on an explicit array of the four lanes' copies of the point (the CPU check of the stage functions)
+template <class F>
+ZKLC_HD void ec_double_quad_ref(ec_xyzz<F> *p4) {
+    typedef typename F::T T;
+    T r1[4], r2[4], r3[4];
+    for (u32 q = 0; q < 4; q++) r1[q] = ecq_stage1<F>(p4[q], q);
+    for (u32 q = 0; q < 4; q++) r2[q] = ecq_stage2<F>(p4[q], r1[0], r1[1], q);
+    T M = F::add(F::dbl(r1[1]), r1[1]);
+    T X3 = F::sub(r2[3], F::dbl(r2[1]));
+    for (u32 q = 0; q < 4; q++) r3[q] = ecq_stage3<F>(p4[q], r2[0], r2[1], M, X3, q);
+    for (u32 q = 0; q < 4; q++) {
+        p4[q].X = X3;
+        p4[q].Y = F::sub(r3[2], r3[1]);
+        p4[q].ZZ = r2[2];
+        p4[q].ZZZ = r3[0];
+    }
+}
+
 // k * p for a small k (k < 2^31), double-and-add
 template <class F>
 ZKLC_HD ec_xyzz<F> msm_small_mul(const ec_xyzz<F> &p, u32 k) {
