@@ -3,6 +3,7 @@
 // against the oracle without a GPU.  Never linked into libzklc_mi355.so.
 #include "../../zk-light-client-implementation_amd/csrc/ed25519_verify.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/poseidon_gl.cuh"
+#include "../../zk-light-client-implementation_amd/csrc/goldilocks_ntt_group.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/bn254_msm_lane.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/poseidon_bn254.cuh"
 #include "../../zk-light-client-implementation_amd/csrc/plonky2_gates.cuh"
@@ -430,6 +431,34 @@ void hostsim_fr_ntt_two_pass(u64 *data, u32 log_n, u32 inverse, u32 coset) {
             for (u32 b = 0; b < N2 / 2; b++) frn_tile_butterfly(tile.data(), p.t2, t, b, tab.data() + (size_t)frn_off_loc2(p) * 10);
         for (u32 k2 = 0; k2 < N2; k2++) frn_pass_b_out(data, frn_tile_load(tile.data(), N2, k2), tab.data(), p, k1, k2, coset && inverse);
     }
+}
+// x * 2^e (e < 96) of the NTT group's inner twiddles
+u64 hostsim_gl_mul_2exp(u64 x, u32 e) { return gl_mul_2exp(x, e); }
+// One butterfly group of the Goldilocks NTT passes in both forms: the product's (shift twiddles inside, one table multiplication
+// per element outside) and the plain definition (every butterfly with its full twiddle).  x: 2^g values, overwritten with the
+// product form's result; plain: receives the definition's.  Returns the number of elements (0 = unsupported g).
+u32 hostsim_gl_ntt_group(u32 g, u32 dit, u32 inverse, u32 logn, u32 s_first, u64 J, u64 *x, u64 *plain) {
+    u64 w = gl_root_of_unity(logn);
+    if (inverse) w = gl_inv(w);
+    const u32 M = 1u << g;
+    u64 tab[16];
+    for (u32 m = 1; m < M; m++) tab[m - 1] = gl_pow(w, ((u64)gl_bitrev_small(m, (int)g) * J) << s_first);
+    for (u32 m = 0; m < M; m++) plain[m] = x[m];
+#define GRP(G)                                                                                       \
+    case G:                                                                                          \
+        if (dit) {                                                                                   \
+            gl_ntt_group_plain<G, true>(plain, w, logn, s_first, J);                                 \
+            if (inverse) gl_ntt_group_regs<G, true, true>(x, tab); else gl_ntt_group_regs<G, true, false>(x, tab);    \
+        } else {                                                                                     \
+            gl_ntt_group_plain<G, false>(plain, w, logn, s_first, J);                                \
+            if (inverse) gl_ntt_group_regs<G, false, true>(x, tab); else gl_ntt_group_regs<G, false, false>(x, tab);  \
+        }                                                                                            \
+        return M;
+    switch (g) {
+        GRP(1) GRP(2) GRP(3) GRP(4)
+    }
+#undef GRP
+    return 0;
 }
 u32 hostsim_g2_op(int op, const u32 *p32, const u32 *q32, u32 *out32) {
     g2_xyzz a;

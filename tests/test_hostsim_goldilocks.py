@@ -98,6 +98,38 @@ def test_loose_arithmetic_edges(hostsim):
             assert hostsim.hostsim_gl_acc3(x.ctypes.data, k.ctypes.data, n, fold) == want, (n, fold)
 
 
+def test_ntt_group_shift_twiddles_equal_the_definition(hostsim):
+    """csrc/goldilocks_ntt_group.cuh: 2^39 is the 64th root of unity of plonky2's generator, x * 2^e, and a butterfly group with
+    shift twiddles inside + one table multiplication per element == every butterfly with its full twiddle, for every group size,
+    both stage orders and both directions."""
+    assert pow(2, 39, P) == pow(1753635133440165772, 2**32 // 64, P)
+    assert gl.root_of_unity(6) == pow(2, 39, P)
+    rng = random.Random(7)
+    f = hostsim.hostsim_gl_mul_2exp
+    f.restype = ctypes.c_uint64
+    f.argtypes = [ctypes.c_uint64, ctypes.c_uint32]
+    edge = [0, 1, P - 1, 2**32 - 1, 2**32, 2**63, 0xFFFFFFFF00000000, P - 2**32]
+    for e in range(96):
+        for x in edge + [rng.randrange(P) for _ in range(20)]:
+            assert f(x, e) == x * pow(2, e, P) % P, (x, e)
+    grp = hostsim.hostsim_gl_ntt_group
+    grp.restype = ctypes.c_uint32
+    grp.argtypes = [ctypes.c_uint32] * 5 + [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    for g in (1, 2, 3, 4):
+        for dit in (0, 1):
+            for inverse in (0, 1):
+                for _ in range(6):
+                    logn = rng.randrange(g, 25)
+                    s_first = rng.randrange(0, logn - g + 1)
+                    J = rng.randrange(1 << (logn - s_first - g))
+                    m = 1 << g
+                    xs = [rng.choice(edge[:3] + [rng.randrange(P)]) for _ in range(m)]
+                    x = (ctypes.c_uint64 * m)(*xs)
+                    pl = (ctypes.c_uint64 * m)()
+                    assert grp(g, dit, inverse, logn, s_first, J, x, pl) == m
+                    assert list(x) == list(pl), (g, dit, inverse, logn, s_first, J)
+
+
 def test_poseidon_asm_generator_selftest_and_committed_file_is_current():
     """csrc/poseidon_gl_asm.inc (the hand-scheduled gfx950 statements of the permutation) is generated by
     tools/gen_poseidon_asm.py: every instruction list is executed by the generator's simulator against big-integer arithmetic
@@ -115,3 +147,18 @@ def test_poseidon_asm_generator_selftest_and_committed_file_is_current():
     before = open(path).read()
     g.main()
     assert open(path).read() == before, "poseidon_gl_asm.inc is stale: run tools/gen_poseidon_asm.py"
+
+
+def test_mul_asm_generator_selftest_and_committed_file_is_current():
+    """tools/gen_gl_asm.py: the batched multiplication statements of the NTT passes -- every instruction list is executed against
+    big-integer arithmetic (canonical results for any 64-bit operands, edge values included), the flag-hazard and constant-bus rules
+    are checked, and csrc/goldilocks_mul_asm.inc is what the generator writes."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_gl_asm", os.path.join(root, "tools", "gen_gl_asm.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert gen.selftest()
+    text = open(os.path.join(root, "zk-light-client-implementation_amd", "csrc", "goldilocks_mul_asm.inc")).read()
+    assert text == gen.render()

@@ -14,17 +14,19 @@
 #define GL_GENERATOR 7ULL
 #define GL_POWER_OF_TWO_GENERATOR 1753635133440165772ULL
 
+// The three primitives below are written so that hipcc emits the short forms (gfx950: v_lshl_add_u64 is a one-instruction 64-bit
+// add, v_cmp_*_u64 a one-instruction compare): "add 2^32 - 1 if the sum wrapped OR is >= p" is ONE select + ONE add for both
+// conditions (wrapped: 2^64 = EPS; >= p: s - p = s + EPS mod 2^64).  5 / 6 / ~10 instructions; the textbook forms with two selects
+// were 9 / 6 / 14 (tools/ubench counts; every prover kernel is integer-issue-bound).
 ZKLC_HD u64 gl_add(u64 a, u64 b) {
     u64 s = a + b;
-    // a + b overflowed 2^64: fold 2^64 = EPS (cannot overflow again, result < p);
-    // otherwise a single conditional subtraction of p
-    u64 wrapped = s + GL_EPS;
-    u64 sub = s - GL_P;
-    return (s < a) ? wrapped : (s >= GL_P ? sub : s);
+    // canonical inputs: a wrapped sum s + 2^64 = s + EPS cannot wrap again and is < p; an unwrapped s >= p is < 2p
+    bool fix = (s < a) | (s >= GL_P);
+    return s + (fix ? GL_EPS : 0);
 }
 ZKLC_HD u64 gl_sub(u64 a, u64 b) {
     u64 d = a - b;
-    return (a < b) ? d + GL_P : d;
+    return d - ((a < b) ? GL_EPS : 0);      // borrow: d + p = d - EPS (mod 2^64)
 }
 ZKLC_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 ZKLC_HD u64 gl_double(u64 a) { return gl_add(a, a); }
@@ -32,12 +34,12 @@ ZKLC_HD u64 gl_double(u64 a) { return gl_add(a, a); }
 // (hi:lo) mod p for any 128-bit value
 ZKLC_HD u64 gl_reduce128(u64 lo, u64 hi) {
     u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
-    u64 t0 = lo - hi_hi;  // 2^96 = -1
-    if (lo < hi_hi) t0 -= GL_EPS;  // borrow: -2^64 = -EPS
-    u64 t1 = hi_lo * GL_EPS;  // 2^64 = EPS ; (hi_lo << 32) - hi_lo
-    u64 r = t0 + t1;
-    if (r < t1) r += GL_EPS;  // carry
-    return r >= GL_P ? r - GL_P : r;
+    u64 t0 = lo - hi_hi;                      // 2^96 = -1
+    t0 -= (lo < hi_hi) ? GL_EPS : 0;          // borrow: -2^64 = -EPS (no second borrow: lo - hi_hi + 2^64 > EPS)
+    u64 r = t0 + hi_lo * GL_EPS;              // 2^64 = EPS ; the product is <= 2^64 - 2^33 + 1 (one v_mad_u64_u32 with t0 as addend)
+    // carry: r + EPS <= p - 2, no second carry; no carry and r >= p: r - p = r + EPS (mod 2^64); never both (a carried r is < p)
+    bool fix = (r < t0) | (r >= GL_P);
+    return r + (fix ? GL_EPS : 0);
 }
 
 // "Loose" arithmetic: values are any u64 congruent to the field element (not necessarily < p).  Products and reduce128

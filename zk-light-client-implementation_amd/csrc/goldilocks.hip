@@ -11,6 +11,7 @@
 // "transpose to row-major leaves" pass of the CPU prover disappears.
 #include <stdlib.h>
 #include "poseidon_gl.cuh"
+#include "goldilocks_ntt_group.cuh"
 #include "zklc_internal.h"
 
 #define NTT_THREADS 256
@@ -56,6 +57,10 @@ struct ntt_pass {
     int log_in;        // input indices >= 2^log_in read as zero (LDE zero padding); = logn otherwise
     int scale_shift;   // log2 of the low table size of the two-level load scale (0 = no load scale)
     u64 out_scale;     // multiplied into every stored value when != 1 (1/n of the inverse transform)
+    // shift-twiddle kernel (gl_ntt_pass_g4_kernel): the k stages in ng groups of gsz[i] <= 4 stages (top stage first); goff[i] =
+    // offset of the group's block in the table of per-element twiddles (gl_get_group_twiddles)
+    int ng, gsz[4];
+    u64 goff[4];
 };
 
 template <bool DIT>
@@ -232,6 +237,104 @@ gl_ntt_pass_r8_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t 
     }
 }
 
+// ---- shift-twiddle variant (the product path; goldilocks_ntt_group.cuh): groups of up to FOUR stages, a lane holds the 16
+// elements of a group; the twiddles inside a group are powers of two (shifts), the rest of every butterfly's twiddle is collected
+// into one multiplication per element by an entry of the group's table block  tab[goff + (m - 1) * NJ + J] = w^((bitrev_g(m) J) << s').
+// 15 general multiplications + 17 shifts per 32 butterflies instead of 32 multiplications, and ceil(k / 4) LDS round trips per
+// pass.  LDS tile padded by one element per 16 (unit-stride and stride-16 / stride-8 groups all spread over the banks).
+#define NTT_TJ(e) ((e) + ((e) >> 4))
+template <int G, bool DIT, bool INV>
+ZKLC_D void gl_ntt_group_lds(u64 *tile, const u64 *__restrict__ tabJ, u64 nj, u32 base, int pb_low) {
+    constexpr int M = 1 << G;
+    u64 x[M], t[M - 1 > 0 ? M - 1 : 1];
+#pragma unroll
+    for (int m = 1; m < M; m++) t[m - 1] = tabJ[(u64)(m - 1) * nj];
+#pragma unroll
+    for (int m = 0; m < M; m++) x[m] = tile[NTT_TJ(base | ((u32)m << pb_low))];
+    gl_ntt_group_regs<G, DIT, INV>(x, t);
+#pragma unroll
+    for (int m = 0; m < M; m++) tile[NTT_TJ(base | ((u32)m << pb_low))] = x[m];
+}
+
+template <bool DIT, bool INV>
+__global__ void __launch_bounds__(NTT_THREADS_MAX)
+gl_ntt_pass_g4_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t in_stride, size_t out_stride, ntt_pass p,
+                      const u64 *__restrict__ tab, const u64 *__restrict__ scale_hi, const u64 *__restrict__ scale_lo) {
+    extern __shared__ u64 tile[];      // 2^(k+c+d) elements + one pad per 16 (NTT_TJ)
+    const u32 n_threads = blockDim.x;
+    const int tile_log = p.k + p.c + p.d;
+    const int tile_n = 1 << tile_log;
+    const int lowbits = p.logn - p.s0 - p.k;
+    const u32 tid = threadIdx.x;
+    const u64 t_id = blockIdx.x;
+    const u64 tileL = t_id & ((1ULL << (lowbits - p.c)) - 1);
+    const u64 tileH = t_id >> (lowbits - p.c);
+    const u64 *src = in + (size_t)blockIdx.y * in_stride;
+    u64 *dst = out + (size_t)blockIdx.y * out_stride;
+
+    auto global_index = [&](u32 e) -> u64 {
+        u64 lowc = e & ((1u << p.c) - 1);
+        u64 mid = (e >> p.c) & ((1u << p.k) - 1);
+        u64 hid = e >> (p.c + p.k);
+        u64 L = (tileL << p.c) | lowc;
+        u64 H = (tileH << p.d) | hid;
+        return (H << (lowbits + p.k)) | (mid << lowbits) | L;
+    };
+
+    for (u32 e = tid; e < (u32)tile_n; e += n_threads) {
+        u64 g = global_index(e);
+        u64 v = 0;
+        if (g < (1ULL << p.log_in)) {
+            v = src[g];
+            if (p.scale_shift) v = gl_mul(v, gl_mul(scale_hi[g >> p.scale_shift], scale_lo[g & ((1u << p.scale_shift) - 1)]));
+        }
+        tile[NTT_TJ(e)] = v;
+    }
+    __syncthreads();
+
+    for (int gg = 0; gg < p.ng; gg++) {
+        const int gi_ = DIT ? (p.ng - 1 - gg) : gg;         // DIT runs the groups (and the stages inside them) backwards
+        const int g = p.gsz[gi_];
+        int t0 = 0;                                          // first (lowest-numbered) stage of the group
+        for (int q = 0; q < gi_; q++) t0 += p.gsz[q];
+        const int mg = p.k - g - t0;                         // number of `mid` bits below the group
+        const int pb_low = p.c + mg;
+        const u64 nj = 1ULL << (mg + lowbits);
+        const u64 *gtab = tab + p.goff[gi_];
+        const u32 n_groups = (u32)tile_n >> g;
+        for (u32 gi = tid; gi < n_groups; gi += n_threads) {
+            u32 base = ((gi >> pb_low) << (pb_low + g)) | (gi & ((1u << pb_low) - 1));
+            u64 lowc = base & ((1u << p.c) - 1);
+            u64 mid_low = (base >> p.c) & ((1u << mg) - 1);
+            u64 J = (mid_low << lowbits) | ((tileL << p.c) | lowc);
+            if (g == 4)
+                gl_ntt_group_lds<4, DIT, INV>(tile, gtab + J, nj, base, pb_low);
+            else if (g == 3)
+                gl_ntt_group_lds<3, DIT, INV>(tile, gtab + J, nj, base, pb_low);
+            else if (g == 2)
+                gl_ntt_group_lds<2, DIT, INV>(tile, gtab + J, nj, base, pb_low);
+            else
+                gl_ntt_group_lds<1, DIT, INV>(tile, gtab + J, nj, base, pb_low);
+        }
+        __syncthreads();
+    }
+
+    for (u32 e = tid; e < (u32)tile_n; e += n_threads) {
+        u64 v = tile[NTT_TJ(e)];
+        if (p.out_scale != 1) v = gl_mul(v, p.out_scale);
+        dst[global_index(e)] = v;
+    }
+}
+
+// block of one group in the table of per-element twiddles: out[(m - 1) * nj + J] = w^((bitrev_g(m) * J) << s_first), 1 <= m < 2^g
+__global__ void gl_group_twiddle_kernel(u64 *out, u64 w, u32 g, u32 s_first, u64 nj) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ((1ULL << g) - 1) * nj) return;
+    u32 m = 1 + (u32)(i / nj);
+    u64 J = i % nj;
+    out[i] = gl_pow(w, ((u64)gl_bitrev_small(m, (int)g) * J) << s_first);
+}
+
 // out[i] = in[bitrev(i)] (per polynomial)
 __global__ void __launch_bounds__(256) gl_bitrev_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t stride, int logn) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -383,7 +486,10 @@ void zklc_gl_fini(zklc_ctx *ctx) {
         if (ctx->gl_tw_inv[i]) (void)hipFree(ctx->gl_tw_inv[i]);
         if (ctx->gl_tws_fwd[i]) (void)hipFree(ctx->gl_tws_fwd[i]);
         if (ctx->gl_tws_inv[i]) (void)hipFree(ctx->gl_tws_inv[i]);
+        if (ctx->gl_twg_fwd[i]) (void)hipFree(ctx->gl_twg_fwd[i]);
+        if (ctx->gl_twg_inv[i]) (void)hipFree(ctx->gl_twg_inv[i]);
         ctx->gl_tw_fwd[i] = ctx->gl_tw_inv[i] = ctx->gl_tws_fwd[i] = ctx->gl_tws_inv[i] = nullptr;
+        ctx->gl_twg_fwd[i] = ctx->gl_twg_inv[i] = nullptr;
     }
     if (ctx->gl_scale_hi) (void)hipFree(ctx->gl_scale_hi);
     if (ctx->gl_scale_lo) (void)hipFree(ctx->gl_scale_lo);
@@ -450,14 +556,21 @@ static int32_t gl_ntt_run(zklc_ctx *ctx, hipStream_t st, const u64 *in, size_t i
         return ZKLC_OK;
     }
     static const bool radix2 = getenv("ZKLC_NTT_RADIX2") != nullptr;   // A/B switch: the original one-stage-per-barrier loop
+    static const bool r8 = getenv("ZKLC_NTT_R8") != nullptr;           // A/B switch: radix-8 groups with a table twiddle per butterfly
     static const bool lds_ok = [] {     // 72 KB of dynamic LDS is above the default 64 KB cap
         const int bytes = ((1 << NTT_TILE_LOG_BIG) + (1 << NTT_TILE_LOG_BIG) / 8) * (int)sizeof(u64);
         return hipFuncSetAttribute((const void *)gl_ntt_pass_r8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void *)gl_ntt_pass_r8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+               hipFuncSetAttribute((const void *)gl_ntt_pass_r8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void *)gl_ntt_pass_g4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void *)gl_ntt_pass_g4_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void *)gl_ntt_pass_g4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+               hipFuncSetAttribute((const void *)gl_ntt_pass_g4_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
     if (!lds_ok) return ZKLC_ERR_HIP;
-    const u64 *tw;
-    int32_t rc = radix2 ? gl_get_twiddles(ctx, st, logn, inverse, &tw) : gl_get_staged_twiddles(ctx, st, logn, inverse, &tw);
+    const bool g4 = !radix2 && !r8;
+    const u64 *tw = nullptr;
+    int32_t rc = ZKLC_OK;
+    if (!g4) rc = radix2 ? gl_get_twiddles(ctx, st, logn, inverse, &tw) : gl_get_staged_twiddles(ctx, st, logn, inverse, &tw);
     if (rc) return rc;
     if (load_shift) {
         if ((rc = gl_get_scale(ctx, st, load_shift, log_in))) return rc;
@@ -485,6 +598,41 @@ static int32_t gl_ntt_run(zklc_ctx *ctx, hipStream_t st, const u64 *in, size_t i
         s0_of[i] = s0;
         s0 += ks[i];
     }
+    // groups of <= 4 stages per pass (sizes as even as possible: 13 = 4 + 3 + 3 + 3) and their blocks in the twiddle table; the
+    // plan depends on logn only, so the table is built once per (logn, direction) and context
+    int ng_of[8], gsz_of[8][4];
+    u64 goff_of[8][4], tab_elems = 0;
+    for (int i = 0; i < np; i++) {
+        int ng = (ks[i] + 3) / 4, base = ks[i] / ng, extra = ks[i] % ng, t0 = 0;
+        ng_of[i] = ng;
+        for (int j = 0; j < ng; j++) {
+            int g = base + (j < extra ? 1 : 0);
+            gsz_of[i][j] = g;
+            goff_of[i][j] = tab_elems;
+            tab_elems += ((1ULL << g) - 1) << (logn - (s0_of[i] + t0) - g);
+            t0 += g;
+        }
+    }
+    if (g4) {
+        void **slot = inverse ? &ctx->gl_twg_inv[logn] : &ctx->gl_twg_fwd[logn];
+        if (!*slot) {
+            ZKLC_HIP(ctx, hipMalloc(slot, tab_elems * 8));
+            u64 w = host_gl_pow(GL_POWER_OF_TWO_GENERATOR, 1ULL << (32 - logn));
+            if (inverse) w = host_gl_pow(w, GL_P - 2);
+            for (int i = 0; i < np; i++) {
+                int t0 = 0;
+                for (int j = 0; j < ng_of[i]; j++) {
+                    int g = gsz_of[i][j], sf = s0_of[i] + t0;
+                    u64 nj = 1ULL << (logn - sf - g), cnt = ((1ULL << g) - 1) * nj;
+                    hipLaunchKernelGGL(gl_group_twiddle_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st,
+                                       (u64 *)*slot + goff_of[i][j], w, (u32)g, (u32)sf, nj);
+                    t0 += g;
+                }
+            }
+            ZKLC_HIP(ctx, hipGetLastError());
+        }
+        tw = (const u64 *)*slot;
+    }
     for (int ii = 0; ii < np; ii++) {
         int i = dit ? (np - 1 - ii) : ii;  // DIT runs the windows bottom-up
         ntt_pass p;
@@ -499,10 +647,28 @@ static int32_t gl_ntt_run(zklc_ctx *ctx, hipStream_t st, const u64 *in, size_t i
         p.log_in = first ? log_in : logn;
         p.scale_shift = (first && load_shift) ? GL_SCALE_LO_LOG : 0;
         p.out_scale = last ? n_inv : 1;
+        p.ng = ng_of[i];
+        for (int j = 0; j < 4; j++) {
+            p.gsz[j] = j < ng_of[i] ? gsz_of[i][j] : 0;
+            p.goff[j] = j < ng_of[i] ? goff_of[i][j] : 0;
+        }
         const u64 *src = first ? in : out;
         size_t sstride = first ? in_stride : out_stride;
         dim3 grid((unsigned)(1ULL << (logn - (p.k + p.c + p.d))), batch);
-        if (radix2) {
+        if (g4) {
+            const int tile_log = p.k + p.c + p.d;
+            const unsigned threads = tile_log > NTT_TILE_LOG_MAX ? NTT_THREADS_MAX : NTT_THREADS;
+            const size_t lds = ((size_t(1) << tile_log) + (size_t(1) << tile_log) / 16) * sizeof(u64);
+            const u64 *sh = (const u64 *)ctx->gl_scale_hi, *sl = (const u64 *)ctx->gl_scale_lo;
+            if (dit && inverse)
+                hipLaunchKernelGGL((gl_ntt_pass_g4_kernel<true, true>), grid, dim3(threads), lds, st, src, out, sstride, out_stride, p, tw, sh, sl);
+            else if (dit)
+                hipLaunchKernelGGL((gl_ntt_pass_g4_kernel<true, false>), grid, dim3(threads), lds, st, src, out, sstride, out_stride, p, tw, sh, sl);
+            else if (inverse)
+                hipLaunchKernelGGL((gl_ntt_pass_g4_kernel<false, true>), grid, dim3(threads), lds, st, src, out, sstride, out_stride, p, tw, sh, sl);
+            else
+                hipLaunchKernelGGL((gl_ntt_pass_g4_kernel<false, false>), grid, dim3(threads), lds, st, src, out, sstride, out_stride, p, tw, sh, sl);
+        } else if (radix2) {
             if (dit)
                 hipLaunchKernelGGL(gl_ntt_pass_kernel<true>, grid, dim3(NTT_THREADS), 0, st, src, out, sstride, out_stride, p, tw,
                                    (const u64 *)ctx->gl_scale_hi, (const u64 *)ctx->gl_scale_lo);

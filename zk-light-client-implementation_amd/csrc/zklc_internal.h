@@ -26,6 +26,9 @@ struct zklc_ctx {
     // staged tables (per stage s: w^(j << s) contiguous), used by the radix-8 passes
     void *gl_tws_fwd[ZKLC_GL_MAX_LOG + 1] = {};
     void *gl_tws_inv[ZKLC_GL_MAX_LOG + 1] = {};
+    // per-element group twiddles of the shift-twiddle passes (goldilocks_ntt_group.cuh): blocks w^((bitrev_g(m) J) << s') per group
+    void *gl_twg_fwd[ZKLC_GL_MAX_LOG + 1] = {};
+    void *gl_twg_inv[ZKLC_GL_MAX_LOG + 1] = {};
     // two-level table of coset-shift powers (shift^j = hi[j >> 10] * lo[j & 1023])
     void *gl_scale_hi = nullptr, *gl_scale_lo = nullptr;
     uint64_t gl_scale_shift = 0;
