@@ -274,11 +274,17 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
 
     def msm_step(d_pts=d_pts, d_sc=d_sc, n=n):
         ctx.bn254_g1_msm_dev(d_pts, d_sc, n, d_out, d_inf, d_ws, wb, stream=stream)
-        if world > 1 and dist.get_backend() == "nccl":
+        if world > 1:
             with torch.cuda.stream(stream):
                 d_out[8] = d_inf[0]
-                dist.all_gather(gathered, d_out)
-                g = torch.stack(gathered)
+                if dist.get_backend() == "nccl":
+                    dist.all_gather(gathered, d_out)
+                    g = torch.stack(gathered)
+                else:       # gloo (functional runs with several ranks on one GPU): the 72-byte partials travel through the host
+                    stream.synchronize()
+                    hs = [torch.zeros(9, dtype=torch.int64) for _ in range(world)]
+                    dist.all_gather(hs, d_out.cpu())
+                    g = torch.stack(hs).to(dev)
                 d_cpts.copy_(g[:, :8] * (g[:, 8:9] == 0))            # infinity partials -> (0, 0)
             ctx.bn254_g1_msm_dev(d_cpts, d_ones, world, d_final, d_inf[1:], d_ws2, wb2, stream=stream)
 
@@ -302,7 +308,7 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
         assert np.array_equal(got, want), "GPU MSM differs from the oracle"
         msm["cpu_baseline"] = {"value": n / dt / 1e6, "unit": "Melem/s", "cores": used, "kind": "port",
                                "sample": "the same 2^%d-point MSM once, oracle/c/bn254_oracle.c (also the parity check)" % args.msm_log}
-    if world > 1 and dist.get_backend() == "nccl":
+    if world > 1:
         # STRONG form (distributed.msm_sharded): ONE 2^msm_log instance, index-sharded over the ranks; every rank reduces its
         # shard to one point, the partials are all-gathered (world x 72 bytes over RCCL) and added locally.  Rank 0 also computes the
         # whole instance alone: the sharded result must be the same affine point.

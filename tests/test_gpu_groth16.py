@@ -51,3 +51,25 @@ def test_groth16_prove_on_the_gpu_equals_the_oracle_and_verifies(zctx):
     w[-1] = (w[-1] + 1) % G.R
     got = prover.prove(w, G.abc_evaluations(r1cs, w, pk["n"]), 5, 6)
     assert not G.verify(vk, ((got[0], got[1]), ((got[3], got[2]), (got[5], got[4])), (got[6], got[7])), [1, 2, 3])
+
+
+def test_proving_key_with_infinity_points_removed(zctx):
+    """gnark stores G1.A / G1.B / G2.B without their points at infinity and marks the positions (InfinityA / InfinityB); the prover
+    filters the wire values accordingly.  The compacted key + masks must give the proof of the complete key."""
+    n_con, n_pub = 40, 2
+    r1cs, wit = G.square_chain_r1cs(n_con, n_public=n_pub)
+    pk, _ = G.setup(r1cs, n_pub, (0x1234567891, 0xabcdef12345, 0x777766665555, 0x3133731337, 0x42424242))
+    inf_a = np.array([p is None for p in pk["A"]])
+    inf_b = np.array([p is None for p in pk["B1"]])
+    assert inf_a.any() or inf_b.any(), "the test system should have wires that occur in no A or B column"
+    assert [p is None for p in pk["B2"]] == list(inf_b)
+    compact = dict(pk)
+    compact["A"] = [p for p in pk["A"] if p is not None]
+    compact["B1"] = [p for p in pk["B1"] if p is not None]
+    compact["B2"] = [p for p in pk["B2"] if p is not None]
+    compact["infinity_a"], compact["infinity_b"] = inf_a, inf_b
+    w = wit([5, 6], 9)
+    abc = G.abc_evaluations(r1cs, w, pk["n"])
+    full = Groth16Prover(zctx, pk).prove(w, abc, 12345, 67890)
+    assert Groth16Prover(zctx, compact).prove(w, abc, 12345, 67890) == full
+    assert full == G.proof_to_uint256x8(G.prove(pk, r1cs, w, 12345, 67890))

@@ -25,6 +25,7 @@ hi = G.hi
 VB = 64
 FB, NF = 36, 12
 TMP_PER_STREAM = 8
+TMP_PER_RANGE_STREAM = 14
 
 
 def T(n):
@@ -143,6 +144,35 @@ def build_mul(n):
     return prog, [r for o in outs for r in o], [r for x in a for r in x] + [r for x in b for r in x], nops
 
 
+def range4_stream(x, out, base, fa, fd):
+    """out = x (x - 1)(x - 2)(x - 3) = y (y + 2), y = x (x - 3): the range check of a two-bit limb (plonky2_gates.cuh:
+    p2_range_product), loose result.  x canonical.  Temporaries T(base .. base+13)."""
+    sc, f = (T(base), T(base + 2), T(base + 4)), T(base + 6)
+    D, Y, Y2 = T(base + 8), T(base + 10), T(base + 12)
+    return ([
+        ("sub_co", D, fa, x[0], 3),
+        ("subb", hi(D), fa, x[1], 0, fa),
+        ("cnd", f, 0, -1, fa),                         # borrow: x - 3 + 2^64 is eps too large
+        ("sub_co", D, fa, D, f),
+        ("subb", hi(D), fd, hi(D), 0, fa),
+    ] + G.mulmod(x, (D, hi(D)), (Y, hi(Y)), sc, f, fa, fd) + [
+        ("add_co", Y2, fa, Y, 2),
+        ("addc", hi(Y2), fa, hi(Y), 0, fa),
+        ("cnd", f, 0, -1, fa),                         # carry: y + 2 - 2^64 is eps too small
+        ("add_co", Y2, fa, Y2, f),
+        ("addc", hi(Y2), fd, hi(Y2), 0, fa),
+    ] + G.mulmod((Y, hi(Y)), (Y2, hi(Y2)), out, sc, f, fa, fd))
+
+
+def build_range4(n):
+    fd = F(NF - 1)
+    outs = [("r%dl" % k, "r%dh" % k) for k in range(n)]
+    x = [("x%dl" % k, "x%dh" % k) for k in range(n)]
+    streams = [range4_stream(x[k], outs[k], TMP_PER_RANGE_STREAM * k, F(k), fd) for k in range(n)]
+    prog, nops = G.schedule(streams)
+    return prog, [r for o in outs for r in o], [r for v in x for r in v], nops
+
+
 def check_constant_bus(prog):
     G.check_constant_bus([i for i in prog if i[0] != "sor"])
 
@@ -182,6 +212,19 @@ def selftest():
             for k in range(n):
                 got = R["r%dl" % k] | (R["r%dh" % k] << 32)
                 assert got == vals[k] * vals[n + k] % P, ("mul%d" % n, k, vals)
+    for n in (2, 3, 4):
+        prog, outs, ins, _ = build_range4(n)
+        G.check_hazards(prog)
+        check_constant_bus(prog)
+        for it in range(300):
+            vals = [rng.choice([0, 1, 2, 3, 4, P - 1, P - 2]) if rng.random() < 0.4 else rng.randrange(P) for _ in range(n)]
+            regs = {}
+            for k, v in enumerate(vals):
+                regs["x%dl" % k], regs["x%dh" % k] = v & M32, v >> 32
+            R = simulate(prog, regs)
+            for k, v in enumerate(vals):
+                got = R["r%dl" % k] | (R["r%dh" % k] << 32)
+                assert got % P == v * (v - 1) * (v - 2) * (v - 3) % P, ("range4_%d" % n, k, v)
     return True
 
 
@@ -195,6 +238,14 @@ def render():
         check_constant_bus(prog)
         parts.append(statement("gl_mul%d_asm" % n, prog, outs, ins, TMP_PER_STREAM * n,
                                "r_k = a_k * b_k mod p (canonical), k < %d: %d instructions, %d s_nop" % (n, len(prog) - nops, nops)))
+        parts.append("")
+    for n in (2, 3, 4):
+        prog, outs, ins, nops = build_range4(n)
+        G.check_hazards(prog)
+        check_constant_bus(prog)
+        parts.append(statement("p2_range4_%d_asm" % n, prog, outs, ins, TMP_PER_RANGE_STREAM * n,
+                               "r_k = x_k (x_k - 1)(x_k - 2)(x_k - 3) mod p (loose; x_k canonical), k < %d: %d instructions, %d s_nop"
+                               % (n, len(prog) - nops, nops)))
         parts.append("")
     return "\n".join(parts)
 

@@ -16,6 +16,9 @@
 #pragma once
 #include "gl_ext.cuh"
 #include "poseidon_gl.cuh"
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKLC_GL_NO_MUL_ASM)
+#include "goldilocks_mul_asm.inc"
+#endif
 
 #define P2_MAX_CH 2
 #define P2_UNUSED_SELECTOR 0xFFFFFFFFULL
@@ -106,6 +109,49 @@ ZKLC_D u64 p2_range_product(u64 x, u32 base) {
     u64 acc = x;
     for (u32 k = 1; k < base; k++) acc = gl_mul_loose(acc, gl_sub(x, k));
     return acc;
+}
+// The range checks of N two-bit limbs, r[q] = p2_range_product(x[q], 4) (loose), x canonical.  On the device in batches of four /
+// three / two limbs per asm statement (tools/gen_gl_asm.py: 44 instructions per limb with the carries in SGPR pairs and the limbs
+// of a batch interleaved; the compiled form is 58): the two-bit limbs are ~70 % of the constraints of the Ed25519 circuit.
+template <int N>
+ZKLC_D void p2_range_products4(const u64 *x, u64 *r) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(ZKLC_GL_NO_MUL_ASM)
+#define P2_LO(v) ((u32)(v))
+#define P2_HI(v) ((u32)((v) >> 32))
+#define P2_PACK(l, h) ((u64)(l) | ((u64)(h) << 32))
+    int i = 0;
+#pragma unroll
+    for (; i + 4 <= N && (N - i) != 5 && (N - i) != 6; i += 4) {      // 5 = 3 + 2, 6 = 3 + 3, never 4 + 1
+        u32 r0l, r0h, r1l, r1h, r2l, r2h, r3l, r3h;
+        p2_range4_4_asm(r0l, r0h, r1l, r1h, r2l, r2h, r3l, r3h, P2_LO(x[i]), P2_HI(x[i]), P2_LO(x[i + 1]), P2_HI(x[i + 1]), P2_LO(x[i + 2]),
+                        P2_HI(x[i + 2]), P2_LO(x[i + 3]), P2_HI(x[i + 3]));
+        r[i] = P2_PACK(r0l, r0h);
+        r[i + 1] = P2_PACK(r1l, r1h);
+        r[i + 2] = P2_PACK(r2l, r2h);
+        r[i + 3] = P2_PACK(r3l, r3h);
+    }
+#pragma unroll
+    for (; N - i >= 3; i += 3) {
+        u32 r0l, r0h, r1l, r1h, r2l, r2h;
+        p2_range4_3_asm(r0l, r0h, r1l, r1h, r2l, r2h, P2_LO(x[i]), P2_HI(x[i]), P2_LO(x[i + 1]), P2_HI(x[i + 1]), P2_LO(x[i + 2]), P2_HI(x[i + 2]));
+        r[i] = P2_PACK(r0l, r0h);
+        r[i + 1] = P2_PACK(r1l, r1h);
+        r[i + 2] = P2_PACK(r2l, r2h);
+    }
+    if (N - i == 2) {
+        u32 r0l, r0h, r1l, r1h;
+        p2_range4_2_asm(r0l, r0h, r1l, r1h, P2_LO(x[i]), P2_HI(x[i]), P2_LO(x[i + 1]), P2_HI(x[i + 1]));
+        r[i] = P2_PACK(r0l, r0h);
+        r[i + 1] = P2_PACK(r1l, r1h);
+        i += 2;
+    }
+    if (N - i == 1) r[i] = p2_range_product(x[i], 4);
+#undef P2_LO
+#undef P2_HI
+#undef P2_PACK
+#else
+    for (int q = 0; q < N; q++) r[q] = p2_range_product(x[q], 4);
+#endif
 }
 // 4 * a for a loose a: (a << 2) + (a >> 62) * (2^32 - 1), one wrap possible
 ZKLC_D u64 p2_mul4_loose(u64 a) {
@@ -199,8 +245,15 @@ ZKLC_D void p2_eval_base_sum(const V &v, u32 num_limbs, u32 base, p2_consumer &o
     for (; i + 8 <= num_limbs; i += 8) {
         u64 l[8];
         p2_load<8>(v, 1 + i, l);
+        if (base == 4) {
+            u64 rp[8];
+            p2_range_products4<8>(l, rp);
 #pragma unroll
-        for (int q = 0; q < 8; q++) out.emit(p2_range_product(l[q], base));
+            for (int q = 0; q < 8; q++) out.emit(rp[q]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++) out.emit(p2_range_product(l[q], base));
+        }
     }
     for (; i < num_limbs; i++) out.emit(p2_range_product(v.w(1 + i), base));
 }
@@ -403,14 +456,21 @@ ZKLC_D void p2_eval_u32_arithmetic(const V &v, u32 num_ops, p2_consumer &out) {
         out.emit(gl_mul(hi_not_max, lo));
         out.emit(gl_sub(gl_add(gl_mul(hi, 1ULL << 32), lo), computed));
         u64 comb_lo = 0, comb_hi = 0;
+        u64 rev[16], rp[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) rev[j] = lh[15 - j];
+        p2_range_products4<16>(rev, rp);
 #pragma unroll
         for (int j = 15; j >= 0; j--) {
-            out.emit(p2_range_product(lh[j], 4));
+            out.emit(rp[15 - j]);
             comb_hi = p2_horner4(comb_hi, lh[j]);
         }
 #pragma unroll
+        for (int j = 0; j < 16; j++) rev[j] = ll[15 - j];
+        p2_range_products4<16>(rev, rp);
+#pragma unroll
         for (int j = 15; j >= 0; j--) {
-            out.emit(p2_range_product(ll[j], 4));
+            out.emit(rp[15 - j]);
             comb_lo = p2_horner4(comb_lo, ll[j]);
         }
         out.emit(gl_sub(gl_canonical(comb_lo), lo));
@@ -430,9 +490,13 @@ ZKLC_D void p2_eval_u32_add_many(const V &v, u32 num_addends, u32 num_ops, p2_co
         u64 res = rc[0], carry = rc[1];
         out.emit(gl_sub(gl_add(gl_mul(carry, 1ULL << 32), res), sum));
         u64 comb_res = 0, comb_carry = 0;
+        u64 rev[18], rp[18];
+#pragma unroll
+        for (int j = 0; j < 18; j++) rev[j] = l[17 - j];
+        p2_range_products4<18>(rev, rp);
 #pragma unroll
         for (int j = 17; j >= 0; j--) {
-            out.emit(p2_range_product(l[j], 4));
+            out.emit(rp[17 - j]);
             if (j < 16)
                 comb_res = p2_horner4(comb_res, l[j]);
             else
@@ -454,9 +518,13 @@ ZKLC_D void p2_eval_u32_subtraction(const V &v, u32 num_ops, p2_consumer &out) {
         u64 initial = gl_sub(gl_sub(x, y), bin);
         out.emit(gl_sub(res, gl_add(initial, gl_mul(bout, 1ULL << 32))));
         u64 comb = 0;
+        u64 rev[16], rp[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) rev[j] = l[15 - j];
+        p2_range_products4<16>(rev, rp);
 #pragma unroll
         for (int j = 15; j >= 0; j--) {
-            out.emit(p2_range_product(l[j], 4));
+            out.emit(rp[15 - j]);
             comb = p2_horner4(comb, l[j]);
         }
         out.emit(gl_sub(gl_canonical(comb), res));
@@ -474,8 +542,10 @@ ZKLC_D void p2_eval_u32_range_check(const V &v, u32 n, p2_consumer &out) {
 #pragma unroll
         for (int j = 15; j >= 0; j--) sum = p2_horner4(sum, l[j]);
         out.emit(gl_sub(gl_canonical(sum), v.w(i)));
+        u64 rp[16];
+        p2_range_products4<16>(l, rp);
 #pragma unroll
-        for (int j = 0; j < 16; j++) out.emit(p2_range_product(l[j], 4));
+        for (int j = 0; j < 16; j++) out.emit(rp[j]);
     }
 }
 

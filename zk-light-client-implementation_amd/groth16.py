@@ -78,8 +78,18 @@ class Groth16Prover:
         B2 = pts("B2", g2_words, 16)
         al, be1, de1 = pts("alpha1", g1_words, 8), pts("beta1", g1_words, 8), pts("delta1", g1_words, 8)
         be2, de2 = pts("beta2", g2_words, 16), pts("delta2", g2_words, 16)
-        self.n_wires = A.shape[0]
-        assert B1.shape[0] == B2.shape[0] == self.n_wires and K.shape[0] == self.n_wires - 1 - self.n_public and Z.shape[0] == self.n - 1
+        # gnark's ProvingKey stores G1.A, G1.B and G2.B WITHOUT their points at infinity (wires that occur in no A / B column) and
+        # keeps the positions as InfinityA / InfinityB (NbInfinityA / NbInfinityB of them); `Prove` filters the wire values the same
+        # way before the multi-exponentiations.  pk["infinity_a"] / pk["infinity_b"]: bool [n_wires], True = removed.  Without the
+        # masks the arrays are taken as complete (a (0, 0) entry is the point at infinity for the MSM kernel as well).
+        inf_a, inf_b = pk.get("infinity_a"), pk.get("infinity_b")
+        self.n_wires = len(inf_a) if inf_a is not None else len(inf_b) if inf_b is not None else A.shape[0]
+        self.keep_a = None if inf_a is None else ~np.asarray(inf_a, dtype=bool)
+        self.keep_b = None if inf_b is None else ~np.asarray(inf_b, dtype=bool)
+        n_a = self.n_wires if self.keep_a is None else int(self.keep_a.sum())
+        n_b = self.n_wires if self.keep_b is None else int(self.keep_b.sum())
+        assert A.shape[0] == n_a and B1.shape[0] == B2.shape[0] == n_b, "key arrays do not match the infinity masks"
+        assert K.shape[0] == self.n_wires - 1 - self.n_public and Z.shape[0] == self.n - 1
         up = lambda a: torch.from_numpy(a.view(np.int64)).to(self.dev)
         # MSM operand layouts: the fixed points first, the per-proof extras (alpha / beta, delta, Ar, Bs1) in the tail
         self.d_A = up(np.concatenate([A, al, de1]))
@@ -153,8 +163,8 @@ class Groth16Prover:
                                                                       zero.data_ptr(), mont_one.ctypes.data, self.n))
         tail = lambda *xs: np.array([fr_to_regular_words(x) for x in xs], dtype=np.uint64)
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(self.dev)
-        sc_a = up(np.concatenate([w_reg, tail(1, r)]))
-        sc_b = up(np.concatenate([w_reg, tail(1, s)]))
+        sc_a = up(np.concatenate([w_reg if self.keep_a is None else w_reg[self.keep_a], tail(1, r)]))
+        sc_b = up(np.concatenate([w_reg if self.keep_b is None else w_reg[self.keep_b], tail(1, s)]))
         torch.cuda.current_stream(self.dev).synchronize()
         ar, ar_inf = self._msm1(self.d_A, sc_a, self.d_A.shape[0])
         bs1, bs1_inf = self._msm1(self.d_B1, sc_b, self.d_B1.shape[0])
