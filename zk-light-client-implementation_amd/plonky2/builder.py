@@ -738,6 +738,12 @@ class CircuitData:
         self._program = None
         self._init_arrays(b.config, uniq, row_gate, row_consts, sig_col, sig_row, len(b.public_inputs))
 
+    def __getstate__(self):
+        """what a prover needs after the build (circuit_cache.py): everything but the builder and its scratch"""
+        st = dict(self.__dict__)
+        st["builder"] = st["_plan"] = st["_trace"] = None
+        return st
+
     @classmethod
     def from_arrays(cls, config, gates, row_gate, row_consts, sig_col, sig_row, num_public_inputs):
         """gates: list sorted by (degree, id); row_gate[n]: index into gates; row_consts[k, n]: gate-local constants;

@@ -1,0 +1,72 @@
+"""Opt-in on-disk cache of built circuits (the reference rebuilds every circuit per call; here a circuit is built once
+per process -- and, with this cache, once per machine).
+
+Building the reference's circuits is host Python and takes minutes for a cold process (the per-signature Ed25519 circuit ~60 s, a
+SHA-256 circuit over a 5 KB inner_rest ~25 s, seven of them in a block window); everything a prover needs afterwards is plain data:
+the gate list, the constants and sigma matrices, the witness program (instruction words, slot tables) and the input targets.
+
+    ZKLC_CIRCUIT_CACHE=<dir>   enables it; unset = no file is read or written.
+
+A cache entry is ONE pickle (protocol 5, numpy buffers inline) of (CircuitData without its builder, aux) so that the Target objects
+shared between `aux` and the witness program's input list stay the same objects.  The file name carries the caller's key and a
+digest of this package's circuit-building sources: any change to them invalidates every entry.  The directory is a LOCAL cache and
+must be trusted like the code itself (pickle executes what it loads); nothing received from a peer or the network ever goes
+through it (the multi-GPU wire format is distributed.encode_obj).
+"""
+import hashlib
+import os
+import pickle
+import tempfile
+
+_SOURCES_DIGEST = None
+
+
+def _sources_digest():
+    global _SOURCES_DIGEST
+    if _SOURCES_DIGEST is None:
+        h = hashlib.sha256()
+        here = os.path.dirname(os.path.abspath(__file__))
+        pkg = os.path.dirname(here)
+        files = sorted(os.path.join(here, f) for f in os.listdir(here) if f.endswith(".py"))
+        files += sorted(os.path.join(pkg, f) for f in os.listdir(pkg) if f.endswith(".py"))
+        for f in files:
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+        _SOURCES_DIGEST = h.hexdigest()[:16]
+    return _SOURCES_DIGEST
+
+
+def cache_dir():
+    d = os.environ.get("ZKLC_CIRCUIT_CACHE")
+    return d if d else None
+
+
+def load_or_build(name, key, build):
+    """build() -> (CircuitData, aux) with the witness program already compiled (`data.witness_program(...)`); `key`: anything with a
+    stable repr that identifies the circuit among those called `name`.  Returns (data, aux, from_cache)."""
+    d = cache_dir()
+    if d is None:
+        data, aux = build()
+        return data, aux, False
+    tag = hashlib.sha256(repr((name, key)).encode()).hexdigest()[:16]
+    path = os.path.join(d, "%s-%s-%s.circuit" % (name, tag, _sources_digest()))
+    if os.path.exists(path):
+        try:
+            with open(path, "rb") as f:
+                data, aux = pickle.load(f)
+            return data, aux, True
+        except Exception:      # a truncated or foreign file: rebuild and replace it
+            pass
+    data, aux = build()
+    assert data._program is not None, "compile the witness program before caching a circuit"
+    os.makedirs(d, exist_ok=True)
+    fd, tmp = tempfile.mkstemp(dir=d, suffix=".tmp")
+    try:
+        with os.fdopen(fd, "wb") as f:
+            pickle.dump((data, aux), f, protocol=5)
+        os.replace(tmp, path)              # atomic: concurrent processes never see a partial entry
+    except Exception:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+        raise
+    return data, aux, False

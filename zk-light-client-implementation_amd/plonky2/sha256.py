@@ -115,8 +115,12 @@ class Sha256Prover:
         block_num = (8 * msg_len + 64 + 512) // 512
         ent = self._circuits.get(block_num)
         if ent is None:
-            data, words = sha256_circuit(msg_len)
-            data.witness_program(list(words))
+            def build():
+                data, words = sha256_circuit(msg_len)
+                data.witness_program(list(words))
+                return data, words
+            from .circuit_cache import load_or_build
+            data, words, _ = load_or_build("sha256", (block_num, sorted(standard_recursion_config().items(), key=str)), build)
             prover = data.prover(self.ctx, self.hasher)
             ent = self._circuits[block_num] = (data, words, prover, data.common_data(), prover.verifier_data())
         return ent

@@ -109,9 +109,15 @@ class ApprovalProver:
         from .plonky2 import ed25519_circuit as E
         ent = self._ed.get(msg_len_bytes)
         if ent is None:
-            b = CircuitBuilder(wide_ecc_config())
-            targets = E.ed25519_circuit(b, 8 * msg_len_bytes)
-            data = b.build()
+            def build():
+                b = CircuitBuilder(wide_ecc_config())
+                targets = E.ed25519_circuit(b, 8 * msg_len_bytes)
+                data = b.build()
+                # the inputs in the order fill_ecdsa_targets names them: the program is the one an example witness would fix
+                data.witness_program(list(targets["msg"]) + list(targets["sig"]) + list(targets["pk"]))
+                return data, targets
+            from .plonky2.circuit_cache import load_or_build
+            data, targets, _ = load_or_build("ed25519", (msg_len_bytes, sorted(wide_ecc_config().items(), key=str)), build)
             prover = data.prover(self.ctx, HASH_GL)
             ent = self._ed[msg_len_bytes] = (data, targets, prover, prover.verifier_data())
         if example is not None and ent[0]._program is None:
