@@ -290,6 +290,173 @@ __global__ void __launch_bounds__(P2_THREADS) p2_quotient_gate_kernel(p2_quotien
         }
 }
 
+// ---- all U32AddMany gates of a circuit in ONE evaluator (the Ed25519 circuit has eight variants, 3..16 addends).
+// Every variant keeps 16 + 2 two-bit limbs per operation after its routed wires, and the limb regions of the variants overlap
+// (columns 54..233 of the 234): evaluated gate by gate that is 900 range checks x (x-1)(x-2)(x-3) and 1 476 column loads per LDE
+// point -- 24.8 GB of HBM traffic for a 3.9 GB matrix (profiles/r03q_pmc_*), the kernel was bandwidth-bound.  The range check of
+// a column does not depend on the variant: here a lane walks the limb columns ONCE, from the top (the Horner sums of every variant
+// then run in step), computes the range product of a column once (four columns per asm batch) and adds it to the accumulator of
+// every variant whose limb region holds the column, at that variant's constraint index; `comb - res` is added as two terms
+// (alpha^k comb here, alpha^k (p - res) when the routed wires are read), the sums being linear.  180 range checks and 756 loads.
+// Constraint indices as in p2_eval_u32_add_many: per operation i: 21 i = the sum, 21 i + 1 + (17 - l) = limb l, 21 i + 19 / + 20 =
+// result / carry recombination.
+// MEASURED (profiles/r03v_prove_ed25519_kernel_stats.csv): 5.49 ms, the same as the eight per-gate evaluations it replaces, with 60 %
+// less traffic and 55 % fewer VALU instructions: the eight static copies of the per-variant step (the accumulators must be indexed
+// statically to stay in registers) make the kernel ~80 KB of code -- more than the 64 KB instruction cache two CUs share -- and 45 %
+// of its instructions are SALU index arithmetic (column -> operation / limb / constraint index per variant) with a scalar table load
+// per constraint.  Bit-exact (the proofs of the real circuit verify, bytes equal the C prover's); kept as an opt-in experiment
+// (ZKLC_P2_ADDMANY=multi), the per-gate launches stay the default.
+#define P2_AM_MAX 8
+// one variant's share of a four-column step of p2_quotient_addmany_multi_kernel (a template so that V is static: the eight copies
+// are too large for `#pragma unroll`, and a rolled loop would index the accumulators dynamically = scratch)
+template <int V>
+__device__ __forceinline__ void p2_am_variant_step(gl_acc3 (&acc)[P2_AM_MAX][P2_MAX_CH], u64 (&comb)[P2_AM_MAX], u32 ops, u32 l0, u32 c0,
+                                                   u32 lo, const u64 *w, const u64 *rp, const p2_quotient_args &a, u32 k0) {
+    auto emit = [&](u32 krel, u64 val) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < P2_MAX_CH; c++)
+            if (c < (int)a.nch) gl_acc3_mul(acc[V][c], val, (gl_ktab *)a.apow[c] + 6 * (size_t)(k0 + krel));
+    };
+    const u32 rel0 = c0 - l0;                         // wraps below the region; ops = 0 for the unused slots
+    const u32 i0 = rel0 / 18, l_top = rel0 - 18 * i0;
+    if (rel0 < 18 * ops && l_top >= 3) {
+        // the usual case: the four columns are limbs l_top .. l_top - 3 of ONE operation, i.e. four consecutive constraints:
+        // the alpha powers of the four are adjacent in the table (one batch of scalar loads instead of four dependent ones)
+        const u32 kb = 21 * i0 + 18 - l_top;
+#pragma unroll
+        for (int c = 0; c < P2_MAX_CH; c++)
+            if (c < (int)a.nch) {
+                gl_ktab *t = (gl_ktab *)a.apow[c] + 6 * (size_t)(k0 + kb);
+#pragma unroll
+                for (int q = 0; q < 4; q++) gl_acc3_mul(acc[V][c], rp[q], t + 6 * q);
+            }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            comb[V] = p2_horner4(comb[V], w[q]);
+            if (l_top - q == 16) {
+                emit(21 * i0 + 20, gl_canonical(comb[V]));
+                comb[V] = 0;
+            } else if (l_top - q == 0) {
+                emit(21 * i0 + 19, gl_canonical(comb[V]));
+                comb[V] = 0;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {                     // region edges and steps that straddle two operations
+        if (c0 < lo + q) continue;
+        const u32 rel = c0 - q - l0;
+        if (rel >= 18 * ops) continue;
+        const u32 i = rel / 18, l = rel - 18 * i;
+        emit(21 * i + 1 + (17 - l), rp[q]);
+        comb[V] = p2_horner4(comb[V], w[q]);
+        if (l == 16) {
+            emit(21 * i + 20, gl_canonical(comb[V]));
+            comb[V] = 0;
+        } else if (l == 0) {
+            emit(21 * i + 19, gl_canonical(comb[V]));
+            comb[V] = 0;
+        }
+    }
+}
+// (eight accumulator sets = 96 VGPRs: two waves per SIMD; left to its occupancy heuristic the compiler spills them to scratch)
+__global__ void __launch_bounds__(P2_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2)))
+p2_quotient_addmany_multi_kernel(p2_quotient_args a, p2_gate_list list) {
+    const size_t N = (size_t)1 << a.lde_bits;
+    size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    u64 pi = __brevll((u64)p) >> (64 - a.lde_bits);
+    const u32 coset = (u32)pi & ((1u << a.rate_bits) - 1);
+    const u64 *W = a.wires + p;
+    const u32 k0 = a.nch + a.nch * (a.npp + 1);      // the gate constraints follow the Z1 and partial-product terms
+    gl_acc3 acc[P2_AM_MAX][P2_MAX_CH];
+#pragma unroll
+    for (int v = 0; v < P2_AM_MAX; v++)
+#pragma unroll
+        for (int c = 0; c < P2_MAX_CH; c++) acc[v][c].c0 = acc[v][c].c1 = acc[v][c].c2 = 0;
+    auto emit = [&](int v, u32 krel, u64 val) __attribute__((always_inline)) {      // not inlined at every site = `acc` in scratch
+#pragma unroll
+        for (int c = 0; c < P2_MAX_CH; c++)
+            if (c < (int)a.nch) gl_acc3_mul(acc[v][c], val, (gl_ktab *)a.apow[c] + 6 * (size_t)(k0 + krel));
+    };
+    // ---- routed wires, variant by variant: sum constraint, and the -res / -carry halves of the recombination constraints
+    u32 lo = 0xFFFFFFFFu, hi = 0;                     // the union of the limb regions
+    u32 OPS[P2_AM_MAX], L0[P2_AM_MAX];                // wave-uniform: operations and first limb column of every variant
+#pragma unroll
+    for (int v = 0; v < P2_AM_MAX; v++) {
+        OPS[v] = L0[v] = 0;
+        if (v >= (int)list.n) continue;
+        const p2_gate g = a.gates[list.idx[v]];
+        const u32 na = g.p[0], ops = g.p[1], per = na + 3;
+        const u32 l0 = per * ops;
+        OPS[v] = ops;
+        L0[v] = l0;
+        lo = l0 < lo ? l0 : lo;
+        hi = l0 + 18 * ops > hi ? l0 + 18 * ops : hi;
+#pragma unroll 1
+        for (u32 i = 0; i < ops; i++) {
+            p2_vars pv;
+            pv.wires = a.wires;
+            pv.stride = N;
+            pv.p = p;
+            u64 rc[2];
+            p2_load<2>(pv, per * i + na + 1, rc);
+            u64 sum = p2_sum_wires(pv, per * i, na + 1);          // the addends and the carry in
+            emit(v, 21 * i, gl_sub(gl_add(gl_mul(rc[1], 1ULL << 32), rc[0]), sum));
+            emit(v, 21 * i + 19, gl_neg(rc[0]));
+            emit(v, 21 * i + 20, gl_neg(rc[1]));
+        }
+    }
+    // ---- limb columns hi-1 .. lo, four per step (the next four are in flight while these are evaluated)
+    u64 comb[P2_AM_MAX];
+#pragma unroll
+    for (int v = 0; v < P2_AM_MAX; v++) comb[v] = 0;
+    auto load4 = [&](u32 top, u64 *w) __attribute__((always_inline)) {               // w[q] = column top - q (0 below `lo`: no variant uses it)
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = top >= lo + q ? W[(size_t)(top - q) * N] : 0;
+    };
+    u64 w[4], nxt[4];
+    if (hi > lo) load4(hi - 1, w);
+#pragma unroll 1
+    for (u32 top = hi; top > lo; top = top >= 4 ? top - 4 : 0) {
+        const u32 c0 = top - 1;                       // the columns of this step: c0, c0 - 1, c0 - 2, c0 - 3
+        if (c0 >= lo + 4) load4(c0 - 4, nxt);
+        u64 rp[4];
+        p2_range_products4<4>(w, rp);
+#define P2_AM_STEP(V) p2_am_variant_step<V>(acc, comb, OPS[V], L0[V], c0, lo, w, rp, a, k0);
+        P2_AM_STEP(0) P2_AM_STEP(1) P2_AM_STEP(2) P2_AM_STEP(3) P2_AM_STEP(4) P2_AM_STEP(5) P2_AM_STEP(6) P2_AM_STEP(7)
+#undef P2_AM_STEP
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] = nxt[q];
+        if (top < 4) break;
+    }
+    u64 sum[P2_MAX_CH];
+    for (int c = 0; c < P2_MAX_CH; c++) sum[c] = 0;
+    p2_vars sv;
+    sv.consts = a.cs;
+    sv.stride = N;
+    sv.p = p;
+    sv.nsel = a.nsel;
+#pragma unroll
+    for (int v = 0; v < P2_AM_MAX; v++) {
+        if (v >= (int)list.n) continue;
+        const u32 gi = list.idx[v];
+        const p2_gate g = a.gates[gi];
+        u64 f = p2_filter(gi, g.group_start, g.group_end, sv.sel(g.selector_index), a.nsel > 1);
+#pragma unroll
+        for (int c = 0; c < P2_MAX_CH; c++)
+            if (c < (int)a.nch) sum[c] = gl_add(sum[c], gl_mul(f, gl_acc3_reduce(acc[v][c])));
+    }
+    const u64 zi = a.zh_inv[coset];
+#pragma unroll
+    for (int c = 0; c < P2_MAX_CH; c++)
+        if (c < (int)a.nch) {
+            u64 *o = a.out + (size_t)c * N + p;
+            *o = gl_add(*o, gl_mul(sum[c], zi));
+        }
+}
+
 typedef void (*p2_gate_kernel_fn)(p2_quotient_args, p2_gate_list);
 static p2_gate_kernel_fn p2_gate_kernel_of(u32 type) {
     switch (type) {
@@ -1203,6 +1370,11 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
                         list.idx[list.n++] = h;
                         done[h] = true;
                     }
+                // A/B, opt-in: the one-pass evaluator of all U32AddMany variants measured the SAME 5.49 ms as the per-gate
+                // launches on the Ed25519 circuit (profiles/r03v_*): see the comment at the kernel
+                static const bool am_multi = getenv("ZKLC_P2_ADDMANY") && !strcmp(getenv("ZKLC_P2_ADDMANY"), "multi");
+                if (am_multi && c->gates[g].type == P2_U32_ADD_MANY && list.n >= 2 && list.n <= P2_AM_MAX)
+                    fn = p2_quotient_addmany_multi_kernel;
                 hipLaunchKernelGGL(fn, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a, list);
             }
         }
