@@ -281,14 +281,38 @@ gl_ntt_pass_g4_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t 
         return (H << (lowbits + p.k)) | (mid << lowbits) | L;
     };
 
-    for (u32 e = tid; e < (u32)tile_n; e += n_threads) {
-        u64 g = global_index(e);
-        u64 v = 0;
-        if (g < (1ULL << p.log_in)) {
-            v = src[g];
-            if (p.scale_shift) v = gl_mul(v, gl_mul(scale_hi[g >> p.scale_shift], scale_lo[g & ((1u << p.scale_shift) - 1)]));
+    // tile load, eight elements of a lane at a time with all eight global loads in flight (one load -> wait -> LDS write per
+    // iteration exposed the HBM latency sixteen times per tile: 39 % of the wave cycles were SQ_WAIT_ANY).  The zero padding of an
+    // LDE (7 of 8 elements of its first pass) issues no load.
+    {
+        constexpr int LD = 8;
+        const u64 lim = 1ULL << p.log_in;
+        for (u32 e0 = tid; e0 < (u32)tile_n; e0 += LD * n_threads) {
+            u64 g[LD], v[LD], sh[LD], sl[LD];
+#pragma unroll
+            for (int q = 0; q < LD; q++) {
+                const u32 e = e0 + q * n_threads;
+                g[q] = global_index(e < (u32)tile_n ? e : tid);
+                v[q] = 0;
+                if (g[q] < lim) v[q] = src[g[q]];          // predicated, still all in flight: nothing below waits before the batch is issued
+            }
+            if (p.scale_shift) {
+#pragma unroll
+                for (int q = 0; q < LD; q++) {
+                    const u64 gc = g[q] < lim ? g[q] : lim - 1;
+                    sh[q] = scale_hi[gc >> p.scale_shift];
+                    sl[q] = scale_lo[gc & ((1u << p.scale_shift) - 1)];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < LD; q++) {
+                const u32 e = e0 + q * n_threads;
+                if (e >= (u32)tile_n) continue;
+                u64 x = g[q] < lim ? v[q] : 0;
+                if (p.scale_shift) x = gl_mul(x, gl_mul(sh[q], sl[q]));
+                tile[NTT_TJ(e)] = x;
+            }
         }
-        tile[NTT_TJ(e)] = v;
     }
     __syncthreads();
 
@@ -319,10 +343,22 @@ gl_ntt_pass_g4_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t 
         __syncthreads();
     }
 
-    for (u32 e = tid; e < (u32)tile_n; e += n_threads) {
-        u64 v = tile[NTT_TJ(e)];
-        if (p.out_scale != 1) v = gl_mul(v, p.out_scale);
-        dst[global_index(e)] = v;
+    {
+        constexpr int LD = 8;
+        for (u32 e0 = tid; e0 < (u32)tile_n; e0 += LD * n_threads) {
+            u64 v[LD];
+#pragma unroll
+            for (int q = 0; q < LD; q++) {
+                const u32 e = e0 + q * n_threads;
+                v[q] = tile[NTT_TJ(e < (u32)tile_n ? e : tid)];
+            }
+#pragma unroll
+            for (int q = 0; q < LD; q++) {
+                const u32 e = e0 + q * n_threads;
+                if (e >= (u32)tile_n) continue;
+                dst[global_index(e)] = p.out_scale != 1 ? gl_mul(v[q], p.out_scale) : v[q];
+            }
+        }
     }
 }
 
