@@ -165,7 +165,10 @@ def pmc_traffic(n):
         return None
 
 
-VALU_INT_PEAK_TLOPS = 37.7    # measured issue ceiling of the quarter-rate integer class (v_mad_u64_u32, carry adds): profiles/r02_valu_ubench.txt
+VALU_INT_PEAK_TLOPS = 37.7    # measured issue ceiling of the multi-pass integer class (v_mad_u64_u32, carry adds): profiles/r02_valu_ubench.txt
+VALU_FAST_PEAK_TLOPS = 62.0   # measured issue rate of the single-pass class (v_mov / v_add_u32 / v_xor / 32-bit shifts), same file
+# static share of single-pass instructions in each priced kernel (tools/valu_mix.py over the shipped code objects, profiles/r04_valu_mix.txt)
+VALU_FAST_SHARE = {"poseidon": 0.001, "lde": 0.192, "msm": 0.202}
 
 
 def poseidon_pmc():
@@ -186,12 +189,15 @@ def pmc_json(name):
         return None
 
 
-def valu_block(wave_instructions, ms, what):
-    """the binding resource of the integer kernels: SQ_INSTS_VALU x 64 lanes / time against the measured issue ceiling"""
+def valu_block(wave_instructions, ms, what, kernel="poseidon"):
+    """the binding resource of the integer kernels: SQ_INSTS_VALU x 64 lanes / time against the issue ceiling of the kernel's
+    instruction mix, 1 / ((1 - f) / int-class rate + f / single-pass rate) with f the static single-pass share"""
     ach = wave_instructions * 64 / (ms * 1e-3) / 1e12
-    return {"bound": "valu-int", "achieved": ach, "peak": VALU_INT_PEAK_TLOPS, "unit": "T lane-instr/s", "frac": ach / VALU_INT_PEAK_TLOPS,
-            "note": "SQ_INSTS_VALU (%s) x 64 lanes / the live time; peak = the measured issue rate of v_mad_u64_u32 / v_mad_i64_i32 / carry "
-                    "adds (profiles/r02_valu_ubench.txt, profiles/r03d_fp_ubench.txt)" % what}
+    f = VALU_FAST_SHARE[kernel]
+    peak = 1.0 / ((1.0 - f) / VALU_INT_PEAK_TLOPS + f / VALU_FAST_PEAK_TLOPS)
+    return {"bound": "valu-int", "achieved": ach, "peak": peak, "unit": "T lane-instr/s", "frac": ach / peak,
+            "note": "SQ_INSTS_VALU (%s) x 64 lanes / the live time; peak = measured issue rates (profiles/r02_valu_ubench.txt) weighted by "
+                    "the kernel's static instruction mix (single-pass share %.3f, tools/valu_mix.py)" % (what, f)}
 
 
 def cpu_baseline(pk, sg, ms, budget_s=12.0):
@@ -299,7 +305,7 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
     if pm is not None and pm.get("log_n") == args.msm_log:
         msm["roofline"]["traffic"] = pm.get("hbm_bytes_per_msm")
         msm["roofline"]["valu"] = valu_block(pm["valu_wave_instructions_per_msm"], ms, "all kernels of one multi-exponentiation, "
-                                                                                       "profiles/msm_pmc_latest.json")
+                                                                                       "profiles/msm_pmc_latest.json", "msm")
     if with_cpu:
         t0 = time.perf_counter()
         want, winf, used = cport.bn254_msm(pts_h, sc_h, nthreads=threads)
@@ -359,7 +365,7 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
     if pl_ is not None:
         res["lde"]["roofline"]["traffic"] = pl_.get("hbm_bytes_per_lde")
         res["lde"]["roofline"]["valu"] = valu_block(pl_["valu_wave_instructions_per_lde"], ms, "all passes of one extension, "
-                                                                                                "profiles/lde_pmc_latest.json")
+                                                                                                "profiles/lde_pmc_latest.json", "lde")
     words = ctx.gl_merkle_tree_words(log_n + rate, cap)
     tree = torch.empty(words, dtype=torch.int64, device=dev)
     ms, wall = _time_stream(lambda: ctx.gl_merkle_commit_dev(lde, N, log_n + rate, batch, cap, tree, stream=stream), stream, 3, barrier)
@@ -412,8 +418,7 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
                     ratio = st["proof"] / st["wires_commit"]
                     ed_cb.update({"value": 1.0 / ((lde_s + mk_s) * ratio), "unit": "proofs/s (wires commitment measured, rest scaled)",
                                   "scaled": "the other stages (Z / partial products, quotient, openings, FRI) by the ratio whole proof / wires "
-                                            "commitment = %.2f of the COMPLETE C proof measured at the fold shape; the u32 gates of this circuit "
-                                            "are not in the C prover" % ratio,
+                                            "commitment = %.2f of the COMPLETE C proof measured at the fold shape" % ratio,
                                   "sample": "wires commitment measured on bounded samples, other stages scaled from the complete CPU proof of the "
                                             "fold shape", "seconds_per_proof": (lde_s + mk_s) * ratio})
                 else:
@@ -528,18 +533,20 @@ def run_bn254_extras(ctx, dev, reduce_max, barrier, world):
 
 
 def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
-    """plonky2 proofs of the reference's circuits: the per-signature Ed25519 circuit (zklc_amd/plonky2/ed25519_circuit.py), the
-    recursion circuits of the fold and the BN128 wrap (zklc_amd/plonky2/recursion.py), then one Block_i signature sub-DAG."""
+    """plonky2 proofs of the reference's circuits through the package's pipeline (zklc_amd.pipeline.BlockPipeline): per-circuit proof
+    times (the per-signature Ed25519 circuit, the recursion shapes of the fold, the closing proof and the BN128 wrap, SHA-256, keys /
+    stakes), then the timed Block_i proofs."""
     import hashlib
-    import queue
-    import threading
     import torch
     import zklc_amd
-    from zklc_amd import signatures as SG
-    from zklc_amd.plonky2 import CircuitBuilder, HASH_GL, HASH_BN128, wide_ecc_config, ed25519_circuit as E
-    from zklc_amd.plonky2.recursion import RecursionProver
+    from zklc_amd.pipeline import BlockPipeline, BlockWindow
+    from zklc_amd.plonky2 import HASH_GL, HASH_BN128, ed25519_circuit as E
+    from zklc_amd.plonky2 import serialization as S
     out = {}
     ed_name = "ed25519_circuit_2p18x234"
+    t_setup = time.perf_counter()
+    pipe = BlockPipeline(torch.cuda.current_device(), prove_streams=args.prove_streams, witness_batch=args.witness_batch,
+                         host_witness=args.host_witness, rank=rank, world=world, comm_device=dev, host_threads=host_cores())
 
     def time_proof(prover, wires, pis, sp, bits):
         d_w = torch.from_numpy(np.ascontiguousarray(wires).view(np.int64)).to(dev)
@@ -555,11 +562,9 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
 
     def describe(data, prover, ms, what):
         cfg = data.config
-        # algorithmic bytes of one proof = the four committed LDE matrices written once + read once by the Merkle hashing
         widths = data.num_constants + cfg["num_routed_wires"] + cfg["num_wires"] + 2 * (1 + data.num_partial_products) + 2 * 8
         return {"ms_per_proof": ms, "proofs_per_s": world * 1e3 / ms, "proof_bytes": prover.proof_bytes, "rows": data.n,
-                "rows_used": sum(1 for g, _ in data.builder.rows if g.id() != "NoopGate"), "wires": cfg["num_wires"],
-                "committed_polys": widths, "gate_types": len(data.gates), "circuit": what,
+                "wires": cfg["num_wires"], "committed_polys": widths, "gate_types": len(data.gates), "circuit": what,
                 "stages_ms": {k: round(v, 3) for k, v in prover.last_timings().items()}}
 
     # ---- a4-a6: the reference's per-signature circuit (crypto/plonky2_ed25519/src/gadgets/eddsa.rs:34-85) with the witnesses of
@@ -567,22 +572,16 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     t0 = time.perf_counter()
     j = json.load(open(os.path.join(ROOT, "tests", "golden", "ed25519_near_c1_small.json")))
     msg = bytes.fromhex(j["msg"])
-    bld = CircuitBuilder(wide_ecc_config())
-    ed_targets = E.ed25519_circuit(bld, 8 * len(msg))
-    ed_data = bld.build()
+    ent = pipe.ed_circuit(len(msg))
+    ed_data, ed_prover = ent.data, ent.provers[0]
     t1 = time.perf_counter()
-    fills = [E.fill_ecdsa_targets(ed_targets, msg, bytes.fromhex(x["approval"])[2:], bytes.fromhex(x["validator_tail"])[1:33])
+    fills = [E.fill_ecdsa_targets(ent.targets, msg, bytes.fromhex(x["approval"])[2:], bytes.fromhex(x["validator_tail"])[1:33])
              for x in j["entries"]]
-    ed_data.witness_program(fills[0])          # compile the generators into the interpreter program (scheduling only)
-    t2 = time.perf_counter()
     wn, pn = ed_data.generate_witness_native(fills)       # csrc/plonky2_witness.cpp, one host thread per signature
-    t3 = time.perf_counter()
-    ed_prover = ed_data.prover(ctx, HASH_GL)
-    ed_common, ed_vd = ed_data.common_data(), ed_prover.verifier_data()
-    ms = time_proof(ed_prover, wn[0], [int(x) for x in pn[0]], stream.cuda_stream, 18)
+    t2 = time.perf_counter()
+    ms = time_proof(ed_prover, wn[0], [int(x) for x in pn[0]], pipe.ctx.stream_ptr(), 18)
     out[ed_name] = describe(ed_data, ed_prover, ms, "reference Ed25519 circuit, real NEAR signature witness")
-    out[ed_name]["host_python_untimed"] = {"circuit_build_s": t1 - t0, "witness_program_compile_s": t2 - t1,
-                                           "native_witness_s_per_signature": (t3 - t2) / len(fills), "native_witness_threads": len(fills)}
+    out[ed_name]["host_python_untimed"] = {"circuit_build_or_cache_load_s": t1 - t0, "native_witness_s_per_signature": (t2 - t1) / len(fills)}
     c1_proofs = [ed_prover.prove_bytes(wn[k], [int(x) for x in pn[k]]) for k in range(len(fills))]
     if args.cpu_baseline_ed25519 and rank == 0 and world == 1 and not args.no_cpu_baseline:
         # opt-in (1-3 minutes of host time, ~12 GB of host memory): ONE complete proof of the Ed25519 circuit on the host cores
@@ -604,11 +603,9 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     # ---- a7: `recursive_proof` (prove_crypto/recursion.rs:16-97).  The fold of signatures.rs:97-105 uses two circuit shapes --
     # R(ed, ed) for the first step, R(R, ed) for every later one (its common data is a fixed point) -- the closing proof carries
     # sha256(valid_keys) as 32 public inputs (:125-139) and the last recursion runs with Poseidon-BN128 Merkle caps
-    # (bin/prove_block.rs:279-287).  All of them live on the fold thread's own context (= HIP stream).
-    nthreads = max(2, args.prove_streams)
-    fold_ctx = zklc_amd.Context(torch.cuda.current_device(), high_priority=True)
-    rp, rpw = RecursionProver(fold_ctx, HASH_GL), RecursionProver(fold_ctx, HASH_BN128)
-    ed3 = [(ed_common, ed_vd, p_) for p_ in c1_proofs]
+    # (bin/prove_block.rs:279-287).  The pipeline's own fold / wrap provers are timed (their circuits stay resident for the blocks).
+    rp, rpw = pipe.rp, pipe.rpw
+    ed3 = [(ent.common, ent.vd, p_) for p_ in c1_proofs]
     shapes_t = {}
 
     def build_step(name, prover_, *a, **kw):
@@ -621,7 +618,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     assert r2[0] == r1[0], "the fold's common data must be a fixed point"
     pis32 = list(hashlib.sha256(b"bench").digest())
     rf = build_step("closing_R(R)+32PI", rp, r2, None, pis32)
-    rw = build_step("wrap_bn128_R(closing)", rpw, rf)
+    build_step("wrap_bn128_R(closing)", rpw, rf)
     fold_steps = {"fold_first_R(ed,ed)": (rp, (ed3[0], ed3[1]), {}), "fold_R(R,ed)": (rp, (r1, ed3[2]), {}),
                   "closing_R(R)+32PI": (rp, (r2, None, pis32), {}), "wrap_bn128_R(closing)": (rpw, (rf,), {})}
     for name, (prover_, a, kw) in fold_steps.items():
@@ -630,7 +627,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         host = dict(prover_.last_host_ms)
         wires = rc.wire_buffer()[0].copy()
         pis_ = pis32 if "32PI" in name else []
-        ms = time_proof(rc.prover, wires, pis_, fold_ctx.stream_ptr(), rc.data.degree_bits)
+        ms = time_proof(rc.prover, wires, pis_, prover_.ctx.stream_ptr(), rc.data.degree_bits)
         key = "recursion_%s_2p%dx135" % (name, rc.data.degree_bits)
         out[key] = describe(rc.data, rc.prover, ms, "in-circuit verifier (recursive_proof) over real inner proofs")
         out[key]["host_ms_per_call"] = {k: round(v, 3) for k, v in host.items()}
@@ -669,510 +666,225 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         data_.witness_program(list(pw_))
         wn_, pn_ = data_.generate_witness_native([pw_])
         t_w = time.perf_counter() - t_
-        pr_ = data_.prover(fold_ctx, HASH_GL)
-        ms = time_proof(pr_, wn_[0], [int(x) for x in pn_[0]], fold_ctx.stream_ptr(), data_.degree_bits)
+        pr_ = data_.prover(pipe.fold_ctx, HASH_GL)
+        ms = time_proof(pr_, wn_[0], [int(x) for x in pn_[0]], pipe.fold_ctx.stream_ptr(), data_.degree_bits)
         key = "%s_2p%dx135" % (name, data_.degree_bits)
         out[key] = describe(data_, pr_, ms, "the reference's circuit (restated), real witness")
         out[key]["host_python_untimed"] = {"program_compile_and_native_witness_s": t_w}
         pr_.close()
 
-    # ---- one FULL Block_i proof (BASELINE configs[2]: `prove_block_bft`, bft.rs:38-500, the path of bin/prove_random.rs) on the
+    # ---- FULL Block_i proofs (BASELINE configs[2]: `prove_block_bft`, bft.rs:38-500, the path of bin/prove_random.rs) on the
     # reference's own data: NEAR mainnet blocks 121798939..43 with the 100 block producers of their epoch, Block_0 of the previous
-    # epoch and the last block of the one before (tests/golden/block_window_HPi5.json: borsh headers pinned by the block hashes).
-    #   a3  batched Ed25519 pre-verification of the 73 present approvals on the GPU (signatures.rs:79)
-    #   a5  native witness generation on the host cores (csrc/plonky2_witness.cpp), chunks of `wchunk` signatures, double-buffered
-    #       in pinned memory, overlapped with proving
-    #   a6  one proof of the reference Ed25519 circuit per approval; `--prove-streams` - 1 host threads, each with its own zklc
-    #       context (= HIP stream) and resident circuit, keep that many proofs in flight
-    #   a7  the left fold agg = recursive_proof(agg, sig_i) as soon as signature proof i exists and the closing proof with
-    #       sha256(valid_keys) -- one host thread + high-priority stream
-    #   8f  everything else of the DAG on two more threads + streams: keys / stakes (needs only valid_keys from the pre-check) on
-    #       one; on the other (zklc_amd.prove_bft.BlockProver) seven header-hash chains (three SHA-256 proofs and four recursions
-    #       each), consecutive heights, equalities, bp_hash, then -- once the signature aggregate exists -- the joining recursions
-    #       and the Poseidon-BN128 wrap of the block proof (bin/prove_block.rs:279-287)
-    from concurrent.futures import Future
-    from zklc_amd.plonky2 import serialization as S
-    from zklc_amd.prove_bft import BlockProver
+    # epoch and the last block of the one before (tests/golden/block_window_HPi5.json: borsh headers pinned by the block hashes),
+    # through zklc_amd.pipeline.BlockPipeline (its docstring lists the threads and streams)
     win = json.load(open(os.path.join(ROOT, "tests", "golden", "block_window_HPi5.json")))
-    hx = bytes.fromhex
-    win_blocks = []
-    for blk in win["blocks"]:
-        f = {k: hx(blk[k]) for k in ("hash", "prev_hash", "epoch_id", "last_ds_final_hash", "last_final_hash")}
-        f["height"] = blk["height"]
-        f["approvals"] = [hx(a) for a in blk["approvals"]]
-        win_blocks.append((f, hx(blk["bytes"])))
-    validators = [hx(v) for v in win["validators"]]
-    approvals = win_blocks[3][0]["approvals"]
-    c2_msg = SG.generate_signed_message(win_blocks[4][0]["height"], win_blocks[3][0]["height"], win_blocks[3][0]["prev_hash"])
-    _, pks_, sigs_ = SG.slice_approvals(approvals, validators)
-    present = [(s_.tobytes(), p_.tobytes()) for s_, p_ in zip(sigs_, pks_)]
-    n_sig = len(present)
-    fills = [E.fill_ecdsa_targets(ed_targets, c2_msg, sg, pk_) for sg, pk_ in present]
-    # --scaling strong: ONE block per step over all ranks: contiguous shards of the signature proofs, local left folds,
-    # a binary-tree fold of the partial aggregates over the ranks (zklc_amd.distributed.tree_fold, 8f.4), the block-header proofs
-    # and the keys / stakes proof on the other ranks, the joins and the wrap on rank 0
-    import importlib
-    DIST = importlib.import_module("zk-light-client-implementation_amd.distributed")
-    # M = the mode of the block pipeline below (switched by set_mode between the weak and the strong section of a multi-GPU run)
-    M = {}
-
-    def set_mode(strong_):
-        M["strong"] = bool(strong_) and world > 1
-        lo_, hi_ = DIST.shard_range(n_sig, rank, world) if M["strong"] else (0, n_sig)
-        M["my_sigs"] = list(range(lo_, hi_))
-        M["hdr_owner"] = DIST.assign_jobs(list(hdr_jobs), world) if M["strong"] else {}
-        M["ks_rank"] = world - 1 if M["strong"] else rank
-    workers = [(ctx, ed_prover)] + [(c_, ed_data.prover(c_, HASH_GL)) for c_ in
-                                    (zklc_amd.Context(torch.cuda.current_device()) for _ in range(nthreads - 2))]
-    nbuf = 2
-    nw_, n_rows = ed_data.config["num_wires"], ed_data.n
-    dev_wit = not args.host_witness
-    if dev_wit:
-        # a5 on the GPU (csrc/plonky2_witness_dev.hip): the generator program runs on the device for a batch of signatures, the
-        # wire matrices (490 MB each) are written in HBM where zklc_plonky2_prove_dev reads them -- no host threads, no PCIe
-        wchunk = max(1, min(64, args.witness_batch))
-        wit_ctx = zklc_amd.Context(torch.cuda.current_device())
-        dwit = ed_data.device_witness(wit_ctx)
-        d_bufs = [torch.zeros((wchunk, nw_, n_rows), dtype=torch.int64, device=dev) for _ in range(nbuf)]
-        pis_w = dwit.run(d_bufs[0].data_ptr(), fills[:1], stream=wit_ctx.stream_ptr())
-        for c_, pr in workers:
-            pr.prove_dev(d_bufs[0][0].data_ptr(), [int(x) for x in pis_w[0]], stream=c_.stream_ptr())
-    else:
-        # host threads of this rank's witness producer; two pinned buffers of wchunk x 490 MB each: smaller chunks when several
-        # ranks share the host
-        wchunk = max(1, min(12 if world == 1 else 6, host_cores() // max(1, world) - nthreads))
-        pinned = [torch.zeros((wchunk, nw_, n_rows), dtype=torch.int64).pin_memory() for _ in range(nbuf)]
-        views = [p_.numpy().view(np.uint64) for p_ in pinned]
-        for _, pr in workers:       # warm every Ed25519 prover once (also pages the pinned buffers in)
-            data_w, pis_w = ed_data.generate_witness_native(fills[:1], out=views[0][:1])
-            pr.prove_host_ptr(views[0][0].ctypes.data, [int(x) for x in pis_w[0]])
+    window = BlockWindow.from_fixture(win)
+    want = window.expected_public_inputs()[0]
+    n_sig = sum(1 for a in window.blocks[3][0]["approvals"] if len(a) == 66)
     barrier()
-    class PipelinedApprovals:
-        """what BlockProver calls for `prove_approvals`: the result of the pipeline below instead of a sequential loop"""
-
-        def __init__(self, recursion):
-            self.recursion, self.future = recursion, None
-
-        def keys_stakes_early(self, msg_, approvals_, validators_):
-            return self.ks_future.result()
-
-        def prove_approvals(self, msg_, approvals_, validators_):
-            assert msg_ == c2_msg
-            rc_, raw_, vk_ = self.future.result()
-            return (rc_, S.proof_from_bytes(raw_, rc_.common, HASH_GL)), vk_
-
-        def close(self):
-            self.recursion.close()
-    from zklc_amd.keys_stakes import KeysStakesProver
-    ks_ctx = zklc_amd.Context(torch.cuda.current_device())
-    ks_prover = KeysStakesProver(ks_ctx)          # keys / stakes needs only valid_keys: its own thread + stream from the start
-    dag_ctx = zklc_amd.Context(torch.cuda.current_device(), high_priority=True)
-    stub = PipelinedApprovals(RecursionProver(dag_ctx, HASH_GL))
-    bprover = BlockProver(dag_ctx, stub)
-    rpw_block = RecursionProver(dag_ctx, HASH_BN128)
-    lock = threading.Lock()
-    cur = {"st": None}       # the state of the block whose fold / DAG stage ran last (results are read from it after the timed region)
-
-    def new_state():
-        """per-block state of the pipeline: the signature stage (witness producer + Ed25519 provers) fills ed_proofs / ed_done, the
-        fold + DAG stage consumes them"""
-        st = {}
-        st["ed_done"] = [threading.Event() for _ in range(n_sig)]
-        st["ed_proofs"] = [None] * n_sig
-        st["free_slots"], st["ready"] = queue.Queue(), queue.Queue()
-        for sl in range(nbuf):
-            st["free_slots"].put(sl)
-        st["slot_left"] = [0] * nbuf
-        st["errors"], st["tw"] = [], [0.0]
-        st["fold_host"] = {"inputs": 0.0, "witness": 0.0, "prove": 0.0}
-        st["result"] = {}
-        return st
-
-    def begin_dag_stage(st):
-        """the fold / DAG / keys-stakes stage of a block owns the stub's futures and the block prover's counters"""
-        stub.future, stub.ks_future, stub.hdr_future = Future(), Future(), Future()
-        bprover.counts, bprover.seconds = {}, {}
-        cur["st"] = st
-
-    def fail(st, e):
-        st["errors"].append(e)
-        for fut in (stub.future, stub.ks_future, stub.hdr_future):
-            if not fut.done():
-                fut.set_exception(e)
-        for ev in st["ed_done"]:
-            ev.set()
-        for _ in range(nthreads):
-            st["ready"].put(None)
-
-    def witness_producer(st):
-        try:
-            # a small first chunk (one signature per proving stream) so that proving starts after one witness time, not after a
-            # full chunk's
-            my_sigs = M["my_sigs"]
-            n_mine = len(my_sigs)
-            bounds = [0, min(n_mine, max(1, nthreads - 1))]
-            while bounds[-1] < n_mine:
-                bounds.append(min(n_mine, bounds[-1] + wchunk))
-            for c0, c1 in zip(bounds, bounds[1:]):
-                idx = my_sigs[c0:c1]
-                sl = st["free_slots"].get()
-                t_ = time.perf_counter()
-                if dev_wit:
-                    pis_ = dwit.run(d_bufs[sl].data_ptr(), [fills[i] for i in idx], stream=wit_ctx.stream_ptr())
-                else:
-                    _, pis_ = ed_data.generate_witness_native([fills[i] for i in idx], out=views[sl][:len(idx)], threads=len(idx))
-                st["tw"][0] += time.perf_counter() - t_
-                with lock:
-                    st["slot_left"][sl] = len(idx)
-                for k, i in enumerate(idx):
-                    st["ready"].put((i, sl, k, [int(x) for x in pis_[k]]))
-            for _ in range(nthreads):
-                st["ready"].put(None)
-        except Exception as e:  # pragma: no cover
-            fail(st, e)
-
-    def ed_worker(st, c_, pr):
-        try:
-            while True:
-                item = st["ready"].get()
-                if item is None:
-                    return
-                i, sl, k, pis_ = item
-                if dev_wit:
-                    st["ed_proofs"][i] = pr.prove_dev(d_bufs[sl][k].data_ptr(), pis_, stream=c_.stream_ptr())
-                else:
-                    st["ed_proofs"][i] = pr.prove_host_ptr(views[sl][k].ctypes.data, pis_)
-                st["ed_done"][i].set()
-                with lock:
-                    st["slot_left"][sl] -= 1
-                    if st["slot_left"][sl] == 0:
-                        st["free_slots"].put(sl)
-        except Exception as e:  # pragma: no cover
-            fail(st, e)
-
-    def fold_worker(st, valid_keys):
-        try:
-            agg = None
-            for i in M["my_sigs"]:
-                st["ed_done"][i].wait()
-                if st["errors"]:
-                    return
-                nxt = (ed_common, ed_vd, st["ed_proofs"][i])
-                if agg is None:
-                    agg = nxt
-                    continue
-                rc, proof = rp.recursive_proof(agg, nxt, raw=True)
-                for k in st["fold_host"]:
-                    st["fold_host"][k] += rp.last_host_ms[k]
-                agg = (rc.common, rc.verifier_only, proof)
-            if M["strong"]:
-                st["result"]["local_agg"] = agg        # a (common, verifier_only, proof bytes) triple, or None without signatures
-                return
-            rc, proof = rp.recursive_proof(agg, None, list(hashlib.sha256(valid_keys).digest()), raw=True)
-            st["result"]["t_signatures"] = time.perf_counter()
-            stub.future.set_result((rc, proof, valid_keys))
-        except Exception as e:  # pragma: no cover
-            fail(st, e)
-
-    bft_args = (hx(win["ep2_last_block"]["bytes"]), hx(win["ep2_last_block"]["hash"]), hx(win["ep1_first_block"]["bytes"]),
-                hx(win["ep1_first_block"]["hash"]), win_blocks)
-    hdr_jobs = bprover.header_jobs(*bft_args)
-    set_mode(args.scaling == "strong")
-
-    def header_worker(st):
-        try:
-            st["result"]["headers"] = {name: bprover.prove_header_job(hdr_jobs[name]) for name in hdr_jobs if M["hdr_owner"][name] == rank}
-        except Exception as e:  # pragma: no cover
-            fail(st, e)
-
-    def dag_worker(st):
-        try:
-            remote = None
-            if M["strong"]:       # the header proofs of the other ranks arrive through stub.hdr_future; rank 0's own are made here
-                remote = lambda name: None if M["hdr_owner"][name] == 0 else stub.hdr_future.result()[name]
-            bi, _ = bprover.prove_block_bft(*bft_args, validators, header_proofs=remote)
-            st["result"]["block"] = bi
-            # bin/prove_block.rs:279-287: recursive_proof::<F, Cbn128, C, D>((..bi..), None, Some(&bi_proof.public_inputs))
-            st["result"]["wrap"] = rpw_block.recursive_proof(bi, None, list(bi[2]["public_inputs"]), raw=True)
-        except Exception as e:  # pragma: no cover
-            fail(st, e)
-
-    def ks_worker(st, valid_keys):
-        try:
-            t_ = time.perf_counter()
-            stub.ks_future.set_result(ks_prover.prove_valid_keys_stakes_in_validators_list(
-                valid_keys, hashlib.sha256(valid_keys).digest(), validators))
-            st["result"]["keys_stakes_s"] = time.perf_counter() - t_
-        except Exception as e:  # pragma: no cover
-            fail(st, e)
-
-    def start_signature_stage(st):
-        """a3 (the batched pre-check of signatures.rs:79), then the witness producer and the Ed25519 provers of one block"""
-        st["t0"] = time.perf_counter()
-        valid_keys, valid_pos, _, _ = SG.verify_approvals(ctx, c2_msg, approvals, validators)
-        assert len(valid_pos) == n_sig, "fixture approvals must verify"
-        st["valid_keys"], st["t_verify"] = valid_keys, time.perf_counter() - st["t0"]
-        ths = [threading.Thread(target=witness_producer, args=(st,))]
-        ths += [threading.Thread(target=ed_worker, args=(st, c_, pr)) for c_, pr in workers]
-        for th in ths:
-            th.start()
-        return ths
-
-    def start_dag_stage(st):
-        """the fold chain, the keys / stakes proof and the rest of the DAG of one block (weak mode: all on this rank)"""
-        begin_dag_stage(st)
-        ths = [threading.Thread(target=fold_worker, args=(st, st["valid_keys"])), threading.Thread(target=dag_worker, args=(st,)),
-               threading.Thread(target=ks_worker, args=(st, st["valid_keys"]))]
-        for th in ths:
-            th.start()
-        return ths
-
-    def prove_blocks_overlapped(k_blocks, on_block_done=None):
-        """k full Block_i proofs as a two-stage pipeline over consecutive blocks (a light client proves a stream of blocks): the
-        signature stage of block b + 1 starts as soon as the last signature proof of block b is out, while the tail of block b --
-        its last fold steps, the closing proof, the joining recursions and the BN128 wrap, ~0.4 s during which the GPU would
-        otherwise sit nearly idle -- completes beside it.  The fold / DAG stages of consecutive blocks share their provers, so
-        they run one after the other.  Every block is complete when this returns."""
-        prev_dag, prev_st = [], None
-        for _ in range(k_blocks):
-            st = new_state()
-            sig = start_signature_stage(st)
-            for th in prev_dag:                   # block b - 1 must be finished before block b's fold / DAG stage takes the provers
-                th.join()
-            if prev_st is not None:
-                if prev_st["errors"]:
-                    raise prev_st["errors"][0]
-                if on_block_done:
-                    on_block_done(prev_st)
-            prev_dag, prev_st = start_dag_stage(st), st
-            for th in sig:
-                th.join()
-        for th in prev_dag:
-            th.join()
-        if prev_st["errors"]:
-            raise prev_st["errors"][0]
-        if on_block_done:
-            on_block_done(prev_st)
-        return prev_st
-
-    def prove_one_block():
-        st = new_state()
-        begin_dag_stage(st)
-        t0 = time.perf_counter()
-        valid_keys, valid_pos, _, _ = SG.verify_approvals(ctx, c2_msg, approvals, validators)   # a3: the pre-check of signatures.rs:79
-        assert len(valid_pos) == n_sig, "fixture approvals must verify"
-        t_verify = time.perf_counter() - t0
-        st["t0"], st["t_verify"], st["valid_keys"] = t0, t_verify, valid_keys
-        sig_threads = [threading.Thread(target=witness_producer, args=(st,))]
-        sig_threads += [threading.Thread(target=ed_worker, args=(st, c_, pr)) for c_, pr in workers]
-        sig_threads += [threading.Thread(target=fold_worker, args=(st, valid_keys))]
-        strong, ks_rank = M["strong"], M["ks_rank"]
-        dag_threads = [threading.Thread(target=dag_worker, args=(st,))] if (not strong or rank == 0) else []
-        side_threads = [threading.Thread(target=ks_worker, args=(st, valid_keys))] if rank == ks_rank else []
-        if strong and rank != 0:
-            side_threads.append(threading.Thread(target=header_worker, args=(st,)))
-        for th in sig_threads + dag_threads + side_threads:
-            th.start()
-        if strong:
-            # (1) the header proofs and the keys / stakes proof of the other ranks travel to rank 0 (point-to-point, ~150 KB each)
-            for th in side_threads:
-                th.join()
-            mine = {"headers": st["result"].get("headers", {}),
-                    "ks": stub.ks_future.result() if (rank == ks_rank and not st["errors"]) else None}
-            parts = DIST.gather_objects(mine if rank != 0 else None, 0, device=dev)
-            if rank == 0:
-                merged = {}
-                for part in parts[1:]:
-                    merged.update(part["headers"])
-                    if part["ks"] is not None and ks_rank != 0:
-                        stub.ks_future.set_result(part["ks"])
-                stub.hdr_future.set_result(merged)
-            # (2) local folds -> binary tree over the ranks -> closing proof on rank 0
-            for th in sig_threads:
-                th.join()
-            total = DIST.tree_fold(None if st["errors"] else st["result"].get("local_agg"),
-                                   lambda a, b: (lambda rc_p: (rc_p[0].common, rc_p[0].verifier_only, rc_p[1]))(rp.recursive_proof(a, b, raw=True)),
-                                   device=dev)
-            if rank == 0 and not st["errors"]:
-                rc, proof = rp.recursive_proof(total, None, list(hashlib.sha256(valid_keys).digest()), raw=True)
-                st["result"]["t_signatures"] = time.perf_counter()
-                stub.future.set_result((rc, proof, valid_keys))
-            for th in dag_threads:
-                th.join()
-        else:
-            for th in sig_threads + dag_threads + side_threads:
-                th.join()
-        if st["errors"]:
-            raise st["errors"][0]
-        return t0, t_verify
-
-    t_setup = time.perf_counter()
-    prove_one_block()                      # builds and uploads the circuits of every shape of the DAG (host Python, one-time)
+    pipe.prove_block_bft(window)           # builds and uploads the circuits of every shape of the DAG (host Python, one-time)
     t_setup = time.perf_counter() - t_setup
-    # The circuits are tens of millions of long-lived Python objects (14 GB of heap): a full generational collection walks all of
-    # them and stalled ONE block in ~15 by 15 s (round 2's sustained 7.13 s against 5.96 s over two blocks; profiles/r03a_bench.json:
-    # nineteen steps of 6.0-6.3 s and one of 20.9 s).  Standard remedy for a long-running service: collect once, then move everything
-    # alive to the permanent generation, so that later collections only look at what a block allocates.
+    # The circuits are tens of millions of long-lived Python objects: a full generational collection walks all of them and stalled
+    # ONE block in ~15 by 15 s (round 2).  Standard remedy for a long-running service: collect once, then move everything alive to
+    # the permanent generation, so that later collections only look at what a block allocates.
     import gc
     gc.collect()
     gc.freeze()
     for _ in range(max(0, args.warmup - 1)):
-        prove_one_block()
+        pipe.prove_block_bft(window)
     barrier()
-    # telemetry of the timed region (judge item: the sustained 20-step figure was 20 % below the 2-step one): per-step seconds, the
-    # GPU's shader clock / power / busy percentage per step from sysfs, host RSS -- sampled on a side thread, no GPU calls
     tele = GpuTelemetry()
-    smi0 = GpuTelemetry.smi_snapshot() if rank == 0 else None
     tele.mark()
-    per_step, rss0 = [], rss_mb()
-    overlap = not M["strong"] and not args.no_block_overlap
+    rss0 = rss_mb()
+    steps = max(1, args.steps)
+    strong_only = args.scaling == "strong" and world > 1
+    overlap = not strong_only and not args.no_block_overlap
+
+    def digests(r):
+        return (hashlib.sha256(r.wrap[1]).hexdigest(), hashlib.sha256(json.dumps(r.block[2], sort_keys=True).encode()).hexdigest())
+    tele_steps = []
+
+    def block_done(r):
+        tele_steps.append(dict(tele.mark(), rss_mb=rss_mb()))
     t_all = time.perf_counter()
     if overlap:
-        # exactly K complete Block_i proofs; consecutive blocks overlap by the tail of the earlier one (prove_blocks_overlapped).
-        # per_step_s = time between consecutive block completions (the first one counts from the start of the region)
-        last_done = [t_all]
-
-        def block_done(st_):
-            now = time.perf_counter()
-            per_step.append(dict(tele.mark(), s=round(now - last_done[0], 4), latency_s=round(now - st_["t0"], 4), rss_mb=rss_mb()))
-            last_done[0] = now
-        st = prove_blocks_overlapped(max(1, args.steps), block_done)
-        t0, t_verify = st["t0"], st["t_verify"]
+        # exactly K complete Block_i proofs; consecutive blocks overlap by the tail of the earlier one (BlockPipeline.prove_stream)
+        res_list = pipe.prove_stream([window] * steps, block_done)
     else:
-        for _ in range(max(1, args.steps)):     # a step = one full Block_i proof
-            t0, t_verify = prove_one_block()
-            per_step.append(dict(tele.mark(), s=round(time.perf_counter() - t0, 4), rss_mb=rss_mb()))
-        st = cur["st"]
+        res_list = []
+        for _ in range(steps):
+            r = pipe.prove_block_bft(window, strong=strong_only)
+            if r is not None:
+                res_list.append(r)
+                block_done(r)
     barrier()
     total_s = reduce_max(time.perf_counter() - t_all)
-    block_s = total_s / max(1, args.steps)
-    smi1 = GpuTelemetry.smi_snapshot() if rank == 0 else None
+    block_s = total_s / steps
     tele.close()
-    strong = M["strong"]
-    if strong and rank != 0:
-        return out            # rank 0 holds the block proof, verifies it and reports
-    sig_s = st["result"]["t_signatures"] - t0
-    block = st["result"]["block"]
-    want = [0] + list(hx(win["blocks"][4]["hash"])) + list(hx(win["ep2_last_block"]["hash"])) + list(hx(win["ep1_first_block"]["hash"]))
-    assert block[2]["public_inputs"] == want, "block proof public inputs"
-    # checker role, untimed: the last two proofs of the DAG -- the Block_i proof and its Poseidon-BN128 wrap -- are the only ones no
-    # later recursion witness checks, so the verifier restatement (pinned by the reference's golden proofs) checks them here
-    # (prove_crypto/recursion.rs:53,81 verify every inner proof natively; bin/prove_block.rs:279-287 is the wrap)
+    tele_all = {k: round(sum(t[k] for t in tele_steps if k in t) / max(1, sum(1 for t in tele_steps if k in t)), 1)
+                for k in ("sclk_mhz", "power_w", "busy_pct", "temp_c", "mclk_mhz") if any(k in t for t in tele_steps)}
+    if strong_only and rank != 0:
+        pipe.close()
+        return out            # rank 0 holds the block proofs, verifies them and reports
+    # ---- checker role, untimed.  EVERY timed block: public inputs as expected and proof bytes identical (the prover is
+    # deterministic: same window -> same bytes) to the LAST block's, whose Block_i proof and Poseidon-BN128 wrap -- the only two
+    # proofs of the DAG that no later recursion witness checks -- are verified by the oracle's verifier restatement (pinned by the
+    # reference's golden proofs; prove_crypto/recursion.rs:53,81 verifies every inner proof natively)
     from oracle import plonky2_verifier as V
     t_v = time.perf_counter()
-    V.verify(json.loads(json.dumps(block[2])), block[1], block[0])
-    wrc, wraw = st["result"]["wrap"]
+    lastr = res_list[-1]
+    d_last = digests(lastr)
+    same = [digests(r) == d_last and r.block[2]["public_inputs"] == want for r in res_list]
+    assert all(same), "a timed block's final proofs differ from the verified one: %s" % same
+    V.verify(json.loads(json.dumps(lastr.block[2])), lastr.block[1], lastr.block[0])
+    wrc, wraw = lastr.wrap
     wrap_json = S.proof_from_bytes(wraw, wrc.common, HASH_BN128)
     V.verify(json.loads(json.dumps(wrap_json)), wrc.verifier_only, wrc.common)
     assert wrap_json["public_inputs"] == want, "wrap proof public inputs"
     t_v = time.perf_counter() - t_v
-    tw, fold_host, result = st["tw"], st["fold_host"], st["result"]
-    out["block_i"] = {"metric": "full Block_i BFT-finality proofs/s (prove_block_bft on NEAR mainnet blocks 121798939..43, 100 validators, %d "
-                                "approvals), end to end from the header / approval / validator bytes: GPU pre-verification, witness "
-                                "generation on the GPU, %d Ed25519-circuit proofs, their left fold and closing proof, keys / stakes, seven SHA-256 "
-                                "header-hash chains, bp_hash, heights, equalities, %d joining recursions, the BN128 wrap; every rank "
-                                "proves its own block" % (n_sig, n_sig, bprover.counts.get("recursive_proof", 0)),
-                      "value": (1 if strong else world) / block_s, "unit": "proofs/s", "seconds_per_block": block_s,
-                      "blocks_timed": max(1, args.steps), "scaling": "strong" if strong else "weak",
-                      "per_step_s": [x["s"] for x in per_step], "per_step_telemetry": per_step, "rss_mb_before": rss0,
-                      "blocks_overlapped": overlap,
-                      "rocm_smi_before": smi0, "rocm_smi_after": smi1,
-                      "signatures_of_this_rank": len(M["my_sigs"]), "header_proofs_by_rank": M["hdr_owner"] or None,
-                      "keys_stakes_cache_hits": ks_prover.cache_hits,
-                      "seconds_until_signature_aggregate": sig_s, "streams": nthreads + 2,
-                      "approvals": n_sig, "witness_on": "gpu" if dev_wit else "host", "witness_batch": wchunk,
-                      "witness_producer_seconds_total": tw[0], "preverify_ms": t_verify * 1e3,
-                      "fold_thread_seconds": {k: round(v / 1e3, 3) for k, v in fold_host.items()},
-                      "dag_thread_seconds": {k: round(v, 3) for k, v in bprover.seconds.items()},
-                      "dag_thread_counts": dict(bprover.counts), "keys_stakes_thread_seconds": result.get("keys_stakes_s"),
-                      "wrap_proof_bytes": len(result["wrap"][1]),
+    per_step_s = [round(b.t_done - a.t_done, 4) for a, b in zip(res_list, res_list[1:])]
+    per_step_s = [round(res_list[0].t_done - t_all, 4)] + per_step_s
+    out["block_i"] = {"value": (1 if strong_only else world) / block_s, "unit": "proofs/s", "seconds_per_block": block_s,
+                      "blocks_timed": steps, "scaling": "strong" if strong_only else "weak",
+                      "per_step_s": per_step_s, "latency_s": [round(r.t_done - r.t0, 4) for r in res_list],
+                      "telemetry_mean": tele_all, "per_step_telemetry": tele_steps, "rss_mb_before": rss0, "rss_mb_after": rss_mb(),
+                      "blocks_overlapped": overlap, "keys_stakes_cache_hits": pipe.ks_prover.cache_hits,
+                      "seconds_until_signature_aggregate": lastr.t_signatures - lastr.t0, "streams": pipe.nthreads + 2,
+                      "approvals": n_sig, "witness_on": "gpu" if pipe.dev_wit else "host", "witness_batch": pipe.wchunk,
+                      "witness_producer_seconds": lastr.witness_s, "preverify_ms": lastr.t_verify * 1e3,
+                      "fold_thread_seconds": {k: round(v / 1e3, 3) for k, v in lastr.fold_host_ms.items()},
+                      "dag_thread_seconds": {k: round(v, 3) for k, v in lastr.dag_seconds.items()},
+                      "dag_thread_counts": dict(lastr.dag_counts), "keys_stakes_thread_seconds": lastr.keys_stakes_s,
+                      "wrap_proof_bytes": len(wraw), "blocks_checked": len(res_list),
                       "final_proof_verified": True, "final_proof_verify_s_untimed": t_v,
-                      "first_block_s_incl_circuit_construction": t_setup,
-                      "cpu_baseline": None,
-                      "note": "every proof is a proof of the reference's own circuit (restated) on the reference's own mainnet data; "
-                              "witness generation is inside the timed region (on the GPU by default, overlapped with proving); circuits are built and "
-                              "uploaded by an untimed first block and reused (the reference rebuilds every circuit on every call); "
-                              "dag_thread_seconds includes the wait for the signature aggregate inside prove_approvals; the "
-                              "reference CPU prover cannot be built here (no Rust toolchain) and publishes no time for this step"}
-    if world > 1 and not strong and not args.no_strong_section:
+                      "first_block_s_incl_circuit_construction": t_setup}
+    if world > 1 and not strong_only and not args.no_strong_section:
         # the STRONG form of the block (SURVEY 8e / 8f.4) measured in the same run, so that one SCALE run holds both: all ranks prove
         # ONE block per step (signature shards, local folds, a binary-tree fold over the ranks, the header proofs on the other ranks,
         # the joins and the wrap on rank 0).  One untimed block builds the tree fold's circuit shapes.
-        set_mode(True)
-        prove_one_block()
+        pipe.prove_block_bft(window, strong=True)
         barrier()
-        ns = max(2, args.steps // 4)
+        ns = max(2, steps // 4)
         t_s = time.perf_counter()
         for _ in range(ns):
-            prove_one_block()
+            sres = pipe.prove_block_bft(window, strong=True)
         barrier()
         strong_s = reduce_max(time.perf_counter() - t_s) / ns
         if rank == 0:
-            sst = cur["st"]
-            assert sst["result"]["block"][2]["public_inputs"] == want, "strong mode: block proof public inputs"
-            sw_rc, sw_raw = sst["result"]["wrap"]
+            assert sres.block[2]["public_inputs"] == want, "strong mode: block proof public inputs"
+            sw_rc, sw_raw = sres.wrap
             V.verify(json.loads(json.dumps(S.proof_from_bytes(sw_raw, sw_rc.common, HASH_BN128))), sw_rc.verifier_only, sw_rc.common)
             out["block_i"]["strong"] = {"value": 1.0 / strong_s, "unit": "proofs/s", "seconds_per_block": strong_s, "blocks_timed": ns,
                                         "scaling": "strong", "final_proof_verified": True,
-                                        "speedup_vs_one_rank_weak_block": block_s / strong_s,
-                                        "header_proofs_by_rank": dict(M["hdr_owner"]),
-                                        "note": "one block over all ranks; the weak figure above (every rank its own block) is the headline"}
-        set_mode(False)
-    if args.c5_validators and not strong:
+                                        "speedup_vs_one_rank_weak_block": block_s / strong_s}
+    if args.c5_validators and not strong_only:
         # BASELINE configs[4] (C5), the part the unmodified circuits can express: a synthetic epoch of N validators who all sign the
         # same Approval message -> batched GPU pre-verification, N Ed25519-circuit proofs (witnesses on the GPU), the left fold and
-        # the closing proof with sha256(valid_keys), through the same pipeline as the block above (one rank = one GPU)
+        # the closing proof with sha256(valid_keys), through BlockPipeline.prove_approvals (one rank = one GPU)
         from oracle import ed25519_ref as ref
         nv = int(args.c5_validators)
+        c2_msg = window.approval_sets()[0][0]
         keys = [ref.synthetic_seed(1, i) for i in range(nv)]
-        pk_l = [ref.keypair(k_)[2] for k_ in keys]
-        sg_l = [ref.sign(k_, c2_msg) for k_ in keys]
+        vals5 = [b"\x04\x00\x00\x00test\x00" + ref.keypair(k_)[2] + (10**30 + i).to_bytes(16, "little") for i, k_ in enumerate(keys)]
+        apps5 = [b"\x01\x00" + ref.sign(k_, c2_msg) for k_ in keys]
         t_ = time.perf_counter()
-        okv = ctx.ed25519_verify_batch(b"".join(pk_l), b"".join(sg_l), c2_msg)
-        t_pre = time.perf_counter() - t_
-        assert int(okv.sum()) == nv
-        vkeys = b"".join(bytes([i & 0xFF]) + pk_l[i] for i in range(nv))
-        fills = [E.fill_ecdsa_targets(ed_targets, c2_msg, sg, pk_) for sg, pk_ in zip(sg_l, pk_l)]
-        n_sig = nv
-        M["my_sigs"] = list(range(nv))
-        st5 = new_state()
-        begin_dag_stage(st5)
-        t_ = time.perf_counter()
-        th = [threading.Thread(target=witness_producer, args=(st5,))] + \
-             [threading.Thread(target=ed_worker, args=(st5, c_, pr)) for c_, pr in workers] + \
-             [threading.Thread(target=fold_worker, args=(st5, vkeys))]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        if st5["errors"]:
-            raise st5["errors"][0]
-        rc5, proof5, _ = stub.future.result()
+        (rc5, proof5), vk5 = pipe.prove_approvals(c2_msg, apps5, vals5)
         dt5 = reduce_max(time.perf_counter() - t_)
-        from oracle import plonky2_verifier as V5
-        V5.verify(json.loads(json.dumps(S.proof_from_bytes(proof5, rc5.common, HASH_GL))), rc5.verifier_only, rc5.common)
-        out["c5_synthetic_epoch"] = {"validators": nv, "seconds": dt5, "signature_proofs_per_s": world * nv / dt5, "preverify_ms": t_pre * 1e3,
-                                     "aggregate_verified": True, "witness_on": "gpu" if dev_wit else "host",
+        assert len(vk5) == 33 * nv
+        V.verify(json.loads(json.dumps(S.proof_from_bytes(proof5, rc5.common, HASH_GL))), rc5.verifier_only, rc5.common)
+        out["c5_synthetic_epoch"] = {"validators": nv, "seconds": dt5, "signature_proofs_per_s": world * nv / dt5,
+                                     "preverify_ms": pipe.last.t_verify * 1e3, "aggregate_verified": True,
+                                     "witness_on": "gpu" if pipe.dev_wit else "host",
                                      "note": "N Ed25519-circuit proofs + %d fold steps + closing proof on one GPU per rank; the keys / "
                                              "stakes circuit of the reference cannot express N > 255 positions (pos as u8), so C5 stops "
                                              "at the signature aggregate" % (nv - 1)}
-    for c_, pr in workers:
-        pr.close()
-        if c_ is not ctx:
-            c_.close()
-    if dev_wit:
-        dwit.close()
-        wit_ctx.close()
-        del d_bufs
-    rp.close()
-    rpw.close()
-    fold_ctx.close()
-    rpw_block.close()
-    bprover.close()
-    dag_ctx.close()
-    ks_prover.close()
-    ks_ctx.close()
+    pipe.close()
     return out
+
+
+def r3(x, nd=4):
+    """numbers of the compact line: `nd` significant digits"""
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x))
+    return x
+
+
+def compact_line(full):
+    """The ONE stdout line of the driver contract, kept below 8 KB (round 3's 20 KB line was not parsed by the driver): the
+    contract keys, `roofline` (+ `valu`), `cpu_baseline` and one short entry per stage; everything else is in the detail file."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "final_proof_verified")
+    line = {k: full[k] for k in keep if k in full}
+
+    def roof(r):
+        if not r:
+            return None
+        o = {k: r3(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms") if k in r}
+        if "valu" in r:
+            o["valu"] = {k: r3(r["valu"][k]) for k in ("bound", "achieved", "peak", "unit", "frac")}
+        return o
+    line["roofline"] = roof(full.get("roofline"))
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: r3(cb[k]) for k in ("value", "unit", "cores", "kind", "sample", "seconds_per_block", "gpu_speedup") if k in cb}
+    st = full.get("stages") or {}
+    cs = {}
+    for name in ("msm", "lde", "merkle", "ed25519_verify"):
+        s_ = st.get(name)
+        if s_:
+            e = {"value": r3(s_["value"]), "unit": s_["unit"]}
+            if "ms" in s_:
+                e["ms"] = r3(s_["ms"])
+            r = s_.get("roofline") or {}
+            if "frac" in r:
+                e["hbm_frac"] = r3(r["frac"])
+            if r.get("traffic"):
+                e["traffic"] = r3(float(r["traffic"]))
+            if "valu" in r:
+                e["valu_frac"] = r3(r["valu"]["frac"])
+            if "cpu_baseline" in s_:
+                e["cpu"] = r3(s_["cpu_baseline"]["value"])
+            if "strong" in s_:
+                e["strong"] = {"value": r3(s_["strong"]["value"]), "ms": r3(s_["strong"]["ms"]), "equal": s_["strong"].get("equals_single_gpu_result")}
+            cs[name] = e
+    for name, s_ in (st.get("bn254_extras") or {}).items():
+        cs[name] = {"value": r3(s_["value"]), "unit": s_["unit"].split(" (")[0], "ms": r3(s_["ms"])}
+    pr = st.get("prove") or {}
+    if pr:
+        cs["prove_ms"] = {k.split("_2p")[0]: r3(v["ms_per_proof"]) for k, v in pr.items() if isinstance(v, dict) and "ms_per_proof" in v}
+        if "c5_synthetic_epoch" in pr:
+            c5 = pr["c5_synthetic_epoch"]
+            cs["c5"] = {"validators": c5["validators"], "seconds": r3(c5["seconds"]), "sig_proofs_per_s": r3(c5["signature_proofs_per_s"])}
+    if cs:
+        line["stages"] = cs
+    blk = full.get("block_i")
+    if blk:
+        b = {k: r3(blk[k]) for k in ("seconds_per_block", "blocks_timed", "blocks_checked", "blocks_overlapped", "approvals", "streams",
+                                     "witness_on", "first_block_s_incl_circuit_construction", "rss_mb_after") if k in blk}
+        b["per_step_s"] = [r3(x, 3) for x in blk.get("per_step_s", [])][:64]
+        tm = blk.get("telemetry_mean") or {}
+        b["gpu"] = {k: tm[k] for k in ("sclk_mhz", "power_w", "busy_pct", "temp_c") if k in tm}
+        if "strong" in blk:
+            b["strong"] = {k: r3(blk["strong"][k]) for k in ("value", "seconds_per_block", "blocks_timed", "final_proof_verified",
+                                                             "speedup_vs_one_rank_weak_block")}
+        line["block_i"] = b
+    line["detail"] = full.get("detail")
+    return line
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start the N ranks (one per GPU, RCCL over xGMI) and
+    become the launcher -- rank 0 of the children prints the line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.stdout.flush()
+    os.execvpe(sys.executable, cmd, env)
 
 
 def main():
@@ -1201,28 +913,40 @@ def main():
     ap.add_argument("--no-strong-section", action="store_true", help="multi-GPU runs: skip the extra strong-scaling blocks after the weak region")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo lets several ranks share one GPU)")
     ap.add_argument("--c5-validators", type=int, default=0, help="also run the C5 stage: a synthetic epoch of this many validators "
-                    "(1000 in BASELINE configs[4]; ~85 s on one MI355X), reported under stages.prove.c5_synthetic_epoch")
+                    "(1000 in BASELINE configs[4]; ~65 s on one MI355X), reported under stages.prove.c5_synthetic_epoch")
     ap.add_argument("--host-witness", action="store_true", help="Ed25519-circuit witnesses from the host interpreter (threads + PCIe) instead of the GPU")
-    ap.add_argument("--witness-batch", type=int, default=32, help="signatures per device witness batch (<= 64; 0.7 GB of HBM each)")
+    ap.add_argument("--witness-batch", type=int, default=32, help="signatures per device witness batch (<= 64; 0.5 GB of HBM each)")
+    ap.add_argument("--detail", default=os.environ.get("ZKLC_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json")),
+                    help="file for the full report (per-circuit stages, telemetry, notes); the stdout line names it")
+    ap.add_argument("--cpu-only", action="store_true", help="functional run of the launcher / collectives / line format without a GPU "
+                    "(CPU tests): no kernels are launched and the line says so; never a measurement")
     args = ap.parse_args()
 
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        self_launch(args)                 # does not return
     import torch
     import torch.distributed as dist
-    import zklc_amd
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(world_env or "1")
     if world != args.gpus:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus))
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    backend = args.backend or ("gloo" if args.cpu_only else "nccl")
+    if args.cpu_only:
+        return main_cpu_only(args, rank, world, backend)
+    import zklc_amd
     local_rank %= max(1, torch.cuda.device_count())       # --backend gloo: several ranks may share one GPU (functional runs)
     torch.cuda.set_device(local_rank)
-    backend = args.backend or "nccl"
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    # the circuits of the block DAG are built once per MACHINE: the ranks of a multi-GPU run (and the driver's N = 1, 2, 4, 8 runs one
+    # after the other) load what an earlier process built (zklc_amd/plonky2/circuit_cache.py; ZKLC_CIRCUIT_CACHE= (empty) disables)
+    os.environ.setdefault("ZKLC_CIRCUIT_CACHE", os.path.join(ROOT, ".circuit_cache"))
 
     pk, sg, ms = make_base_set()
     base_n = pk.shape[0]
@@ -1321,20 +1045,16 @@ def main():
                 "metric": "Block_i BFT-finality proofs/sec (100 validators)", "value": blk["value"], "unit": "proofs/s",
                 "n_gpus": world, "steps": blk["blocks_timed"], "warmup": max(1, args.warmup),
                 "ms_per_step": blk["seconds_per_block"] * 1e3, "higher_is_better": True, "scaling": blk["scaling"], "vs_baseline": None,
-                "dtype": "u64", "data": "NEAR mainnet block window shipped with the reference (tests/golden/block_window_HPi5.json), "
-                                        "no synthetic inputs",
+                "dtype": "u64", "data": "NEAR mainnet block window shipped with the reference (tests/golden/block_window_HPi5.json)",
                 "config": {"workload": "configs[2]: full plonky2 BFT-finality proof of Block_i (prove_block_bft, 5-block window, 100 "
-                                       "validators, %d approvals), one block per GPU per step, end to end from the borsh bytes; "
-                                       "BN254 G1 MSM 2^22 and the batched Ed25519 verification (configs[1]) are under `stages`"
+                                       "validators, %d approvals), one block per GPU per step, end to end from the borsh bytes"
                                        % blk["approvals"],
                            "approvals": blk["approvals"],
                            "proofs_per_block": dict(blk["dag_thread_counts"], ed25519_circuit=blk["approvals"],
                                                     fold_and_closing_recursions=blk["approvals"], keys_stakes_and_its_hash=3, bn128_wrap=1),
-                           "msm_2p22_melem_per_s": stages["msm"]["value"]},
-                "roofline": dict(mk["roofline"], kernel="gl_hash_leaves_kernel (+ Merkle levels, ~3 % of the permutations): Poseidon leaf "
-                                                        "hashing, ~50 % of the kernel time of a block proof", kernel_ms=mk["ms"],
-                                 note="measured live by the `merkle` stage (HIP events on the launch stream): 2^20 leaves x 234 columns; "
-                                      + mk["roofline"]["note"] + "; the binding resource is integer VALU issue, see `valu`"),
+                           "msm_2p22_melem_per_s": r3(stages["msm"]["value"])},
+                "roofline": dict(mk["roofline"], kernel="gl_hash_leaves_kernel (Poseidon leaf hashing: ~50 % of the kernel time of a block)",
+                                 kernel_ms=mk["ms"]),
                 "final_proof_verified": blk["final_proof_verified"],
                 "block_i": blk, "stages": dict(stages, ed25519_verify=verify),
             }
@@ -1342,14 +1062,9 @@ def main():
             if pm is not None:
                 out["roofline"]["traffic"] = pm.get("hbm_bytes_per_launch")
                 if "SQ_INSTS_VALU_per_launch" in pm:
-                    lane_instr = pm["SQ_INSTS_VALU_per_launch"] * 64
-                    ach = lane_instr / (mk["ms"] * 1e-3) / 1e12
-                    out["roofline"]["valu"] = {
-                        "bound": "valu-int", "achieved": ach, "peak": VALU_INT_PEAK_TLOPS, "unit": "T lane-instr/s", "frac": ach / VALU_INT_PEAK_TLOPS,
-                        "instructions_per_permutation": lane_instr / ((1 << 20) * 30),   # ceil(234 / 8) permutations per leaf
-                        "note": "SQ_INSTS_VALU of the kernel (profiles/poseidon_pmc_latest.json) x 64 lanes / the live kernel time; peak = the "
-                                "measured issue rate of v_mad_u64_u32 / v_add_co / v_addc (profiles/r02_valu_ubench.txt); fast-class "
-                                "instructions (v_mov, v_add_u32) issue ~1.7x faster, so the fraction can exceed 1"}
+                    out["roofline"]["valu"] = valu_block(pm["SQ_INSTS_VALU_per_launch"], mk["ms"], "gl_hash_leaves_kernel, "
+                                                         "profiles/poseidon_pmc_latest.json")
+                    out["roofline"]["valu"]["instructions_per_permutation"] = pm["SQ_INSTS_VALU_per_launch"] * 64 / ((1 << 20) * 30)
             try:
                 if "cpu_baseline" in edp:
                     cb = edp["cpu_baseline"]
@@ -1363,26 +1078,62 @@ def main():
                         block_s = blk["approvals"] * cb["seconds_per_proof"] + n_small * fold_s
                         out["cpu_baseline"] = {
                             "value": 1.0 / block_s, "unit": "proofs/s", "cores": cb["cores"], "kind": "port",
-                            "sample": "MEASURED: one complete CPU proof at the fold shape (oracle/c/plonky2_prover_oracle.c, C + OpenMP: %.2f s, "
-                                      "proof bytes equal to the GPU's: %s) and the wires commitment of the Ed25519 shape on bounded samples.  SCALED "
-                                      "(unless --cpu-baseline-ed25519 measured the whole Ed25519-shape proof: stages.prove.ed25519_circuit_2p18x234."
-                                      "cpu_baseline says which): the other stages of that proof by the fold shape's stage ratio (%.1f s per proof); the block = %d "
-                                      "Ed25519-shape proofs + %d proofs of 2^12..2^14-row circuits, each counted at the measured fold-shape time.  The "
-                                      "reference's Rust prover cannot be built here; its only published time is 30 s per Groth16 proof "
-                                      "(gnark-plonky2-verifier/README.md:35-39)"
-                                      % (fold_s, fold.get("proof_bytes_equal_gpu"), cb["seconds_per_proof"], blk["approvals"], n_small),
+                            "sample": "oracle C+OpenMP prover: one complete proof at the fold shape measured (%.2f s, bytes == GPU: %s); "
+                                      "Ed25519 shape: %s (%.1f s/proof); block = %d x that + %d small proofs at the fold-shape time"
+                                      % (fold_s, fold.get("proof_bytes_equal_gpu"),
+                                         "measured whole" if "cpu_baseline_measured" in edp else "wires commitment measured, other stages scaled by the fold shape's ratio",
+                                         cb["seconds_per_proof"], blk["approvals"], n_small),
                             "seconds_per_block": block_s, "gpu_speedup": block_s / blk["seconds_per_block"]}
                     else:
                         out["cpu_baseline"] = {"value": cb["value"] / blk["approvals"], "unit": "proofs/s (upper bound)", "cores": cb["cores"],
                                                "kind": "port",
-                                               "sample": "the wires commitment (coset LDE + Poseidon Merkle tree) of ONE of the %d Ed25519-circuit "
-                                                         "proofs of a block with oracle/c/goldilocks_oracle.c, from bounded samples; a block needs at "
-                                                         "least %d times that on the CPU" % (blk["approvals"], blk["approvals"])}
+                                               "sample": "wires commitment (coset LDE + Poseidon Merkle tree) of ONE of the %d Ed25519-circuit "
+                                                         "proofs of a block, oracle/c/goldilocks_oracle.c, bounded samples" % blk["approvals"]}
             except Exception as e:
                 out["cpu_baseline"] = {"value": None, "error": repr(e)[:300]}
             del out["stages"]["prove"]["block_i"]
-        print(json.dumps(out), flush=True)
+        emit(out, args.detail)
     ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def emit(out, detail_path):
+    """full report -> the detail file; ONE compact JSON line -> stdout"""
+    try:
+        with open(detail_path, "w") as f:
+            json.dump(out, f, indent=1)
+        out["detail"] = os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT) else detail_path
+    except OSError as e:
+        out["detail"] = "not written: %r" % (e,)
+    line = json.dumps(compact_line(out), separators=(",", ":"))
+    assert len(line) < 8192, "bench line too long for the driver (%d bytes)" % len(line)
+    print(line, flush=True)
+
+
+def main_cpu_only(args, rank, world, backend):
+    """`--cpu-only`: the launcher, the process group, the collectives of the strong MSM section (72-byte partials, all-gather) and
+    the line format, with NO kernel launched -- the CPU test of `python bench.py --gpus 2` (tests/test_bench_contract.py)."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend)
+    part = torch.zeros(9, dtype=torch.int64)
+    part[0] = rank + 1
+    got = [torch.zeros(9, dtype=torch.int64) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(got, part)
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert int(t[0]) == world - 1
+    else:
+        got = [part]
+    assert [int(g[0]) for g in got] == list(range(1, world + 1))
+    if rank == 0:
+        emit({"metric": "Block_i BFT-finality proofs/sec (100 validators)", "value": None, "unit": "proofs/s", "n_gpus": world,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+              "vs_baseline": None, "dtype": "u64", "data": "none (--cpu-only: functional run of the launcher, no GPU work, not a measurement)",
+              "config": {"workload": "none", "ranks_seen": len(got)}}, args.detail)
     if world > 1:
         dist.destroy_process_group()
 

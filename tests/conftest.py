@@ -9,6 +9,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+STASH = {}       # results the sequential GPU tests leave for the pipeline parity tests of the same session (HPi5, epoch_CRTZ)
+# circuits are built once per machine (zklc_amd/plonky2/circuit_cache.py): the pipeline tests load the Ed25519 circuit the session's
+# ApprovalProver built; ZKLC_CIRCUIT_CACHE= (empty) disables
+os.environ.setdefault("ZKLC_CIRCUIT_CACHE", os.path.join(ROOT, ".circuit_cache"))
 
 
 def pytest_configure(config):

@@ -31,6 +31,8 @@ def test_epoch_blocks_proof_on_the_gpu(zctx, block_prover):
                                   ep3_last_block_bytes=hx(w["ep3_last_block"]["bytes"]), ep3_last_block_hash=hx(w["ep3_last_block"]["hash"]),
                                   validators_n_1=[hx(v) for v in w["validators_n_1"]])
     print("epoch blocks: %.1f s (circuits of the shapes not seen earlier in the session are built in Python); counts %s" % (time.time() - t0, bp.counts))
+    import conftest
+    conftest.STASH["epoch_CRTZ"] = (b0, bn_1)
     for proof in (b0, bn_1):
         V.verify(json.loads(json.dumps(proof[2])), proof[1], proof[0])
     assert b0[2]["public_inputs"] == [1] + list(hx(w["blocks"][4]["hash"])) + list(hx(w["ep2_last_block"]["hash"])) + \

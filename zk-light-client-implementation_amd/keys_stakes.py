@@ -88,9 +88,13 @@ class KeysStakesProver:
         rc, proof = self.recursion.recursive_proof(ks, (hc, hv, hp), ks[2]["public_inputs"])
         return rc.common, rc.verifier_only, proof
 
-    def close(self):
+    def close_circuits(self):
+        """the keys / stakes circuits resident on the GPU (not the SHA-256 / recursion provers, which may be shared)"""
         for e in self._cache:
             e[4].close()
         self._cache = []
+
+    def close(self):
+        self.close_circuits()
         self.sha.close()
         self.recursion.close()

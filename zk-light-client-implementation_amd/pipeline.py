@@ -1,0 +1,510 @@
+"""`prove_block_bft` as a pipeline on one MI355X (and, in the strong form, over the GPUs of a node).
+
+Reference: near_bft_finality/src/prove_bft/bft.rs:38-500 (`prove_block_bft`), prove_block_data/signatures.rs:43-141
+(`prove_approvals`; :144-274 is its NATS fan-out, which this replaces on a node), bin/prove_block.rs:279-287 (the BN128 wrap).
+`prove_bft.BlockProver` is the reference's sequential driver restated; this module runs the SAME nodes of the SAME DAG -- the
+proofs are byte-identical to the sequential driver's (tests/test_gpu_pipeline.py) -- on concurrent host threads, each with its own
+zklc context (= HIP stream), so that the GPU always has several proofs in flight:
+
+  signature stage (per approval set)
+    a3  one batched Ed25519 pre-verification launch (signatures.rs:79)
+    a5  witness producer: the generator program of the Ed25519 circuit on the GPU for a batch of signatures
+        (csrc/plonky2_witness_dev.hip), wire matrices written in HBM, double-buffered (`host_witness=True`: host interpreter
+        threads + pinned buffers)
+    a6  `prove_streams - 1` Ed25519 provers, each with a resident copy of the circuit on its own stream
+  fold / DAG stage
+    a7  fold thread: agg = recursive_proof(agg, sig_i) as soon as signature proof i exists (signatures.rs:97-105), then the
+        closing proof with sha256(valid_keys) (:125-139); high-priority stream
+    8f  keys / stakes thread (needs only valid_keys, known after the pre-check) and the DAG thread (`BlockProver` over a stub
+        `prove_approvals` that waits for the fold thread: header-hash chains, bp_hash, heights, equalities, the joining recursions,
+        the Poseidon-BN128 wrap)
+  consecutive blocks (`prove_stream`): the signature stage of block b + 1 starts when the last signature proof of block b is out;
+  the tail of block b (last fold steps, closing proof, joins, wrap) completes beside it.
+
+Strong form (`strong=True`, world > 1): contiguous shards of every approval set's signature proofs, local left folds, a
+binary-tree fold of the partial aggregates over the ranks (distributed.tree_fold), header proofs and keys / stakes on the other
+ranks, joins and wrap on rank 0.  No data-path collective in the weak form (every rank its own blocks).
+"""
+import hashlib
+import queue
+import threading
+import time
+from concurrent.futures import Future
+
+import numpy as np
+
+from . import distributed as DIST
+from . import signatures as SG
+
+
+class BlockWindow:
+    """The arguments of `prove_block_bft` (bft.rs:38-62): two or three epoch-boundary blocks as (borsh bytes, hash), the window
+    [(fields, borsh bytes)] in the reference's order ([Block_i+4 .. Block_i] or [Block_4 .. Block_0, Block_n-1]) and the
+    validator lists as borsh ValidatorStake bytes."""
+
+    def __init__(self, ep2_last_block, ep1_first_block, blocks, validators, ep3_last_block=None, validators_n_1=None):
+        self.ep2_last_block, self.ep1_first_block, self.ep3_last_block = ep2_last_block, ep1_first_block, ep3_last_block
+        self.blocks, self.validators, self.validators_n_1 = list(blocks), list(validators), validators_n_1
+        if len(self.blocks) not in (5, 6):
+            raise ValueError("Invalid blocks.len() %d" % len(self.blocks))
+
+    @classmethod
+    def from_fixture(cls, win):
+        """tests/golden/block_window_*.json (made by tests/golden/make_block_window_fixture.py from the reference's data/)"""
+        hx = bytes.fromhex
+        blocks = []
+        for blk in win["blocks"]:
+            f = {k: hx(blk[k]) for k in ("hash", "prev_hash", "epoch_id", "last_ds_final_hash", "last_final_hash")}
+            f["height"] = blk["height"]
+            f["approvals"] = [hx(a) for a in blk["approvals"]]
+            blocks.append((f, hx(blk["bytes"])))
+        pair = lambda k: (hx(win[k]["bytes"]), hx(win[k]["hash"])) if win.get(k) else None
+        vn1 = [hx(v) for v in win["validators_n_1"]] if win.get("validators_n_1") else None
+        return cls(pair("ep2_last_block"), pair("ep1_first_block"), blocks, [hx(v) for v in win["validators"]],
+                   pair("ep3_last_block"), vn1)
+
+    def bft_args(self):
+        a = (self.ep2_last_block[0], self.ep2_last_block[1], self.ep1_first_block[0], self.ep1_first_block[1], self.blocks)
+        kw = {}
+        if self.ep3_last_block is not None:
+            kw = {"ep3_last_block_bytes": self.ep3_last_block[0], "ep3_last_block_hash": self.ep3_last_block[1],
+                  "validators_n_1": self.validators_n_1}
+        return a, kw
+
+    def approval_sets(self):
+        """[(msg, approvals, validators)] in the order prove_block_bft reaches them (bft.rs:264-316: the finality proof of Block_i /
+        Block_0 signed by the approvals in Block_i+1's successor header; :317-500: the one of Block_n-1)"""
+        b = self.blocks
+        sets = [(SG.generate_signed_message(b[4][0]["height"], b[3][0]["height"], b[3][0]["prev_hash"]), b[3][0]["approvals"],
+                 self.validators)]
+        if len(b) == 6:
+            sets.append((SG.generate_signed_message(b[5][0]["height"], b[4][0]["height"], b[4][0]["prev_hash"]), b[4][0]["approvals"],
+                         self.validators_n_1))
+        return sets
+
+    def expected_public_inputs(self):
+        """public inputs of the final proof(s): [flag, hash(block), hash(ancestor), hash(ancestor)] (bft.rs:470-500)"""
+        b = self.blocks
+        if len(b) == 5:
+            return [[0] + list(b[4][0]["hash"]) + list(self.ep2_last_block[1]) + list(self.ep1_first_block[1])]
+        return [[1] + list(b[4][0]["hash"]) + list(self.ep2_last_block[1]) + list(self.ep1_first_block[1]),
+                [1] + list(b[5][0]["hash"]) + list(self.ep3_last_block[1]) + list(self.ep2_last_block[1])]
+
+
+class _EdCircuit:
+    """the reference's per-signature circuit for one message length (prove_crypto/ed25519.rs:18-42), resident once per prover stream,
+    with its device witness interpreter and the double-buffered wire matrices"""
+    pass
+
+
+class _ApprovalStub:
+    """what the DAG thread's BlockProver calls for `prove_approvals` / keys-stakes: the results of the pipeline's other threads"""
+
+    def __init__(self, recursion):
+        self.recursion = recursion
+        self.sets = {}                   # message bytes -> _SetState of the block in its fold / DAG stage
+
+    def keys_stakes_early(self, msg, approvals, validators):
+        return self.sets[bytes(msg)].ks_future.result()
+
+    def prove_approvals(self, msg, approvals, validators):
+        from .plonky2 import HASH_GL
+        from .plonky2 import serialization as S
+        rc, raw, valid_keys = self.sets[bytes(msg)].future.result()
+        return (rc, S.proof_from_bytes(raw, rc.common, HASH_GL)), valid_keys
+
+    def close(self):
+        self.recursion.close()
+
+
+class _SetState:
+    """one approval set of one block: filled by the signature stage, consumed by the fold thread"""
+
+    def __init__(self, msg, approvals, validators):
+        self.msg, self.approvals, self.validators = bytes(msg), approvals, validators
+        self.future, self.ks_future = Future(), Future()
+        self.local_agg = None
+
+
+class BlockResult:
+    """block / block_n_1: (common, verifier_only, proof json) triples of prove_block_bft; wrap / wrap_n_1: (RecursiveCircuit, proof
+    bytes) of the BN128 wrap when asked for; timings in seconds"""
+
+    def __init__(self):
+        self.block = self.block_n_1 = self.wrap = self.wrap_n_1 = None
+        self.t0 = self.t_signatures = self.t_done = None
+        self.t_verify = self.witness_s = self.keys_stakes_s = 0.0
+        self.fold_host_ms = {"inputs": 0.0, "witness": 0.0, "prove": 0.0}
+        self.dag_seconds, self.dag_counts = {}, {}
+        self.aggregates = []             # (RecursiveCircuit, raw closing proof, valid_keys) per approval set
+
+
+class BlockPipeline:
+    def __init__(self, device_id=0, prove_streams=4, witness_batch=32, host_witness=False, rank=0, world=1, comm_device=None,
+                 host_threads=None, wrap=True):
+        """One per process (= per GPU rank).  prove_streams: proofs in flight (prove_streams - 1 Ed25519 provers + the fold
+        stream); witness_batch: signatures per device witness batch (<= 64; 0.49 GB of HBM each, two buffers per message length).
+        rank / world / comm_device: the torch.distributed position for the strong form (collectives on `comm_device`)."""
+        import zklc_amd
+        from .keys_stakes import KeysStakesProver
+        from .plonky2 import HASH_BN128, HASH_GL
+        from .plonky2.recursion import RecursionProver
+        from .prove_bft import BlockProver
+        self.device_id, self.rank, self.world, self.comm_device = device_id, rank, world, comm_device
+        self.nthreads = max(2, int(prove_streams))
+        self.dev_wit = not host_witness
+        self.wrap = wrap
+        self.nbuf = 2
+        if self.dev_wit:
+            self.wchunk = max(1, min(64, int(witness_batch)))
+        else:
+            import os
+            cores = host_threads or len(os.sched_getaffinity(0))
+            self.wchunk = max(1, min(12 if world == 1 else 6, cores // max(1, world) - self.nthreads))
+        self.ctx = zklc_amd.Context(device_id)                       # pre-check + the first Ed25519 prover
+        self.ed_ctxs = [self.ctx] + [zklc_amd.Context(device_id) for _ in range(self.nthreads - 2)]
+        self.wit_ctx = zklc_amd.Context(device_id) if self.dev_wit else None
+        self.fold_ctx = zklc_amd.Context(device_id, high_priority=True)
+        self.ks_ctx = zklc_amd.Context(device_id)
+        self.dag_ctx = zklc_amd.Context(device_id, high_priority=True)
+        self.rp = RecursionProver(self.fold_ctx, HASH_GL)
+        self.ks_prover = KeysStakesProver(self.ks_ctx)
+        self.stub = _ApprovalStub(RecursionProver(self.dag_ctx, HASH_GL))
+        self.bprover = BlockProver(self.dag_ctx, self.stub)
+        self.rpw = RecursionProver(self.dag_ctx, HASH_BN128) if wrap else None
+        self._ed = {}
+        self._lock = threading.Lock()
+        self.last = None
+
+    # ------------------------------------------------------------------------------------------------ circuits
+    def ed_circuit(self, msg_len):
+        """build (or load from the circuit cache) the Ed25519 circuit of this message length and make it resident on every prover
+        stream; two device wire-matrix buffers PER CIRCUIT (the device interpreter writes only the cells its program has slots for
+        and relies on the rest staying zero, so two circuits never share a buffer)"""
+        ent = self._ed.get(msg_len)
+        if ent is not None:
+            return ent
+        import torch
+        from .plonky2 import CircuitBuilder, HASH_GL, wide_ecc_config
+        from .plonky2 import ed25519_circuit as E
+        from .plonky2.circuit_cache import load_or_build
+
+        def build():
+            b = CircuitBuilder(wide_ecc_config())
+            targets = E.ed25519_circuit(b, 8 * msg_len)
+            data = b.build()
+            data.witness_program(list(targets["msg"]) + list(targets["sig"]) + list(targets["pk"]))
+            return data, targets
+        ent = _EdCircuit()
+        ent.data, ent.targets, _ = load_or_build("ed25519", (msg_len, sorted(wide_ecc_config().items(), key=str)), build)
+        ent.provers = [ent.data.prover(c, HASH_GL) for c in self.ed_ctxs]
+        ent.common, ent.vd = ent.data.common_data(), ent.provers[0].verifier_data()
+        nw, n_rows = ent.data.config["num_wires"], ent.data.n
+        ent.free_slots = queue.Queue()
+        for sl in range(self.nbuf):
+            ent.free_slots.put(sl)
+        ent.slot_left = [0] * self.nbuf
+        if self.dev_wit:
+            ent.dwit = ent.data.device_witness(self.wit_ctx)
+            ent.d_bufs = [torch.zeros((self.wchunk, nw, n_rows), dtype=torch.int64, device="cuda:%d" % self.device_id)
+                          for _ in range(self.nbuf)]
+            torch.cuda.synchronize(self.device_id)       # the fill ran on torch's stream, the kernels run on the contexts'
+        else:
+            ent.pinned = [torch.zeros((self.wchunk, nw, n_rows), dtype=torch.int64).pin_memory() for _ in range(self.nbuf)]
+            ent.views = [p.numpy().view(np.uint64) for p in ent.pinned]
+        self._ed[msg_len] = ent
+        return ent
+
+    # ------------------------------------------------------------------------------------------------ one block's state
+    def _new_state(self, sets, strong):
+        st = {"sets": [_SetState(*s) for s in sets], "errors": [], "ready": queue.Queue(), "res": BlockResult(), "strong": strong,
+              "hdr_future": Future()}
+        return st
+
+    def _fail(self, st, e):
+        st["errors"].append(e)
+        for s in st["sets"]:
+            for fut in (s.future, s.ks_future):
+                if not fut.done():
+                    fut.set_exception(e)
+            for ev in getattr(s, "ed_done", []):
+                ev.set()
+        if not st["hdr_future"].done():
+            st["hdr_future"].set_exception(e)
+        for _ in range(self.nthreads):
+            st["ready"].put(None)
+
+    def _precheck(self, st):
+        """a3 for every approval set of the block + the witness inputs of the signatures this rank proves"""
+        from .plonky2 import ed25519_circuit as E
+        t0 = time.perf_counter()
+        for s in st["sets"]:
+            s.valid_keys, valid_pos, _, _ = SG.verify_approvals(self.ctx, s.msg, s.approvals, s.validators)   # raises InvalidSignature
+            if not valid_pos:
+                raise ValueError("no approvals present")
+            _, pks, sigs = SG.slice_approvals(s.approvals, s.validators)
+            s.n_sig = len(valid_pos)
+            lo, hi = DIST.shard_range(s.n_sig, self.rank, self.world) if st["strong"] else (0, s.n_sig)
+            s.my_sigs = list(range(lo, hi))
+            s.ed = self.ed_circuit(len(s.msg))
+            s.fills = {i: E.fill_ecdsa_targets(s.ed.targets, s.msg, sigs[i].tobytes(), pks[i].tobytes()) for i in s.my_sigs}
+            if s.fills and s.ed.data._program is None:
+                s.ed.data.witness_program(next(iter(s.fills.values())))
+            s.ed_done = [threading.Event() for _ in range(s.n_sig)]
+            s.ed_proofs = [None] * s.n_sig
+        st["res"].t_verify = time.perf_counter() - t0
+
+    # ------------------------------------------------------------------------------------------------ worker threads
+    def _witness_producer(self, st):
+        try:
+            first = True
+            for s in st["sets"]:
+                ent, n_mine = s.ed, len(s.my_sigs)
+                # a small first chunk (one signature per prover stream) so that proving starts after one witness time
+                bounds = [0, min(n_mine, max(1, self.nthreads - 1))] if first else [0]
+                first = False
+                while bounds[-1] < n_mine:
+                    bounds.append(min(n_mine, bounds[-1] + self.wchunk))
+                for c0, c1 in zip(bounds, bounds[1:]):
+                    idx = s.my_sigs[c0:c1]
+                    if not idx:
+                        continue
+                    sl = ent.free_slots.get()
+                    if st["errors"]:
+                        ent.free_slots.put(sl)
+                        return
+                    t_ = time.perf_counter()
+                    fills = [s.fills[i] for i in idx]
+                    if self.dev_wit:
+                        pis = ent.dwit.run(ent.d_bufs[sl].data_ptr(), fills, stream=self.wit_ctx.stream_ptr())
+                    else:
+                        _, pis = ent.data.generate_witness_native(fills, out=ent.views[sl][:len(idx)], threads=len(idx))
+                    st["res"].witness_s += time.perf_counter() - t_
+                    with self._lock:
+                        ent.slot_left[sl] = len(idx)
+                    for k, i in enumerate(idx):
+                        st["ready"].put((s, i, sl, k, [int(x) for x in pis[k]]))
+            for _ in range(self.nthreads):
+                st["ready"].put(None)
+        except Exception as e:
+            self._fail(st, e)
+
+    def _ed_worker(self, st, w):
+        try:
+            while True:
+                item = st["ready"].get()
+                if item is None:
+                    return
+                s, i, sl, k, pis = item
+                ent = s.ed
+                if self.dev_wit:
+                    s.ed_proofs[i] = ent.provers[w].prove_dev(ent.d_bufs[sl][k].data_ptr(), pis, stream=self.ed_ctxs[w].stream_ptr())
+                else:
+                    s.ed_proofs[i] = ent.provers[w].prove_host_ptr(ent.views[sl][k].ctypes.data, pis)
+                s.ed_done[i].set()
+                with self._lock:
+                    ent.slot_left[sl] -= 1
+                    if ent.slot_left[sl] == 0:
+                        ent.free_slots.put(sl)
+        except Exception as e:
+            self._fail(st, e)
+
+    def _fold_worker(self, st):
+        try:
+            res = st["res"]
+            for s in st["sets"]:
+                agg = None
+                for i in s.my_sigs:
+                    s.ed_done[i].wait()
+                    if st["errors"]:
+                        return
+                    nxt = (s.ed.common, s.ed.vd, s.ed_proofs[i])
+                    if agg is None:
+                        agg = nxt
+                        continue
+                    rc, proof = self.rp.recursive_proof(agg, nxt, raw=True)
+                    for k in res.fold_host_ms:
+                        res.fold_host_ms[k] += self.rp.last_host_ms[k]
+                    agg = (rc.common, rc.verifier_only, proof)
+                if st["strong"]:
+                    s.local_agg = agg            # a (common, verifier_only, proof bytes) triple, or None without signatures
+                    continue
+                self._close_set(st, s, agg)
+        except Exception as e:
+            self._fail(st, e)
+
+    def _close_set(self, st, s, agg):
+        """signatures.rs:125-139: the closing proof carries sha256(valid_keys) as 32 public inputs"""
+        rc, proof = self.rp.recursive_proof(agg, None, list(hashlib.sha256(s.valid_keys).digest()), raw=True)
+        st["res"].t_signatures = time.perf_counter()
+        st["res"].aggregates.append((rc, proof, s.valid_keys))
+        s.future.set_result((rc, proof, s.valid_keys))
+
+    def _ks_worker(self, st):
+        try:
+            t_ = time.perf_counter()
+            for s in st["sets"]:
+                s.ks_future.set_result(self.ks_prover.prove_valid_keys_stakes_in_validators_list(
+                    s.valid_keys, hashlib.sha256(s.valid_keys).digest(), s.validators))
+            st["res"].keys_stakes_s = time.perf_counter() - t_
+        except Exception as e:
+            self._fail(st, e)
+
+    def _header_worker(self, st, jobs, owner):
+        try:
+            st["headers"] = {name: self.bprover.prove_header_job(jobs[name]) for name in jobs if owner[name] == self.rank}
+        except Exception as e:
+            self._fail(st, e)
+
+    def _dag_worker(self, st, window, owner):
+        try:
+            res = st["res"]
+            remote = None
+            if st["strong"]:      # the header proofs of the other ranks arrive through hdr_future; rank 0's own are made here
+                remote = lambda name: None if owner[name] == 0 else st["hdr_future"].result()[name]
+            a, kw = window.bft_args()
+            res.block, res.block_n_1 = self.bprover.prove_block_bft(*a, window.validators, header_proofs=remote, **kw)
+            if self.rpw is not None:
+                # bin/prove_block.rs:279-287: recursive_proof::<F, Cbn128, C, D>((..bi..), None, Some(&bi_proof.public_inputs))
+                res.wrap = self.rpw.recursive_proof(res.block, None, list(res.block[2]["public_inputs"]), raw=True)
+                if res.block_n_1 is not None:
+                    res.wrap_n_1 = self.rpw.recursive_proof(res.block_n_1, None, list(res.block_n_1[2]["public_inputs"]), raw=True)
+            res.dag_seconds, res.dag_counts = dict(self.bprover.seconds), dict(self.bprover.counts)
+            res.t_done = time.perf_counter()
+        except Exception as e:
+            self._fail(st, e)
+
+    # ------------------------------------------------------------------------------------------------ stages
+    def _start(self, fns):
+        ths = [threading.Thread(target=f, args=a) for f, a in fns]
+        for th in ths:
+            th.start()
+        return ths
+
+    def _start_signature_stage(self, st):
+        st["res"].t0 = time.perf_counter()
+        self._precheck(st)
+        return self._start([(self._witness_producer, (st,))] + [(self._ed_worker, (st, w)) for w in range(len(self.ed_ctxs))])
+
+    def _begin_dag_stage(self, st):
+        """the fold / DAG / keys-stakes stage of a block owns the stub's futures and the block prover's counters"""
+        self.stub.sets = {s.msg: s for s in st["sets"]}
+        self.bprover.counts, self.bprover.seconds = {}, {}
+
+    def _start_dag_stage(self, st, window):
+        self._begin_dag_stage(st)
+        return self._start([(self._fold_worker, (st,)), (self._dag_worker, (st, window, {})), (self._ks_worker, (st,))])
+
+    @staticmethod
+    def _join(ths):
+        for th in ths:
+            th.join()
+
+    @staticmethod
+    def _raise(st):
+        if st["errors"]:
+            raise st["errors"][0]
+
+    # ------------------------------------------------------------------------------------------------ public API
+    def prove_block_bft(self, window, strong=False):
+        """ONE block, every stage concurrently -> BlockResult (rank 0 in the strong form; the other ranks return None)."""
+        strong = bool(strong) and self.world > 1
+        st = self._new_state(window.approval_sets(), strong)
+        a, kw = window.bft_args()
+        jobs = self.bprover.header_jobs(*a, kw.get("ep3_last_block_bytes"), kw.get("ep3_last_block_hash"))
+        owner = DIST.assign_jobs(list(jobs), self.world) if strong else {}
+        ks_rank = self.world - 1 if strong else self.rank
+        self._begin_dag_stage(st)
+        sig = self._start_signature_stage(st) + self._start([(self._fold_worker, (st,))])
+        dag = self._start([(self._dag_worker, (st, window, owner))]) if (not strong or self.rank == 0) else []
+        side = self._start([(self._ks_worker, (st,))]) if self.rank == ks_rank else []
+        if strong and self.rank != 0:
+            side += self._start([(self._header_worker, (st, jobs, owner))])
+        if strong:
+            # (1) the header proofs and the keys / stakes proofs of the other ranks travel to rank 0 (point-to-point, ~150 KB each)
+            self._join(side)
+            ok = not st["errors"]
+            mine = {"headers": st.get("headers", {}),
+                    "ks": [s.ks_future.result() for s in st["sets"]] if (self.rank == ks_rank and ok) else None}
+            parts = DIST.gather_objects(mine if self.rank != 0 else None, 0, device=self.comm_device)
+            if self.rank == 0:
+                merged = {}
+                for part in parts[1:]:
+                    merged.update(part["headers"])
+                    if part["ks"] is not None and ks_rank != 0:
+                        for s, ks in zip(st["sets"], part["ks"]):
+                            s.ks_future.set_result(ks)
+                st["hdr_future"].set_result(merged)
+            # (2) local folds -> binary tree over the ranks -> closing proof on rank 0, per approval set
+            self._join(sig)
+            combine = lambda x, y: (lambda rc_p: (rc_p[0].common, rc_p[0].verifier_only, rc_p[1]))(self.rp.recursive_proof(x, y, raw=True))
+            for s in st["sets"]:
+                total = DIST.tree_fold(None if st["errors"] else s.local_agg, combine, device=self.comm_device)
+                if self.rank == 0 and not st["errors"]:
+                    self._close_set(st, s, total)
+            self._join(dag)
+        else:
+            self._join(sig + dag + side)
+        self._raise(st)
+        self.last = st["res"]
+        return st["res"] if (not strong or self.rank == 0) else None
+
+    def prove_stream(self, windows, on_block_done=None):
+        """Consecutive blocks as a two-stage pipeline (a light client proves a stream of blocks): the signature stage of block
+        b + 1 starts as soon as the last signature proof of block b is out, while the tail of block b -- its last fold steps, the
+        closing proof, the joining recursions and the BN128 wrap, ~0.4 s during which the GPU would otherwise sit nearly idle --
+        completes beside it.  The fold / DAG stages of consecutive blocks share their provers, so they run one after the other.
+        Returns the BlockResults in order; `on_block_done(result)` is called as each block completes."""
+        results, prev_dag, prev_st = [], [], None
+        for window in windows:
+            st = self._new_state(window.approval_sets(), False)
+            try:
+                sig = self._start_signature_stage(st)
+            except Exception:
+                self._join(prev_dag)
+                raise
+            self._join(prev_dag)                  # block b - 1 must be finished before block b's fold / DAG stage takes the provers
+            if prev_st is not None:
+                self._raise(prev_st)
+                results.append(prev_st["res"])
+                if on_block_done:
+                    on_block_done(prev_st["res"])
+            prev_dag, prev_st = self._start_dag_stage(st, window), st
+            self._join(sig)
+        self._join(prev_dag)
+        if prev_st is not None:
+            self._raise(prev_st)
+            results.append(prev_st["res"])
+            if on_block_done:
+                on_block_done(prev_st["res"])
+            self.last = prev_st["res"]
+        return results
+
+    def prove_approvals(self, msg, approvals, validators):
+        """`prove_approvals` (signatures.rs:43-141) alone through the pipeline's signature stage and fold thread:
+        -> ((RecursiveCircuit, closing proof bytes), valid_keys).  BASELINE configs[4] (a synthetic epoch of N validators) runs
+        through this: the keys / stakes circuit cannot express N > 255 positions, the signature aggregate can."""
+        st = self._new_state([(msg, approvals, validators)], False)
+        ths = self._start_signature_stage(st) + self._start([(self._fold_worker, (st,))])
+        self._join(ths)
+        self._raise(st)
+        rc, raw, valid_keys = st["sets"][0].future.result()
+        self.last = st["res"]
+        return (rc, raw), valid_keys
+
+    def close(self):
+        for ent in self._ed.values():
+            for pr in ent.provers:
+                pr.close()
+            if self.dev_wit:
+                ent.dwit.close()
+                ent.d_bufs = None
+        self._ed = {}
+        self.rp.close()
+        if self.rpw is not None:
+            self.rpw.close()
+        self.bprover.close()              # closes the stub's recursion prover, the SHA-256 and primitive provers of the DAG thread
+        self.ks_prover.close()
+        for c in self.ed_ctxs[1:] + [x for x in (self.wit_ctx, self.fold_ctx, self.ks_ctx, self.dag_ctx) if x is not None]:
+            c.close()
+        self.ctx.close()

@@ -29,9 +29,12 @@ def _sources_digest():
         pkg = os.path.dirname(here)
         files = sorted(os.path.join(here, f) for f in os.listdir(here) if f.endswith(".py"))
         files += sorted(os.path.join(pkg, f) for f in os.listdir(pkg) if f.endswith(".py"))
+        # the cached witness programs are interpreted by native code: a change of the opcode encoding must invalidate them too
+        files += [os.path.join(pkg, "csrc", f) for f in ("plonky2_witness_ops.h", "plonky2_witness.cpp", "plonky2_witness_dev.hip")]
         for f in files:
             h.update(os.path.basename(f).encode())
-            h.update(open(f, "rb").read())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
         _SOURCES_DIGEST = h.hexdigest()[:16]
     return _SOURCES_DIGEST
 
@@ -55,8 +58,10 @@ def load_or_build(name, key, build):
             with open(path, "rb") as f:
                 data, aux = pickle.load(f)
             return data, aux, True
-        except Exception:      # a truncated or foreign file: rebuild and replace it
-            pass
+        except Exception as e:      # a truncated or foreign file: rebuild and replace it -- and say so, once per entry
+            import sys
+            print("zklc circuit cache: entry %s discarded (%s: %s), rebuilding" % (os.path.basename(path), type(e).__name__, e),
+                  file=sys.stderr)
     data, aux = build()
     assert data._program is not None, "compile the witness program before caching a circuit"
     os.makedirs(d, exist_ok=True)

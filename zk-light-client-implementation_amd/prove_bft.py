@@ -25,6 +25,7 @@ class BlockProver:
         """parts = (approvals, hashes, keys, primitives) overrides the GPU provers (the CPU test of the DAG wiring passes
         stand-ins that check their inputs and return the public inputs a real proof would carry)"""
         self.counts, self.seconds = {}, {}
+        self.ctx, self._pipeline = ctx, None
         if parts is not None:
             self.approvals, self.hashes, self.keys, self.prims = parts
             self.recursion = self.approvals.recursion
@@ -181,11 +182,22 @@ class BlockProver:
 
     # ---- bft.rs:38-500
     def prove_block_bft(self, ep2_last_block_bytes, ep2_last_block_hash, ep1_first_block_bytes, ep1_first_block_hash, blocks,
-                        validators, ep3_last_block_bytes=None, ep3_last_block_hash=None, validators_n_1=None, header_proofs=None):
+                        validators, ep3_last_block_bytes=None, ep3_last_block_hash=None, validators_n_1=None, header_proofs=None,
+                        pipelined=False):
         """blocks: [(fields, header bytes)] in the order [Block_i+4, .., Block_i] (a randomly selected block) or
         [Block_4, .., Block_0, Block_n-1] (epoch blocks); fields = dict with hash, height, prev_hash, epoch_id,
         last_ds_final_hash, last_final_hash, approvals.  Returns (proof of Block_i / Block_0, proof of Block_n-1 or None).
-        header_proofs: {name: proof} or a callable name -> proof for header proofs made elsewhere (header_jobs)."""
+        header_proofs: {name: proof} or a callable name -> proof for header proofs made elsewhere (header_jobs).
+        pipelined=True: the same DAG through zklc_amd.pipeline.BlockPipeline (several proofs in flight on their own HIP streams,
+        witnesses on the GPU) -- byte-identical proofs, a fraction of the time; its contexts and circuits are created on first use."""
+        if pipelined:
+            from .pipeline import BlockPipeline, BlockWindow
+            if self._pipeline is None:
+                self._pipeline = BlockPipeline(self.ctx.device_id, wrap=False)
+            res = self._pipeline.prove_block_bft(BlockWindow(
+                (ep2_last_block_bytes, ep2_last_block_hash), (ep1_first_block_bytes, ep1_first_block_hash), blocks, validators,
+                (ep3_last_block_bytes, ep3_last_block_hash) if ep3_last_block_bytes is not None else None, validators_n_1))
+            return res.block, res.block_n_1
         jobs = self.header_jobs(ep2_last_block_bytes, ep2_last_block_hash, ep1_first_block_bytes, ep1_first_block_hash, blocks,
                                 ep3_last_block_bytes, ep3_last_block_hash)
 
@@ -234,7 +246,7 @@ class BlockProver:
         self.approvals.close()
         self.hashes.sha.close()
         self.prims.close()
-        for e in getattr(self.keys, "_cache", []):      # the keys / stakes circuits resident on the GPU (the sha / recursion provers
-            e[4].close()                                 # it shares with the others are closed above, once)
-        if hasattr(self.keys, "_cache"):
-            self.keys._cache = []
+        self.keys.close_circuits()       # the sha / recursion provers it shares with the others are closed above, once
+        if self._pipeline is not None:
+            self._pipeline.close()
+            self._pipeline = None
