@@ -131,6 +131,9 @@ def main():
     for e in bp.keys._cache:
         SHAPES.append(("keys / stakes circuit (%d validators, %d valid keys)" % (len(e[0][1]), len(e[0][0])), rows_used(e[1]),
                        e[1].degree_bits, len(e[1].gates), len(e[1].builder._const_targets), 0.0))
+    if "--dump-inner" in sys.argv:       # the Block_i circuit's common data: the input shape of the wrap circuit (tools/wrap_instance.py)
+        with open(sys.argv[sys.argv.index("--dump-inner") + 1], "w") as f:
+            json.dump(bi[0], f, separators=(",", ":"))
     wrap = R.RecursionProver(None, HASH_BN128)
     wrc, _ = wrap.recursive_proof(bi, None, list(bi[2]["public_inputs"]))
     print("%-52s %9s %7s %6s %7s %7s" % ("circuit (first occurrence in the DAG)", "rows", "degree", "gates", "consts", "build s"))

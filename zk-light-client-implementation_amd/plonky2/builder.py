@@ -710,7 +710,8 @@ class CircuitData:
             for k, c in enumerate(cs):
                 row_consts[k, r] = c
         routed = b.config["num_routed_wires"]
-        # sigma: every routed wire maps to the next wire of its copy class (cyclically; members ordered by (column, row))
+        # sigma: every routed wire maps to the next wire of its copy class, cyclically; members in (row, column) order -- the order in
+        # which plonky2's `wire_partition` (plonk/permutation_argument.rs) walks the wires: for row { for column }
         sig_col = np.tile(np.arange(routed, dtype=np.int64)[:, None], (1, n))
         sig_row = np.tile(np.arange(n, dtype=np.int64)[None, :], (routed, 1))
         pk = np.fromiter(b.parent.keys(), dtype=np.int64, count=len(b.parent))
@@ -722,7 +723,7 @@ class CircuitData:
         if len(wk):
             col, row = wk & 255, wk >> 8
             assert int(col.max()) < routed, "copy constraint on a non-routed wire"
-            o = np.lexsort((row, col, wr))
+            o = np.lexsort((col, row, wr))
             col, row, wr = col[o], row[o], wr[o]
             first = np.ones(len(wr), dtype=bool)
             first[1:] = wr[1:] != wr[:-1]
