@@ -301,6 +301,29 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
            "roofline": {"bound": "hbm", "achieved": 96.0 * n / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": 96.0 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                         "note": "algorithmic bytes = 96 B/element (64 B point + 32 B scalar); integer-VALU-bound"}}
+    # the other scalar distributions of SURVEY 8(d) C4 at the same size (a Groth16 witness is W-shaped: gnark-plonky2-verifier/cmd/
+    # web-api.go:77): (W) 50 % in {0, 1}, 30 % < 2^64, 20 % uniform; (A1) all scalars equal; (A2) all < 2^64.  Parity of these shapes
+    # against the oracle is tests/test_gpu_bn254.py (2^20); here the result must not depend on the order of the points
+    by_dist = {}
+    for name in ("W", "A1", "A2"):
+        s_ = sc_h.copy()
+        if name == "W":
+            kind = rng.random(n)
+            small = kind < 0.5
+            s_[small] = 0
+            s_[small, 0] = rng.integers(0, 2, size=int(small.sum()), dtype=np.uint64)
+            s_[(kind >= 0.5) & (kind < 0.8), 1:] = 0
+        elif name == "A1":
+            s_[:] = s_[0]
+        else:
+            s_[:, 1:] = 0
+        d_s2 = torch.from_numpy(s_.view(np.int64)).to(dev)
+        ms_d, wall_d = _time_stream(lambda: msm_step(d_pts, d_s2, n), stream, 3, barrier)
+        wall_d = reduce_max(wall_d)
+        by_dist[name] = {"ms": wall_d, "value": n * world / (wall_d * 1e-3) / 1e6, "unit": "Melem/s"}
+        del d_s2
+    msm["distributions"] = by_dist
+    msm_step()                                                    # d_out holds the uniform instance again (parity check below)
     pm = pmc_json("msm_pmc_latest.json")
     if pm is not None and pm.get("log_n") == args.msm_log:
         msm["roofline"]["traffic"] = pm.get("hbm_bytes_per_msm")
@@ -844,6 +867,8 @@ def compact_line(full):
                 e["valu_frac"] = r3(r["valu"]["frac"])
             if "cpu_baseline" in s_:
                 e["cpu"] = r3(s_["cpu_baseline"]["value"])
+            if "distributions" in s_:
+                e["dist_ms"] = {k: r3(v["ms"]) for k, v in s_["distributions"].items()}
             if "strong" in s_:
                 e["strong"] = {"value": r3(s_["strong"]["value"]), "ms": r3(s_["strong"]["ms"]), "equal": s_["strong"].get("equals_single_gpu_result")}
             cs[name] = e

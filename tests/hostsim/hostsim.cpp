@@ -221,13 +221,19 @@ static u32 hostsim_msm(const u64 *points, const u64 *scalars, u32 n, u32 mode, u
             }
         }
     std::vector<i32> buckets((size_t)pl.total_buckets * XY, 0);       // zeroed = infinity, as the product memsets it
-    if (mode == 0) {
+    if (mode != 1) {
         // the product path: converted points, slices of the sorted entries, combine
         const u32 E = run, slices = (u32)(((u64)n * pl.windows + MSM_SLICE - 1) / MSM_SLICE);
         std::vector<i32> cpoints((size_t)n * 2 * F::LIMBS), partials(((size_t)slices + 1) * 2 * XY, 0x5a5a5a5a);
-        for (u32 i = 0; i < n; i++) msm_convert_point<F>(cpoints.data() + (size_t)i * 2 * F::LIMBS, points, i);
-        for (u32 lane = 0; lane < slices; lane++)
-            msm_slice_lane<F>(cpoints.data(), entries.data(), offsets.data(), pl.total_buckets, E, lane, buckets.data(), partials.data());
+        if (mode == 0) {        // packed 8 x 32-bit records (the product default)
+            for (u32 i = 0; i < n; i++) msm_convert_point<F, true>(cpoints.data() + (size_t)i * msm_rec<F, true>::WORDS, points, i);
+            for (u32 lane = 0; lane < slices; lane++)
+                msm_slice_lane<F, true>(cpoints.data(), entries.data(), offsets.data(), pl.total_buckets, E, lane, buckets.data(), partials.data());
+        } else {                // mode 2: records of ten 32-bit limbs per coordinate (ZKLC_MSM_PACKED=0)
+            for (u32 i = 0; i < n; i++) msm_convert_point<F, false>(cpoints.data() + (size_t)i * 2 * F::LIMBS, points, i);
+            for (u32 lane = 0; lane < slices; lane++)
+                msm_slice_lane<F, false>(cpoints.data(), entries.data(), offsets.data(), pl.total_buckets, E, lane, buckets.data(), partials.data());
+        }
         for (u32 key = 0; key < pl.total_buckets; key++) {
             u32 la, lb, which;
             if (!msm_combine_span<F>(offsets.data(), totals.data(), key, la, lb, which)) continue;
@@ -265,7 +271,7 @@ static u32 hostsim_msm(const u64 *points, const u64 *scalars, u32 n, u32 mode, u
     for (u32 w = pl.windows; w-- > 0;) {
         ec_xyzz<F> win = ec_infinity<F>();
         for (u32 si = 0; si < seg_per_window; si++) win = ec_add(win, msm_segment_lane<F>(buckets.data(), pl, w, si));
-        if (F::LIMBS == 10 && mode == 0) {                            // as msm_final_kernel for G1: the doublings by a quad of lanes
+        if (mode != 1) {                                              // as msm_final_kernel (G1 and G2): the doublings by a quad of lanes
             ec_xyzz<F> q4[4] = {win, win, win, win};
             for (u32 k = 0; k < pl.c * w; k++) ec_double_quad_ref<F>(q4);
             win = q4[0];

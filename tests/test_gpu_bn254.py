@@ -69,6 +69,36 @@ def test_witness_like_distribution(zctx):
     assert ginf == winf and np.array_equal(got, want)
 
 
+def witness_like(rng, n):
+    """50 % in {0, 1}, 30 % < 2^64, 20 % uniform -- what a Groth16 witness vector looks like
+    (gnark-plonky2-verifier/cmd/web-api.go:77)"""
+    sc = rand_scalars(rng, n)
+    kind = rng.random(n)
+    small = kind < 0.5
+    sc[small] = 0
+    sc[small, 0] = rng.integers(0, 2, size=int(small.sum()), dtype=np.uint64)
+    mid = (kind >= 0.5) & (kind < 0.8)
+    sc[mid, 1:] = 0
+    return sc
+
+
+def test_witness_like_and_adversarial_scalars_at_2_pow_20(zctx):
+    """the distributions that matter at (nearly) the headline size, bit-exact against the oracle's C Pippenger: (W) witness-like --
+    a quarter of a million scalars equal to 1 land in ONE bucket, cut into ~2 000 slices and summed by the heavy-combine kernel;
+    (A1) all scalars equal -- every window has a single bucket holding all 2^20 points; (A2) top windows zero (scalars < 2^64)"""
+    n = 1 << 20
+    rng = np.random.default_rng(20)
+    pts = cport.bn254_gen_points(n, 11, 7)
+    cases = {"W": witness_like(rng, n),
+             "A1": np.tile(np.array(scalar_words(0x2F0E1D2C3B4A59687766554433221100FFEEDDCCBBAA99887766554433221100 % bn.R), dtype=np.uint64), (n, 1)),
+             "A2": rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64) * np.array([1, 0, 0, 0], dtype=np.uint64)}
+    for name, sc in cases.items():
+        sc = np.ascontiguousarray(sc)
+        got, ginf = zctx.bn254_g1_msm(pts, sc)
+        want, winf, _ = cport.bn254_msm(pts, sc, nthreads=16)
+        assert ginf == winf and np.array_equal(got, want), name
+
+
 def test_adversarial_equal_points_and_scalars(zctx):
     """(A): all points equal (every bucket addition after the first is a DOUBLING), all scalars equal,
     points at infinity in the input, and a cancelling pair."""

@@ -62,6 +62,9 @@ def test_msm_lane_walk_matches_oracle(hostsim, kind, n):
     # and so does the one-lane-per-bucket walk on the raw points
     got3, inf3 = _run(hostsim, pts, sc, mode=1, heavy_min=2, heavy_threads=3)
     assert inf3 == inf and np.array_equal(got3, got)
+    # and the slices over records of ten 32-bit limbs per coordinate (ZKLC_MSM_PACKED=0; mode 0 reads the packed 64-byte records)
+    got4, inf4 = _run(hostsim, pts, sc, mode=2)
+    assert inf4 == inf and np.array_equal(got4, got)
 
 
 def _reduced(sc):
@@ -125,3 +128,26 @@ def test_plan_and_digit_codes(hostsim):
                     neg = code > 0x8000
                     mag = 0x10000 - code if neg else code
                     assert (neg, mag) == (d < 0, abs(d))
+
+
+def test_g2_lane_walk_with_quad_doublings_matches_python(hostsim):
+    """G2 (coordinates in Fp2) through the same lane code, the final doublings by a quad of lanes (ecq_stage* over Fp2Field, as
+    msm_final_kernel runs them since round 4) -- against the oracle's Python G2 arithmetic; scalars with digits in every window"""
+    n = 12
+    rng = np.random.default_rng(2)
+    cur, step, pts, plist = B.g2_mul(31337, B.G2), B.g2_mul(99, B.G2), [], []
+    for _ in range(n):
+        pts.append(B.g2_to_words(cur))
+        plist.append(cur)
+        cur = B.g2_add(cur, step)
+    pts = np.array(pts, dtype=np.uint64)
+    vals = [(int(rng.integers(0, 2**63)) << 190 | int(rng.integers(0, 2**63)) << 100 | int(rng.integers(0, 2**63))) % R for _ in range(n - 2)] + [R - 1, 1]
+    sc = np.array([[(v >> (64 * k)) & (2**64 - 1) for k in range(4)] for v in vals], dtype=np.uint64)
+    out = (ctypes.c_uint32 * 32)()
+    outs = []
+    for mode in (0, 1, 2):       # 0: packed records + quad doublings (the product path); 2: unpacked records; 1: one lane per bucket, ec_double
+        inf = hostsim.hostsim_msm_g2(pts.ctypes.data_as(ctypes.c_void_p), sc.ctypes.data_as(ctypes.c_void_p), n, mode, 1 << 30, 4, out)
+        assert not inf
+        outs.append([out[2 * i] | (out[2 * i + 1] << 32) for i in range(16)])
+    want = B.g2_to_words(B.g2_msm(vals, plist))
+    assert outs[0] == outs[1] == outs[2] == [int(x) for x in want]

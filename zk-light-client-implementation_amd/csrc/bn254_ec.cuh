@@ -27,6 +27,10 @@ struct FpField {
     static ZKLC_M u32 is_zero(const T &a) { return fp_is_zero(a); }
     static ZKLC_M T from_gnark(const u32 *w) { return fp_from_gnark(w); }
     static ZKLC_M void to_gnark(u32 *w, const T &a) { fp_to_gnark(w, a); }
+    // packed record form: the canonical value in [0, p) (internal Montgomery domain) as 8 x 32 bits -- 32 bytes instead of 40
+    static constexpr int PACKW = 8;
+    static ZKLC_M void pack(u32 *w, const T &a) { fp_freeze_words(w, a); }
+    static ZKLC_M T unpack(const u32 *w) { return fp_from_words_raw(w); }
     static ZKLC_M void store(i32 *d, const T &a) {
 #pragma unroll
         for (int k = 0; k < 10; k++) d[k] = a.v[k];
@@ -55,6 +59,17 @@ struct Fp2Field {
     static ZKLC_M u32 is_zero(const T &a) { return fp2_is_zero(a); }
     static ZKLC_M T from_gnark(const u32 *w) { return fp2_from_gnark(w); }
     static ZKLC_M void to_gnark(u32 *w, const T &a) { fp2_to_gnark(w, a); }
+    static constexpr int PACKW = 16;
+    static ZKLC_M void pack(u32 *w, const T &a) {
+        fp_freeze_words(w, a.c0);
+        fp_freeze_words(w + 8, a.c1);
+    }
+    static ZKLC_M T unpack(const u32 *w) {
+        T a;
+        a.c0 = fp_from_words_raw(w);
+        a.c1 = fp_from_words_raw(w + 8);
+        return a;
+    }
     static ZKLC_M void store(i32 *d, const T &a) {
         FpField::store(d, a.c0);
         FpField::store(d + 10, a.c1);

@@ -173,21 +173,21 @@ __global__ void __launch_bounds__(256) msm_scan_add_kernel(u32 *out, const u32 *
 
 // ---- 3. bucket accumulation over SLICES of the sorted entries (bn254_msm_lane.cuh: msm_slice_lane), template over the coordinate
 // field F (FpField = G1, Fp2Field = G2); WAVES = the occupancy the register allocation is asked to keep
-template <class F>
+template <class F, bool PK>
 __global__ void __launch_bounds__(256) msm_convert_kernel(const u64 *__restrict__ points, u32 n, i32 *__restrict__ cpoints) {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) msm_convert_point<F>(cpoints + (size_t)i * 2 * F::LIMBS, points, i);
+    if (i < n) msm_convert_point<F, PK>(cpoints + (size_t)i * msm_rec<F, PK>::WORDS, points, i);
 }
 
 #define MSM_SLICE_BLOCK 256
-template <class F, int WAVES>
+template <class F, int WAVES, bool PK>
 __global__ void __launch_bounds__(MSM_SLICE_BLOCK, WAVES)
 msm_slice_kernel(const i32 *__restrict__ cpoints, const u32 *__restrict__ entries, const u32 *__restrict__ offsets,
                  const u32 *__restrict__ counts, msm_plan pl, i32 *__restrict__ buckets, i32 *__restrict__ partials) {
     u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
     u32 T = pl.total_buckets;
     u32 E = offsets[T - 1] + counts[T - 1];
-    msm_slice_lane<F>(cpoints, entries, offsets, T, E, lane, buckets, partials);
+    msm_slice_lane<F, PK>(cpoints, entries, offsets, T, E, lane, buckets, partials);
 }
 
 // one lane per bucket: the sum of the partials of a bucket cut by slice boundaries (usually two of them); buckets cut into more
@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(msm_cfg<F>::BLOCK) msm_window_kernel(const i32
     if (threadIdx.x == 0) msm_store_xyzz<F>(win_out + (size_t)w * XY, acc);
 }
 
-// quad broadcast of a base-field element (DPP quad_perm [SRC, SRC, SRC, SRC])
+// quad broadcast of a field element (DPP quad_perm [SRC, SRC, SRC, SRC] on every limb)
 template <int SRC>
 ZKLC_D fp msm_quad_bcast(const fp &v) {
     fp r;
@@ -279,40 +279,47 @@ ZKLC_D fp msm_quad_bcast(const fp &v) {
 #endif
     return r;
 }
+template <int SRC>
+ZKLC_D fp2 msm_quad_bcast(const fp2 &v) {
+    fp2 r;
+    r.c0 = msm_quad_bcast<SRC>(v.c0);
+    r.c1 = msm_quad_bcast<SRC>(v.c1);
+    return r;
+}
 // one doubling by the four lanes of a quad (bn254_msm_lane.cuh: ecq_stage*); every lane holds the point before and after
-ZKLC_D void msm_double_quad(ec_xyzz<FpField> &p, u32 role) {
-    fp r1 = ecq_stage1<FpField>(p, role);
-    fp V = msm_quad_bcast<0>(r1), XX = msm_quad_bcast<1>(r1);
-    fp r2 = ecq_stage2<FpField>(p, V, XX, role);
-    fp W = msm_quad_bcast<0>(r2), S = msm_quad_bcast<1>(r2), ZZ3 = msm_quad_bcast<2>(r2), MM = msm_quad_bcast<3>(r2);
-    fp M = fp_add(fp_dbl(XX), XX);
-    fp X3 = fp_sub(MM, fp_dbl(S));
-    fp r3 = ecq_stage3<FpField>(p, W, S, M, X3, role);
-    fp ZZZ3 = msm_quad_bcast<0>(r3), WY = msm_quad_bcast<1>(r3), MS = msm_quad_bcast<2>(r3);
+template <class F>
+ZKLC_D void msm_double_quad(ec_xyzz<F> &p, u32 role) {
+    typedef typename F::T T;
+    T r1 = ecq_stage1<F>(p, role);
+    T V = msm_quad_bcast<0>(r1), XX = msm_quad_bcast<1>(r1);
+    T r2 = ecq_stage2<F>(p, V, XX, role);
+    T W = msm_quad_bcast<0>(r2), S = msm_quad_bcast<1>(r2), ZZ3 = msm_quad_bcast<2>(r2), MM = msm_quad_bcast<3>(r2);
+    T M = F::add(F::dbl(XX), XX);
+    T X3 = F::sub(MM, F::dbl(S));
+    T r3 = ecq_stage3<F>(p, W, S, M, X3, role);
+    T ZZZ3 = msm_quad_bcast<0>(r3), WY = msm_quad_bcast<1>(r3), MS = msm_quad_bcast<2>(r3);
     p.X = X3;
-    p.Y = fp_sub(MS, WY);
+    p.Y = F::sub(MS, WY);
     p.ZZ = ZZ3;
     p.ZZZ = ZZZ3;
 }
 
-// result = sum_w 2^(c w) W_w ; affine output in gnark Montgomery words + infinity flag.  G1: a quad of lanes per window shares
-// every doubling (msm_double_quad); G2 (and more windows than quads): one lane per window.
+// result = sum_w 2^(c w) W_w ; affine output in gnark Montgomery words + infinity flag.  A quad of lanes per window shares every
+// doubling (msm_double_quad: three multiplication-times instead of nine on the 240-doubling serial tail).
 template <class F>
 __global__ void __launch_bounds__(msm_cfg<F>::BLOCK) msm_final_kernel(const i32 *__restrict__ win_out, msm_plan pl, u64 *__restrict__ out_affine, u32 *__restrict__ out_inf) {
     const int XY = msm_cfg<F>::XYZZ;
     __shared__ i32 lds[msm_cfg<F>::BLOCK * msm_cfg<F>::XYZZ];
     ec_xyzz<F> acc = ec_infinity<F>();
-    bool quads = false;
-    if constexpr (F::LIMBS == 10) {
-        quads = 4 * pl.windows <= (u32)msm_cfg<F>::BLOCK;
-        if (quads && threadIdx.x < 4 * pl.windows) {
-            u32 w = threadIdx.x >> 2, role = threadIdx.x & 3;
-            ec_xyzz<F> p = msm_load_xyzz<F>(win_out + (size_t)w * XY);
-            u32 dbl = pl.c * w;
+    // a quad of lanes per window shares every doubling (G1 and G2); with more windows than quads (tiny inputs) one lane per window
+    const bool quads = 4 * pl.windows <= (u32)msm_cfg<F>::BLOCK;
+    if (quads && threadIdx.x < 4 * pl.windows) {
+        u32 w = threadIdx.x >> 2, role = threadIdx.x & 3;
+        ec_xyzz<F> p = msm_load_xyzz<F>(win_out + (size_t)w * XY);
+        u32 dbl = pl.c * w;
 #pragma unroll 1
-            for (u32 k = 0; k < dbl; k++) msm_double_quad(p, role);
-            if (role == 0) acc = p;
-        }
+        for (u32 k = 0; k < dbl; k++) msm_double_quad<F>(p, role);
+        if (role == 0) acc = p;
     }
     if (!quads && threadIdx.x < pl.windows) {
         acc = msm_load_xyzz<F>(win_out + (size_t)threadIdx.x * XY);
@@ -419,15 +426,27 @@ static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points
     // the bucket array starts as infinity (all-zero limbs): empty buckets are never written
     ZKLC_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)pl.total_buckets * XB, st));
     if (pl.n) {
-        hipLaunchKernelGGL(msm_convert_kernel<F>, dim3((pl.n + 255) / 256), dim3(256), 0, st, d_points, pl.n, cpoints);
-        // A/B switch ZKLC_MSM_WAVES = 1..3: waves per SIMD the slice kernel's register allocation keeps (default per field)
+        // A/B switches: ZKLC_MSM_PACKED = 0 / 1 (point records of 10 x 32-bit limbs per coordinate / packed 8 x 32 bits, default packed),
+        // ZKLC_MSM_WAVES = 1..3: waves per SIMD the G1 slice kernel's register allocation keeps
+        const char *pkv = getenv("ZKLC_MSM_PACKED");
+        const bool packed = !(pkv && pkv[0] == '0');
+        if (packed)
+            hipLaunchKernelGGL((msm_convert_kernel<F, true>), dim3((pl.n + 255) / 256), dim3(256), 0, st, d_points, pl.n, cpoints);
+        else
+            hipLaunchKernelGGL((msm_convert_kernel<F, false>), dim3((pl.n + 255) / 256), dim3(256), 0, st, d_points, pl.n, cpoints);
         const char *v = getenv("ZKLC_MSM_WAVES");
         int waves = (v && v[0] >= '1' && v[0] <= '3') ? v[0] - '0' : MSM_SLICE_WAVES_G1;
         if (F::LIMBS != 10) waves = 1;       // the Fp2 kernel needs the whole register file
         dim3 g((slices + MSM_SLICE_BLOCK - 1) / MSM_SLICE_BLOCK), b(MSM_SLICE_BLOCK);
-#define MSM_SLICE_LAUNCH(W)                                                                                                   \
-    hipLaunchKernelGGL((msm_slice_kernel<F, W>), g, b, 0, st, (const i32 *)cpoints, (const u32 *)entries, (const u32 *)offsets, \
-                       (const u32 *)totals, pl, buckets, partials)
+#define MSM_SLICE_LAUNCH(W)                                                                                                          \
+    do {                                                                                                                             \
+        if (packed)                                                                                                                  \
+            hipLaunchKernelGGL((msm_slice_kernel<F, W, true>), g, b, 0, st, (const i32 *)cpoints, (const u32 *)entries,              \
+                               (const u32 *)offsets, (const u32 *)totals, pl, buckets, partials);                                   \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((msm_slice_kernel<F, W, false>), g, b, 0, st, (const i32 *)cpoints, (const u32 *)entries,             \
+                               (const u32 *)offsets, (const u32 *)totals, pl, buckets, partials);                                   \
+    } while (0)
         if constexpr (F::LIMBS != 10) {
             MSM_SLICE_LAUNCH(1);
         } else {

@@ -179,21 +179,33 @@ ZKLC_HD void msm_bucket_lane(ec_xyzz<F> &acc, const u64 *points, const u32 *entr
 #define MSM_SLICE 128u
 #define MSM_COMBINE_SERIAL 32u    // buckets cut into more slices than this are summed by a workgroup (heavy-combine kernel)
 
-template <class F>
+// PK = packed records (round 4): x then y as canonical values in 8 x 32 bits per Fp coordinate -- 64 bytes per G1 point (one
+// aligned half cache line per gather instead of an 80-byte record straddling two 128-byte lines), 128 per G2 point; unpacking is
+// ~60 shift / mask instructions per point against ~2 800 of the addition
+template <class F, bool PK>
+struct msm_rec {
+    static constexpr int WORDS = PK ? 2 * F::PACKW : 2 * F::LIMBS;     // 32-bit words per converted point
+};
+template <class F, bool PK>
 ZKLC_HD void msm_convert_point(i32 *dst, const u64 *points, u32 idx) {
     typename F::T x, y;
     msm_load_point<F>(points, idx, x, y);
-    F::store(dst, F::reduce(x));
-    F::store(dst + F::LIMBS, F::reduce(y));
+    if (PK) {
+        F::pack(reinterpret_cast<u32 *>(dst), F::reduce(x));
+        F::pack(reinterpret_cast<u32 *>(dst) + F::PACKW, F::reduce(y));
+    } else {
+        F::store(dst, F::reduce(x));
+        F::store(dst + F::LIMBS, F::reduce(y));
+    }
 }
 
 template <class F>
 struct msm_cpoint {
     i32 w[2 * F::LIMBS];
 };
-template <class F>
+template <class F, bool PK>
 ZKLC_HD void msm_fetch_cpoint(msm_cpoint<F> &r, const i32 *cpoints, u32 idx) {
-    const int W = 2 * F::LIMBS;
+    const int W = msm_rec<F, PK>::WORDS;
 #if defined(__HIPCC__)
     const int4 *p = reinterpret_cast<const int4 *>(cpoints + (size_t)idx * W);
 #pragma unroll
@@ -208,6 +220,16 @@ ZKLC_HD void msm_fetch_cpoint(msm_cpoint<F> &r, const i32 *cpoints, u32 idx) {
     for (int k = 0; k < W; k++) r.w[k] = cpoints[(size_t)idx * W + k];
 #endif
 }
+template <class F, bool PK>
+ZKLC_HD void msm_cpoint_xy(const msm_cpoint<F> &r, typename F::T &x, typename F::T &y) {
+    if (PK) {
+        x = F::unpack(reinterpret_cast<const u32 *>(r.w));
+        y = F::unpack(reinterpret_cast<const u32 *>(r.w) + F::PACKW);
+    } else {
+        x = F::load(r.w);
+        y = F::load(r.w + F::LIMBS);
+    }
+}
 
 template <class F>
 ZKLC_HD ec_xyzz<F> msm_select_xyzz(const ec_xyzz<F> &a, const ec_xyzz<F> &b, u32 take_b) {
@@ -220,7 +242,7 @@ ZKLC_HD ec_xyzz<F> msm_select_xyzz(const ec_xyzz<F> &a, const ec_xyzz<F> &b, u32
 }
 
 // offsets[0 .. T): exclusive scan of the bucket sizes; E = number of entries.  One call = one lane.
-template <class F>
+template <class F, bool PK>
 ZKLC_HD void msm_slice_lane(const i32 *cpoints, const u32 *entries, const u32 *offsets, u32 T, u32 E, u32 lane, i32 *buckets,
                             i32 *partials) {
     const int XY = msm_cfg<F>::XYZZ;
@@ -242,16 +264,17 @@ ZKLC_HD void msm_slice_lane(const i32 *cpoints, const u32 *entries, const u32 *o
     acc.X = acc.Y = acc.ZZ = acc.ZZZ = F::one();      // any finite value: discarded by the first (fresh) step
     u32 ent_cur = entries[lo];
     msm_cpoint<F> raw_cur;
-    msm_fetch_cpoint<F>(raw_cur, cpoints, ent_cur >> 1);
+    msm_fetch_cpoint<F, PK>(raw_cur, cpoints, ent_cur >> 1);
     u32 ent_next = lo + 1 < hi ? entries[lo + 1] : 0;
     for (u32 e = lo; e < hi; e++) {
         msm_cpoint<F> raw_next = raw_cur;
         u32 ent_next2 = 0;
         if (e + 1 < hi) {
-            msm_fetch_cpoint<F>(raw_next, cpoints, ent_next >> 1);
+            msm_fetch_cpoint<F, PK>(raw_next, cpoints, ent_next >> 1);
             if (e + 2 < hi) ent_next2 = entries[e + 2];
         }
-        typename F::T x = F::load(raw_cur.w), y = F::load(raw_cur.w + F::LIMBS);
+        typename F::T x, y;
+        msm_cpoint_xy<F, PK>(raw_cur, x, y);
         y = F::select(y, F::neg(y), ent_cur & 1);
         ec_xyzz<F> started;                            // the segment's first point as an accumulator
         started.X = x;

@@ -457,6 +457,229 @@ p2_quotient_addmany_multi_kernel(p2_quotient_args a, p2_gate_list list) {
         }
 }
 
+// ---- all U32AddMany variants over an LDS tile shared by the FOUR WAVES of a workgroup (round 4; the default for circuits with several
+// variants).  What the two forms above leave on the table: evaluated gate by gate, the range product x (x-1)(x-2)(x-3) of a limb column
+// is recomputed by every variant whose limb region holds it -- 900 products per LDE point for 180 distinct columns, ~45 k of the
+// kernel's ~68 k lane-instructions per point, and the wire matrix is fetched 3.2 times (profiles/r03q_pmc_*); the one-pass kernel
+// (p2_quotient_addmany_multi_kernel) computes each product once but needs eight static copies of the per-variant step in ONE wave
+// (80 KB of code, SALU-bound).  Here a workgroup owns 64 LDE points: the limb columns are walked from the top in phases of
+// P2_AMT_COLS; in a phase every wave loads and range-checks a quarter of the columns ONCE (twelve loads in flight, three asm batches)
+// and leaves (wire, product) in LDS; after the barrier every wave consumes the tile for ITS OWN two variants (p2_amt_plan: balanced
+// by operation count on the host) -- wave-uniform constraint indices, so the alpha powers stay scalar loads, two static copies of the
+// step, accumulators of two variants in registers.  Every column is read from HBM once (the routed wires once more), every product
+// computed once; 48 KB of LDS per workgroup = three workgroups per CU.  Same field values as the per-gate form (the sums commute).
+#define P2_AMT_COLS 48u
+#define P2_AMT_WAVES 4
+struct p2_amt_plan {
+    u32 slot[P2_AMT_WAVES][2];      // position in the gate list of the (up to) two variants of every wave; 0xFFFFFFFF = none
+    u32 lo, hi;                     // the union of the limb regions: columns [lo, hi)
+};
+// the part of variant (ops, l0)'s limb region inside the phase [base, top), columns descending; S = the wave's variant slot
+template <int S>
+__device__ __forceinline__ void p2_amt_consume(gl_acc3 (&acc)[2][P2_MAX_CH], u64 (&comb)[2], u32 ops, u32 l0, u32 base, u32 top,
+                                               const u64 *tw, const u64 *trp, u32 lane, const p2_quotient_args &a, u32 k0) {
+    const u32 r_end = l0 + 18 * ops;
+    const u32 c_hi = top < r_end ? top : r_end, c_lo = base > l0 ? base : l0;
+    auto emit = [&](u32 krel, u64 val) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < P2_MAX_CH; c++)
+            if (c < (int)a.nch) gl_acc3_mul(acc[S][c], val, (gl_ktab *)a.apow[c] + 6 * (size_t)(k0 + krel));
+    };
+    u32 c = c_hi;                                      // exclusive; nothing to do when the region misses the phase
+#pragma unroll 1
+    while (c > c_lo && c_hi > c_lo) {
+        const u32 rel = c - 1 - l0, i = rel / 18, l = rel - 18 * i;     // the top column of this run is limb l of operation i
+        u32 cnt = l + 1;                               // down to limb 0 of the operation, or to the bottom of the phase / region
+        if (cnt > c - c_lo) cnt = c - c_lo;
+        const u32 kb = 21 * i + 18 - l;                // constraint of limb l; limb l - q is constraint kb + q
+        u32 q = 0;
+#pragma unroll 1
+        for (; q + 4 <= cnt; q += 4) {
+            u64 w[4], rp[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 col = c - 1 - q - j - base;
+                w[j] = tw[(size_t)col * 64 + lane];
+                rp[j] = trp[(size_t)col * 64 + lane];
+            }
+#pragma unroll
+            for (int ch = 0; ch < P2_MAX_CH; ch++)
+                if (ch < (int)a.nch) {
+                    gl_ktab *t = (gl_ktab *)a.apow[ch] + 6 * (size_t)(k0 + kb + q);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) gl_acc3_mul(acc[S][ch], rp[j], t + 6 * j);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                comb[S] = p2_horner4(comb[S], w[j]);
+                const u32 lj = l - q - j;
+                if (lj == 16) {
+                    emit(21 * i + 20, gl_canonical(comb[S]));
+                    comb[S] = 0;
+                } else if (lj == 0) {
+                    emit(21 * i + 19, gl_canonical(comb[S]));
+                    comb[S] = 0;
+                }
+            }
+        }
+#pragma unroll 1
+        for (; q < cnt; q++) {
+            const u32 col = c - 1 - q - base, lj = l - q;
+            const u64 w = tw[(size_t)col * 64 + lane], rp = trp[(size_t)col * 64 + lane];
+            emit(kb + q, rp);
+            comb[S] = p2_horner4(comb[S], w);
+            if (lj == 16) {
+                emit(21 * i + 20, gl_canonical(comb[S]));
+                comb[S] = 0;
+            } else if (lj == 0) {
+                emit(21 * i + 19, gl_canonical(comb[S]));
+                comb[S] = 0;
+            }
+        }
+        c -= cnt;
+    }
+}
+__global__ void __launch_bounds__(64 * P2_AMT_WAVES) p2_quotient_addmany_tile_kernel(p2_quotient_args a, p2_gate_list list, p2_amt_plan plan) {
+    __shared__ u64 tw[P2_AMT_COLS * 64], trp[P2_AMT_COLS * 64];
+    const size_t N = (size_t)1 << a.lde_bits;
+    const u32 lane = threadIdx.x & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t p = (size_t)blockIdx.x * 64 + lane;
+    const u64 *W = a.wires + p;
+    const u32 k0 = a.nch + a.nch * (a.npp + 1);       // the gate constraints follow the Z1 and partial-product terms
+    gl_acc3 acc[2][P2_MAX_CH];
+    u64 comb[2] = {0, 0};
+    u32 OPS[2], L0[2], GI[2];                         // wave-uniform: this wave's variants
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+#pragma unroll
+        for (int c = 0; c < P2_MAX_CH; c++) acc[s][c].c0 = acc[s][c].c1 = acc[s][c].c2 = 0;
+        OPS[s] = L0[s] = 0;
+        GI[s] = 0xFFFFFFFFu;
+        const u32 pos = plan.slot[wave][s];
+        if (pos == 0xFFFFFFFFu) continue;
+        GI[s] = list.idx[pos];
+        const p2_gate g = a.gates[GI[s]];
+        const u32 na = g.p[0], ops = g.p[1], per = na + 3;
+        OPS[s] = ops;
+        L0[s] = per * ops;
+        // routed wires: the sum constraint and the -res / -carry halves of the two recombination constraints (linear: the limb
+        // halves are added when the tile is consumed)
+#pragma unroll 1
+        for (u32 i = 0; i < ops; i++) {
+            p2_vars pv;
+            pv.wires = a.wires;
+            pv.stride = N;
+            pv.p = p;
+            u64 rc[2];
+            p2_load<2>(pv, per * i + na + 1, rc);
+            const u64 sum = p2_sum_wires(pv, per * i, na + 1);          // the addends and the carry in
+            const u64 e0 = gl_sub(gl_add(gl_mul(rc[1], 1ULL << 32), rc[0]), sum), e1 = gl_neg(rc[0]), e2 = gl_neg(rc[1]);
+#pragma unroll
+            for (int c = 0; c < P2_MAX_CH; c++)
+                if (c < (int)a.nch) {
+                    gl_ktab *t = (gl_ktab *)a.apow[c] + 6 * (size_t)(k0 + 21 * i);
+                    if (s == 0) {
+                        gl_acc3_mul(acc[0][c], e0, t);
+                        gl_acc3_mul(acc[0][c], e1, t + 6 * 19);
+                        gl_acc3_mul(acc[0][c], e2, t + 6 * 20);
+                    } else {
+                        gl_acc3_mul(acc[1][c], e0, t);
+                        gl_acc3_mul(acc[1][c], e1, t + 6 * 19);
+                        gl_acc3_mul(acc[1][c], e2, t + 6 * 20);
+                    }
+                }
+        }
+    }
+    // ---- limb columns hi-1 .. lo in phases of P2_AMT_COLS
+    const u32 per_wave = P2_AMT_COLS / P2_AMT_WAVES;  // 12 = three asm batches of four range products
+#pragma unroll 1
+    for (u32 top = plan.hi; top > plan.lo;) {
+        const u32 base = top - plan.lo > P2_AMT_COLS ? top - P2_AMT_COLS : plan.lo;
+        {
+            u64 w[per_wave], rp[per_wave];
+            const u32 first = base + wave * per_wave;
+#pragma unroll
+            for (u32 j = 0; j < per_wave; j++) {
+                const u32 col = first + j < top ? first + j : top - 1;      // clamped: a duplicate of the last column, not stored
+                w[j] = W[(size_t)col * N];
+            }
+            p2_range_products4<per_wave>(w, rp);
+#pragma unroll
+            for (u32 j = 0; j < per_wave; j++)
+                if (first + j < top) {
+                    tw[(size_t)(first + j - base) * 64 + lane] = w[j];
+                    trp[(size_t)(first + j - base) * 64 + lane] = rp[j];
+                }
+        }
+        __syncthreads();
+        if (OPS[0]) p2_amt_consume<0>(acc, comb, OPS[0], L0[0], base, top, tw, trp, lane, a, k0);
+        if (OPS[1]) p2_amt_consume<1>(acc, comb, OPS[1], L0[1], base, top, tw, trp, lane, a, k0);
+        __syncthreads();
+        top = base;
+    }
+    // ---- filter_v * sum_v per wave, the waves' sums through LDS, one read-modify-write of the output per point
+    u64 sum[P2_MAX_CH];
+#pragma unroll
+    for (int c = 0; c < P2_MAX_CH; c++) sum[c] = 0;
+    p2_vars sv;
+    sv.consts = a.cs;
+    sv.stride = N;
+    sv.p = p;
+    sv.nsel = a.nsel;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        if (GI[s] == 0xFFFFFFFFu) continue;
+        const p2_gate g = a.gates[GI[s]];
+        const u64 f = p2_filter(GI[s], g.group_start, g.group_end, sv.sel(g.selector_index), a.nsel > 1);
+#pragma unroll
+        for (int c = 0; c < P2_MAX_CH; c++)
+            if (c < (int)a.nch) sum[c] = gl_add(sum[c], gl_mul(f, gl_acc3_reduce(acc[s][c])));
+    }
+    u64 *part = tw;                                   // [wave][challenge][lane]; the tile is free after the last barrier
+#pragma unroll
+    for (int c = 0; c < P2_MAX_CH; c++) part[((size_t)wave * P2_MAX_CH + c) * 64 + lane] = sum[c];
+    __syncthreads();
+    if (wave == 0) {
+        const u64 pi = __brevll((u64)p) >> (64 - a.lde_bits);
+        const u64 zi = a.zh_inv[(u32)pi & ((1u << a.rate_bits) - 1)];
+#pragma unroll
+        for (int c = 0; c < P2_MAX_CH; c++)
+            if (c < (int)a.nch) {
+                u64 t = sum[c];
+                for (u32 w = 1; w < P2_AMT_WAVES; w++) t = gl_add(t, part[((size_t)w * P2_MAX_CH + c) * 64 + lane]);
+                u64 *o = a.out + (size_t)c * N + p;
+                *o = gl_add(*o, gl_mul(t, zi));
+            }
+    }
+}
+// host: variants -> waves, heaviest first onto the least loaded wave with a free slot.  false = the list does not fit the kernel
+static bool p2_amt_make_plan(const p2_gate *gates, const p2_gate_list &list, p2_amt_plan &plan) {
+    if (list.n < 2 || list.n > 2 * P2_AMT_WAVES) return false;
+    u32 load[P2_AMT_WAVES] = {0, 0, 0, 0}, used[P2_AMT_WAVES] = {0, 0, 0, 0};
+    for (int w = 0; w < P2_AMT_WAVES; w++) plan.slot[w][0] = plan.slot[w][1] = 0xFFFFFFFFu;
+    plan.lo = 0xFFFFFFFFu;
+    plan.hi = 0;
+    bool taken[P2_GATE_LIST_MAX] = {};
+    for (u32 r = 0; r < list.n; r++) {
+        u32 best = 0xFFFFFFFFu;
+        for (u32 t = 0; t < list.n; t++)
+            if (!taken[t] && (best == 0xFFFFFFFFu || gates[list.idx[t]].p[1] > gates[list.idx[best]].p[1])) best = t;
+        taken[best] = true;
+        const p2_gate &g = gates[list.idx[best]];
+        const u32 ops = g.p[1], l0 = (g.p[0] + 3) * ops;
+        if (ops == 0 || 24 * ops >= 480) return false;      // accumulator head room (p2_consumer normalises every 480 products)
+        u32 w = 0xFFFFFFFFu;
+        for (u32 k = 0; k < P2_AMT_WAVES; k++)
+            if (used[k] < 2 && (w == 0xFFFFFFFFu || load[k] < load[w])) w = k;
+        plan.slot[w][used[w]++] = best;
+        load[w] += ops;
+        plan.lo = l0 < plan.lo ? l0 : plan.lo;
+        plan.hi = l0 + 18 * ops > plan.hi ? l0 + 18 * ops : plan.hi;
+    }
+    return plan.hi > plan.lo;
+}
+
 typedef void (*p2_gate_kernel_fn)(p2_quotient_args, p2_gate_list);
 static p2_gate_kernel_fn p2_gate_kernel_of(u32 type) {
     switch (type) {
@@ -1373,6 +1596,15 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
                 // A/B, opt-in: the one-pass evaluator of all U32AddMany variants measured the SAME 5.49 ms as the per-gate
                 // launches on the Ed25519 circuit (profiles/r03v_*): see the comment at the kernel
                 static const bool am_multi = getenv("ZKLC_P2_ADDMANY") && !strcmp(getenv("ZKLC_P2_ADDMANY"), "multi");
+                // A/B: ZKLC_P2_ADDMANY=pergate keeps one launch per variant list; the default for several variants is the LDS tile
+                static const bool am_pergate = getenv("ZKLC_P2_ADDMANY") && !strcmp(getenv("ZKLC_P2_ADDMANY"), "pergate");
+                if (c->gates[g].type == P2_U32_ADD_MANY && !am_multi && !am_pergate && N >= 64) {
+                    p2_amt_plan plan;
+                    if (p2_amt_make_plan(c->gates.data(), list, plan)) {
+                        hipLaunchKernelGGL(p2_quotient_addmany_tile_kernel, dim3(N / 64), dim3(64 * P2_AMT_WAVES), 0, st, a, list, plan);
+                        continue;
+                    }
+                }
                 if (am_multi && c->gates[g].type == P2_U32_ADD_MANY && list.n >= 2 && list.n <= P2_AM_MAX)
                     fn = p2_quotient_addmany_multi_kernel;
                 hipLaunchKernelGGL(fn, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, a, list);
