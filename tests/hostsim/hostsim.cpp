@@ -353,6 +353,77 @@ void hostsim_p2_eval_gate(u32 type, const u32 *params, const u64 *extra, const u
     (void)n_wires;
     (void)n_consts;
 }
+// the U32AddMany LDS-tile evaluator (p2_quotient_addmany_tile_kernel) walked for ONE LDE point: the four waves of the workgroup one
+// after the other per phase, the tile arrays with the kernel's [column][64 lanes] layout (lane 0 used).  variants: n x (num_addends,
+// num_ops); slots[4][2] = the host plan (position in the list or 0xFFFFFFFF).  out[v * nch + c] = sum_i alpha_c^i constraint_i of
+// variant v, comparable with hostsim_p2_eval_gate of that variant.
+void hostsim_p2_addmany_tile(const u32 *variants, u32 n, const u32 *slots, const u64 *wires, const u64 *alpha, u32 nch, u64 *out, u32 k0) {
+    static u32 tab[P2_MAX_CH][1024 * 6];
+    gl_ktab *apow[P2_MAX_CH];
+    for (int c = 0; c < P2_MAX_CH; c++) {
+        u64 a = c < (int)nch ? alpha[c] : 0, pw = 1;
+        for (int i = 0; i < 1024; i++) {
+            gl_limbs22(pw, &tab[c][6 * i]);
+            pw = gl_mul(pw, a);
+        }
+        apow[c] = tab[c];
+    }
+    const u32 COLS = 48, WAVES = 4, per_wave = COLS / WAVES;
+    u32 lo = 0xFFFFFFFFu, hi = 0;
+    for (u32 v = 0; v < n; v++) {
+        u32 na = variants[2 * v], ops = variants[2 * v + 1], l0 = (na + 3) * ops;
+        lo = l0 < lo ? l0 : lo;
+        hi = l0 + 18 * ops > hi ? l0 + 18 * ops : hi;
+    }
+    gl_acc3 acc[WAVES][2][P2_MAX_CH];
+    u64 comb[WAVES][2];
+    u32 OPS[WAVES][2], L0[WAVES][2];
+    p2_vars pv;
+    pv.wires = wires;
+    pv.stride = 1;
+    pv.p = 0;
+    for (u32 w = 0; w < WAVES; w++)
+        for (int s = 0; s < 2; s++) {
+            for (int c = 0; c < P2_MAX_CH; c++) acc[w][s][c].c0 = acc[w][s][c].c1 = acc[w][s][c].c2 = 0;
+            comb[w][s] = 0;
+            OPS[w][s] = L0[w][s] = 0;
+            u32 pos = slots[2 * w + s];
+            if (pos == 0xFFFFFFFFu) continue;
+            u32 na = variants[2 * pos], ops = variants[2 * pos + 1];
+            OPS[w][s] = ops;
+            L0[w][s] = (na + 3) * ops;
+            if (s == 0)
+                p2_amt_routed<0>(acc[w], pv, na, ops, apow, (int)nch, k0);
+            else
+                p2_amt_routed<1>(acc[w], pv, na, ops, apow, (int)nch, k0);
+        }
+    static u64 tw[48 * 64], trp[48 * 64];
+    for (u32 top = hi; top > lo;) {
+        const u32 base = top - lo > COLS ? top - COLS : lo;
+        for (u32 w = 0; w < WAVES; w++) {
+            u64 x[12], rp[12];
+            const u32 first = base + w * per_wave;
+            for (u32 j = 0; j < per_wave; j++) x[j] = wires[first + j < top ? first + j : top - 1];
+            p2_range_products4<12>(x, rp);
+            for (u32 j = 0; j < per_wave; j++)
+                if (first + j < top) {
+                    tw[(size_t)(first + j - base) * 64] = x[j];
+                    trp[(size_t)(first + j - base) * 64] = rp[j];
+                }
+        }
+        for (u32 w = 0; w < WAVES; w++) {
+            if (OPS[w][0]) p2_amt_consume<0>(acc[w], comb[w], OPS[w][0], L0[w][0], base, top, tw, trp, 0, apow, (int)nch, k0);
+            if (OPS[w][1]) p2_amt_consume<1>(acc[w], comb[w], OPS[w][1], L0[w][1], base, top, tw, trp, 0, apow, (int)nch, k0);
+        }
+        top = base;
+    }
+    for (u32 w = 0; w < WAVES; w++)
+        for (int s = 0; s < 2; s++) {
+            u32 pos = slots[2 * w + s];
+            if (pos == 0xFFFFFFFFu) continue;
+            for (u32 c = 0; c < nch; c++) out[pos * nch + c] = gl_acc3_reduce(acc[w][s][c]);
+        }
+}
 u64 hostsim_p2_filter(u32 row, u32 start, u32 end, u64 s, u32 many) { return p2_filter(row, start, end, s, many != 0); }
 void hostsim_gl2_op(int op, const u64 *a, const u64 *b, u64 e, u64 *out) {
     gl2 x = gl2_make(a[0], a[1]), y = gl2_make(b[0], b[1]), r;

@@ -94,3 +94,28 @@ def test_extension_field_ops(hostsim):
         e = rng.getrandbits(40)
         from oracle.plonky2_verifier import ext_pow
         assert call(5, a, a, e) == ext_pow(a, e)
+
+
+def test_addmany_tile_walk_matches_the_per_gate_evaluator(hostsim):
+    """the U32AddMany LDS-tile evaluator (csrc/plonky2_prover.hip: p2_quotient_addmany_tile_kernel; lane-level pieces p2_amt_routed /
+    p2_amt_consume in plonky2_gates.cuh) walked for one LDE point -- four waves, phases of 48 limb columns, the real Ed25519 circuit's
+    eight variants on the host plan's slots -- gives every variant the sum its own evaluator (p2_eval_u32_add_many) gives"""
+    variants = [(11, 5), (13, 5), (15, 4), (16, 4), (3, 9), (5, 9), (7, 8), (9, 6)]
+    slots = [4, 2, 5, 3, 6, 1, 7, 0]          # the plan printed by the GPU run: heaviest first onto the least loaded wave
+    rng = random.Random(7)
+    f = hostsim.hostsim_p2_addmany_tile
+    f.restype = None
+    f.argtypes = [ctypes.c_void_p, ctypes.c_uint32] + [ctypes.c_void_p] * 3 + [ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+    for trial, (vs, sl) in enumerate([(variants, slots), (variants[:3], [0, 0xFFFFFFFF, 1, 0xFFFFFFFF, 2] + [0xFFFFFFFF] * 3)]):
+        wires = [rng.randrange(P) for _ in range(234)]
+        alphas = [rng.randrange(P), rng.randrange(P)]
+        va = np.array([x for v in vs for x in v], dtype=np.uint32)
+        sa = np.array(sl, dtype=np.uint32)
+        wa, aa = np.array(wires, dtype=np.uint64), np.array(alphas, dtype=np.uint64)
+        out = np.zeros(2 * len(vs), dtype=np.uint64)
+        k0 = 22 * trial          # the kernels start the gate constraints at alpha^k0 (after the Z / partial-product terms)
+        f(va.ctypes.data, len(vs), sa.ctypes.data, wa.ctypes.data, aa.ctypes.data, 2, out.ctypes.data, k0)
+        for k, (na, ops) in enumerate(vs):
+            want = _call(hostsim, G.U32AddManyGate(na, ops), wires, [], [0] * 4, alphas)
+            want = [w * pow(a, k0, P) % P for w, a in zip(want, alphas)]
+            assert [int(x) % P for x in out[2 * k:2 * k + 2]] == want, (trial, k, na, ops)

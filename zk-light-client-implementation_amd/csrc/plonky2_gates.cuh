@@ -507,6 +507,100 @@ ZKLC_D void p2_eval_u32_add_many(const V &v, u32 num_addends, u32 num_ops, p2_co
     }
 }
 
+// ---- the lane-level pieces of the U32AddMany LDS-tile evaluator (plonky2_prover.hip: p2_quotient_addmany_tile_kernel), shared with
+// tests/hostsim.  S = the wave's variant slot (static: the accumulators stay in registers).
+// routed wires of one variant: the sum constraint and the -res / -carry halves of the two recombination constraints
+template <int S, class V>
+ZKLC_D void p2_amt_routed(gl_acc3 (&acc)[2][P2_MAX_CH], const V &pv, u32 na, u32 ops, gl_ktab *const (&apow)[P2_MAX_CH], int nch, u32 k0) {
+    const u32 per = na + 3;
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (u32 i = 0; i < ops; i++) {
+        u64 rc[2];
+        p2_load<2>(pv, per * i + na + 1, rc);
+        const u64 sum = p2_sum_wires(pv, per * i, na + 1);          // the addends and the carry in
+        const u64 e0 = gl_sub(gl_add(gl_mul(rc[1], 1ULL << 32), rc[0]), sum), e1 = gl_neg(rc[0]), e2 = gl_neg(rc[1]);
+#pragma unroll
+        for (int c = 0; c < P2_MAX_CH; c++)
+            if (c < nch) {
+                gl_ktab *t = apow[c] + 6 * (size_t)(k0 + 21 * i);
+                gl_acc3_mul(acc[S][c], e0, t);
+                gl_acc3_mul(acc[S][c], e1, t + 6 * 19);
+                gl_acc3_mul(acc[S][c], e2, t + 6 * 20);
+            }
+    }
+}
+// the part of variant (ops, l0)'s limb region inside the phase [base, top), columns descending; S = the wave's variant slot
+template <int S>
+ZKLC_D void p2_amt_consume(gl_acc3 (&acc)[2][P2_MAX_CH], u64 (&comb)[2], u32 ops, u32 l0, u32 base, u32 top, const u64 *tw,
+                           const u64 *trp, u32 lane, gl_ktab *const (&apow)[P2_MAX_CH], int nch, u32 k0) {
+    const u32 r_end = l0 + 18 * ops;
+    const u32 c_hi = top < r_end ? top : r_end, c_lo = base > l0 ? base : l0;
+    if (c_hi <= c_lo) return;                          // the region misses the phase
+    auto emit = [&](u32 krel, u64 val) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < P2_MAX_CH; c++)
+            if (c < nch) gl_acc3_mul(acc[S][c], val, apow[c] + 6 * (size_t)(k0 + krel));
+    };
+    // one Horner step of the limb recombination; after limb 16 (carry part complete) and limb 0 (result part complete) the sum is
+    // emitted at its constraint and restarted.  The running sum lives in a LOCAL for the whole call (written back once): as
+    // `comb[S] = 0` inside the conditional the restart after limb 0 was lost by the device compiler (round 4, found by dumping the
+    // emitted (constraint, value) pairs of one lane: every carry sum still held the previous operation's result sum).
+    u64 cb = comb[S];
+    auto horner = [&](u64 w, u32 i, u32 lj) __attribute__((always_inline)) {
+        cb = p2_horner4(cb, w);
+        const bool carry_done = lj == 16, res_done = lj == 0;
+        if (carry_done | res_done) {
+            emit(21 * i + (carry_done ? 20u : 19u), gl_canonical(cb));
+            cb = 0;
+        }
+    };
+    u32 c = c_hi;                                      // exclusive
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    while (c > c_lo) {
+        const u32 rel = c - 1 - l0, i = rel / 18, l = rel - 18 * i;     // the top column of this run is limb l of operation i
+        u32 cnt = l + 1;                               // down to limb 0 of the operation, or to the bottom of the phase / region
+        if (cnt > c - c_lo) cnt = c - c_lo;
+        const u32 kb = 21 * i + 18 - l;                // constraint of limb l; limb l - q is constraint kb + q
+        u32 q = 0;
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+        for (; q + 4 <= cnt; q += 4) {
+            u64 w[4], rp[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 col = c - 1 - q - j - base;
+                w[j] = tw[(size_t)col * 64 + lane];
+                rp[j] = trp[(size_t)col * 64 + lane];
+            }
+#pragma unroll
+            for (int ch = 0; ch < P2_MAX_CH; ch++)
+                if (ch < nch) {
+                    gl_ktab *t = apow[ch] + 6 * (size_t)(k0 + kb + q);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) gl_acc3_mul(acc[S][ch], rp[j], t + 6 * j);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; j++) horner(w[j], i, l - q - j);
+        }
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+        for (; q < cnt; q++) {
+            const u32 col = c - 1 - q - base;
+            const u64 w = tw[(size_t)col * 64 + lane], rp = trp[(size_t)col * 64 + lane];
+            emit(kb + q, rp);
+            horner(w, i, l - q);
+        }
+        c -= cnt;
+    }
+    comb[S] = cb;
+}
+
 // subtraction_u32.rs: per op (x, y, borrow_in, result, borrow_out), then 16 two-bit limbs of result
 template <class V>
 ZKLC_D void p2_eval_u32_subtraction(const V &v, u32 num_ops, p2_consumer &out) {

@@ -474,71 +474,6 @@ struct p2_amt_plan {
     u32 slot[P2_AMT_WAVES][2];      // position in the gate list of the (up to) two variants of every wave; 0xFFFFFFFF = none
     u32 lo, hi;                     // the union of the limb regions: columns [lo, hi)
 };
-// the part of variant (ops, l0)'s limb region inside the phase [base, top), columns descending; S = the wave's variant slot
-template <int S>
-__device__ __forceinline__ void p2_amt_consume(gl_acc3 (&acc)[2][P2_MAX_CH], u64 (&comb)[2], u32 ops, u32 l0, u32 base, u32 top,
-                                               const u64 *tw, const u64 *trp, u32 lane, const p2_quotient_args &a, u32 k0) {
-    const u32 r_end = l0 + 18 * ops;
-    const u32 c_hi = top < r_end ? top : r_end, c_lo = base > l0 ? base : l0;
-    auto emit = [&](u32 krel, u64 val) __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < P2_MAX_CH; c++)
-            if (c < (int)a.nch) gl_acc3_mul(acc[S][c], val, (gl_ktab *)a.apow[c] + 6 * (size_t)(k0 + krel));
-    };
-    u32 c = c_hi;                                      // exclusive; nothing to do when the region misses the phase
-#pragma unroll 1
-    while (c > c_lo && c_hi > c_lo) {
-        const u32 rel = c - 1 - l0, i = rel / 18, l = rel - 18 * i;     // the top column of this run is limb l of operation i
-        u32 cnt = l + 1;                               // down to limb 0 of the operation, or to the bottom of the phase / region
-        if (cnt > c - c_lo) cnt = c - c_lo;
-        const u32 kb = 21 * i + 18 - l;                // constraint of limb l; limb l - q is constraint kb + q
-        u32 q = 0;
-#pragma unroll 1
-        for (; q + 4 <= cnt; q += 4) {
-            u64 w[4], rp[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const u32 col = c - 1 - q - j - base;
-                w[j] = tw[(size_t)col * 64 + lane];
-                rp[j] = trp[(size_t)col * 64 + lane];
-            }
-#pragma unroll
-            for (int ch = 0; ch < P2_MAX_CH; ch++)
-                if (ch < (int)a.nch) {
-                    gl_ktab *t = (gl_ktab *)a.apow[ch] + 6 * (size_t)(k0 + kb + q);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) gl_acc3_mul(acc[S][ch], rp[j], t + 6 * j);
-                }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                comb[S] = p2_horner4(comb[S], w[j]);
-                const u32 lj = l - q - j;
-                if (lj == 16) {
-                    emit(21 * i + 20, gl_canonical(comb[S]));
-                    comb[S] = 0;
-                } else if (lj == 0) {
-                    emit(21 * i + 19, gl_canonical(comb[S]));
-                    comb[S] = 0;
-                }
-            }
-        }
-#pragma unroll 1
-        for (; q < cnt; q++) {
-            const u32 col = c - 1 - q - base, lj = l - q;
-            const u64 w = tw[(size_t)col * 64 + lane], rp = trp[(size_t)col * 64 + lane];
-            emit(kb + q, rp);
-            comb[S] = p2_horner4(comb[S], w);
-            if (lj == 16) {
-                emit(21 * i + 20, gl_canonical(comb[S]));
-                comb[S] = 0;
-            } else if (lj == 0) {
-                emit(21 * i + 19, gl_canonical(comb[S]));
-                comb[S] = 0;
-            }
-        }
-        c -= cnt;
-    }
-}
 __global__ void __launch_bounds__(64 * P2_AMT_WAVES) p2_quotient_addmany_tile_kernel(p2_quotient_args a, p2_gate_list list, p2_amt_plan plan) {
     __shared__ u64 tw[P2_AMT_COLS * 64], trp[P2_AMT_COLS * 64];
     const size_t N = (size_t)1 << a.lde_bits;
@@ -549,6 +484,9 @@ __global__ void __launch_bounds__(64 * P2_AMT_WAVES) p2_quotient_addmany_tile_ke
     const u32 k0 = a.nch + a.nch * (a.npp + 1);       // the gate constraints follow the Z1 and partial-product terms
     gl_acc3 acc[2][P2_MAX_CH];
     u64 comb[2] = {0, 0};
+    gl_ktab *apow[P2_MAX_CH];
+#pragma unroll
+    for (int c = 0; c < P2_MAX_CH; c++) apow[c] = (gl_ktab *)a.apow[c];
     u32 OPS[2], L0[2], GI[2];                         // wave-uniform: this wave's variants
 #pragma unroll
     for (int s = 0; s < 2; s++) {
@@ -565,31 +503,14 @@ __global__ void __launch_bounds__(64 * P2_AMT_WAVES) p2_quotient_addmany_tile_ke
         L0[s] = per * ops;
         // routed wires: the sum constraint and the -res / -carry halves of the two recombination constraints (linear: the limb
         // halves are added when the tile is consumed)
-#pragma unroll 1
-        for (u32 i = 0; i < ops; i++) {
-            p2_vars pv;
-            pv.wires = a.wires;
-            pv.stride = N;
-            pv.p = p;
-            u64 rc[2];
-            p2_load<2>(pv, per * i + na + 1, rc);
-            const u64 sum = p2_sum_wires(pv, per * i, na + 1);          // the addends and the carry in
-            const u64 e0 = gl_sub(gl_add(gl_mul(rc[1], 1ULL << 32), rc[0]), sum), e1 = gl_neg(rc[0]), e2 = gl_neg(rc[1]);
-#pragma unroll
-            for (int c = 0; c < P2_MAX_CH; c++)
-                if (c < (int)a.nch) {
-                    gl_ktab *t = (gl_ktab *)a.apow[c] + 6 * (size_t)(k0 + 21 * i);
-                    if (s == 0) {
-                        gl_acc3_mul(acc[0][c], e0, t);
-                        gl_acc3_mul(acc[0][c], e1, t + 6 * 19);
-                        gl_acc3_mul(acc[0][c], e2, t + 6 * 20);
-                    } else {
-                        gl_acc3_mul(acc[1][c], e0, t);
-                        gl_acc3_mul(acc[1][c], e1, t + 6 * 19);
-                        gl_acc3_mul(acc[1][c], e2, t + 6 * 20);
-                    }
-                }
-        }
+        p2_vars pv;
+        pv.wires = a.wires;
+        pv.stride = N;
+        pv.p = p;
+        if (s == 0)
+            p2_amt_routed<0>(acc, pv, na, ops, apow, (int)a.nch, k0);
+        else
+            p2_amt_routed<1>(acc, pv, na, ops, apow, (int)a.nch, k0);
     }
     // ---- limb columns hi-1 .. lo in phases of P2_AMT_COLS
     const u32 per_wave = P2_AMT_COLS / P2_AMT_WAVES;  // 12 = three asm batches of four range products
@@ -613,8 +534,8 @@ __global__ void __launch_bounds__(64 * P2_AMT_WAVES) p2_quotient_addmany_tile_ke
                 }
         }
         __syncthreads();
-        if (OPS[0]) p2_amt_consume<0>(acc, comb, OPS[0], L0[0], base, top, tw, trp, lane, a, k0);
-        if (OPS[1]) p2_amt_consume<1>(acc, comb, OPS[1], L0[1], base, top, tw, trp, lane, a, k0);
+        if (OPS[0]) p2_amt_consume<0>(acc, comb, OPS[0], L0[0], base, top, tw, trp, lane, apow, (int)a.nch, k0);
+        if (OPS[1]) p2_amt_consume<1>(acc, comb, OPS[1], L0[1], base, top, tw, trp, lane, apow, (int)a.nch, k0);
         __syncthreads();
         top = base;
     }
@@ -1598,7 +1519,36 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
                 static const bool am_multi = getenv("ZKLC_P2_ADDMANY") && !strcmp(getenv("ZKLC_P2_ADDMANY"), "multi");
                 // A/B: ZKLC_P2_ADDMANY=pergate keeps one launch per variant list; the default for several variants is the LDS tile
                 static const bool am_pergate = getenv("ZKLC_P2_ADDMANY") && !strcmp(getenv("ZKLC_P2_ADDMANY"), "pergate");
-                if (c->gates[g].type == P2_U32_ADD_MANY && !am_multi && !am_pergate && N >= 64) {
+                // debug (ZKLC_P2_ADDMANY=check): the per-gate evaluator and the LDS-tile kernel into zeroed scratch outputs, compared on
+                // the host (every LDE point, both challenges); the proof itself then takes the per-gate path
+                static const bool am_check = getenv("ZKLC_P2_ADDMANY") && !strcmp(getenv("ZKLC_P2_ADDMANY"), "check");
+                if (am_check && c->gates[g].type == P2_U32_ADD_MANY && N >= 64) {
+                    p2_amt_plan plan;
+                    if (p2_amt_make_plan(c->gates.data(), list, plan)) {
+                        u64 *s1 = nullptr, *s2 = nullptr;
+                        const size_t words = (size_t)nch * N;
+                        ZKLC_HIP(ctx, hipMalloc(&s1, words * 8));
+                        ZKLC_HIP(ctx, hipMalloc(&s2, words * 8));
+                        ZKLC_HIP(ctx, hipMemsetAsync(s1, 0, words * 8, st));
+                        ZKLC_HIP(ctx, hipMemsetAsync(s2, 0, words * 8, st));
+                        p2_quotient_args b1 = a, b2 = a;
+                        b1.out = s1;
+                        b2.out = s2;
+                        hipLaunchKernelGGL(fn, dim3((N + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, b1, list);
+                        hipLaunchKernelGGL(p2_quotient_addmany_tile_kernel, dim3(N / 64), dim3(64 * P2_AMT_WAVES), 0, st, b2, list, plan);
+                        std::vector<u64> h1(words), h2(words);
+                        ZKLC_HIP(ctx, hipMemcpyAsync(h1.data(), s1, words * 8, hipMemcpyDeviceToHost, st));
+                        ZKLC_HIP(ctx, hipMemcpyAsync(h2.data(), s2, words * 8, hipMemcpyDeviceToHost, st));
+                        ZKLC_HIP(ctx, zklc_stream_wait(st));
+                        size_t bad = 0;
+                        for (size_t i = 0; i < words; i++) bad += h1[i] % GL_P != h2[i] % GL_P;
+                        fprintf(stderr, "[zklc] addmany check: %u variants, limb columns [%u, %u): %zu of %zu values differ\n", list.n, plan.lo,
+                                plan.hi, bad, words);
+                        (void)hipFree(s1);
+                        (void)hipFree(s2);
+                    }
+                }
+                if (c->gates[g].type == P2_U32_ADD_MANY && !am_multi && !am_pergate && !am_check && N >= 64) {
                     p2_amt_plan plan;
                     if (p2_amt_make_plan(c->gates.data(), list, plan)) {
                         hipLaunchKernelGGL(p2_quotient_addmany_tile_kernel, dim3(N / 64), dim3(64 * P2_AMT_WAVES), 0, st, a, list, plan);
