@@ -171,16 +171,39 @@ u32 hostsim_g1_op(int op, const u32 *p16, u32 pinf, const u32 *q16, u32 qinf, u3
 template <class F>
 static u32 hostsim_msm(const u64 *points, const u64 *scalars, u32 n, u32 mode, u32 heavy_min, u32 heavy_threads, u32 *out) {
     const int AFF = msm_cfg<F>::AFF, XY = msm_cfg<F>::XYZZ;
-    msm_plan pl = msm_make_plan(n);
+    // mode 0: the product plan (G1: the endomorphism split from MSM_GLV_MIN_POINTS points on); modes 1 / 2: no split
+    msm_plan pl = msm_make_plan(n, F::LIMBS == 10 && mode == 0);
     const u32 bpw = pl.buckets_per_window;
     std::vector<unsigned short> dig((size_t)pl.n_pad * pl.windows, 0);
-    for (u32 i = 0; i < pl.n_pad; i++) {
-        bool live = i < pl.n && !msm_point_is_inf<AFF>(points, i);
-        u32 sw[8], carry = 0;
-        if (live) msm_load_scalar(scalars, i, sw);
-        for (u32 w = 0; w < pl.windows; w++) {
-            int d = live ? msm_digit(sw, w, pl.c, carry) : 0;
-            dig[(size_t)w * pl.n_pad + i] = (unsigned short)msm_digit_code(d);
+    std::vector<i32> glv_points;                      // msm_glv_prepare_kernel: digits of both halves + the two point records
+    if (pl.glv) {
+        const int W = msm_rec<F, true>::WORDS;
+        glv_points.resize((size_t)pl.n * W);
+        for (u32 i = 0; i < n; i++) {
+            bool live = !msm_point_is_inf<AFF>(points, i);
+            u32 sw[8], m1[8] = {0}, m2[8] = {0}, neg1 = 0, neg2 = 0;
+            if (live) {
+                msm_load_scalar(scalars, i, sw);
+                msm_glv_split(sw, m1, neg1, m2, neg2);
+            }
+            u32 carry1 = 0, carry2 = 0;
+            for (u32 w = 0; w < pl.windows; w++) {
+                int d1 = live ? msm_digit(m1, w, pl.c, carry1) : 0, d2 = live ? msm_digit(m2, w, pl.c, carry2) : 0;
+                dig[(size_t)w * pl.n_pad + i] = (unsigned short)msm_digit_code(d1);
+                dig[(size_t)w * pl.n_pad + n + i] = (unsigned short)msm_digit_code(d2);
+            }
+            if (carry1 | carry2) return 0xdeadu;      // the top window never carries out (|k_i| < 2^127)
+            msm_convert_point_glv<F, true>(glv_points.data() + (size_t)i * W, glv_points.data() + ((size_t)n + i) * W, points, i, neg1, neg2);
+        }
+    } else {
+        for (u32 i = 0; i < pl.n_pad; i++) {
+            bool live = i < pl.n && !msm_point_is_inf<AFF>(points, i);
+            u32 sw[8], carry = 0;
+            if (live) msm_load_scalar(scalars, i, sw);
+            for (u32 w = 0; w < pl.windows; w++) {
+                int d = live ? msm_digit(sw, w, pl.c, carry) : 0;
+                dig[(size_t)w * pl.n_pad + i] = (unsigned short)msm_digit_code(d);
+            }
         }
     }
     std::vector<u32> cnt((size_t)pl.total_buckets * pl.chunks, 0), totals(pl.total_buckets), offsets(pl.total_buckets);
@@ -223,10 +246,13 @@ static u32 hostsim_msm(const u64 *points, const u64 *scalars, u32 n, u32 mode, u
     std::vector<i32> buckets((size_t)pl.total_buckets * XY, 0);       // zeroed = infinity, as the product memsets it
     if (mode != 1) {
         // the product path: converted points, slices of the sorted entries, combine
-        const u32 E = run, slices = (u32)(((u64)n * pl.windows + MSM_SLICE - 1) / MSM_SLICE);
-        std::vector<i32> cpoints((size_t)n * 2 * F::LIMBS), partials(((size_t)slices + 1) * 2 * XY, 0x5a5a5a5a);
+        const u32 E = run, slices = (u32)(((u64)pl.n * pl.windows + MSM_SLICE - 1) / MSM_SLICE);
+        std::vector<i32> cpoints((size_t)pl.n * 2 * F::LIMBS), partials(((size_t)slices + 1) * 2 * XY, 0x5a5a5a5a);
         if (mode == 0) {        // packed 8 x 32-bit records (the product default)
-            for (u32 i = 0; i < n; i++) msm_convert_point<F, true>(cpoints.data() + (size_t)i * msm_rec<F, true>::WORDS, points, i);
+            if (pl.glv)
+                cpoints = glv_points;
+            else
+                for (u32 i = 0; i < n; i++) msm_convert_point<F, true>(cpoints.data() + (size_t)i * msm_rec<F, true>::WORDS, points, i);
             for (u32 lane = 0; lane < slices; lane++)
                 msm_slice_lane<F, true>(cpoints.data(), entries.data(), offsets.data(), pl.total_buckets, E, lane, buckets.data(), partials.data());
         } else {                // mode 2: records of ten 32-bit limbs per coordinate (ZKLC_MSM_PACKED=0)
@@ -288,6 +314,11 @@ u32 hostsim_msm_g1(const u64 *points, const u64 *scalars, u32 n, u32 mode, u32 h
 }
 u32 hostsim_msm_g2(const u64 *points, const u64 *scalars, u32 n, u32 mode, u32 heavy_min, u32 heavy_threads, u32 *out32) {
     return hostsim_msm<Fp2Field>(points, scalars, n, mode, heavy_min, heavy_threads, out32);
+}
+void hostsim_msm_glv_split(const u64 *scalar4, u32 *m1, u32 *m2, u32 *negs) {
+    u32 sw[8];
+    msm_load_scalar(scalar4, 0, sw);
+    msm_glv_split(sw, m1, negs[0], m2, negs[1]);
 }
 void hostsim_msm_plan(u64 n, u32 *out8) {
     msm_plan pl = msm_make_plan(n);

@@ -151,3 +151,40 @@ def test_g2_lane_walk_with_quad_doublings_matches_python(hostsim):
         outs.append([out[2 * i] | (out[2 * i + 1] << 32) for i in range(16)])
     want = B.g2_to_words(B.g2_msm(vals, plist))
     assert outs[0] == outs[1] == outs[2] == [int(x) for x in want]
+
+
+def test_glv_split_and_the_split_msm(hostsim):
+    """the endomorphism split of the G1 multi-exponentiation (bn254_msm_lane.cuh: msm_glv_split): k = k1 + k2 lambda (mod r) with
+    |k1|, |k2| < 2^127 for random and extreme scalars; lambda P = (beta x, y) on the oracle's curve arithmetic; and the whole lane walk
+    WITH the split (>= 256 points: 2 n items, 8 windows at c = 16 -- here smaller windows, same code) equals the oracle's naive sum"""
+    lam = 4407920970296243842393367215006156084916469457145843978461
+    beta = 2203960485148121921418603742825762020974279258880205651966
+    assert (lam * lam + lam + 1) % R == 0 and pow(beta, 3, B.P) == 1
+    assert B.mul(lam, B.G1) == (beta * B.G1[0] % B.P, B.G1[1])
+    rng = np.random.default_rng(11)
+    f = hostsim.hostsim_msm_glv_split
+    f.restype = None
+    cases = [0, 1, 2, R - 1, R - 2, lam, R - lam, 1 << 253, (1 << 127), (1 << 127) - 1, 2**256 - 1] + \
+        [int(rng.integers(0, 2**63)) << 191 | int(rng.integers(0, 2**63)) << 128 | int(rng.integers(0, 2**63)) << 64 | int(rng.integers(0, 2**63))
+         for _ in range(3000)]
+    for k in cases:
+        sc = np.array([(k >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+        m1, m2, negs = (ctypes.c_uint32 * 4)(), (ctypes.c_uint32 * 4)(), (ctypes.c_uint32 * 2)()
+        f(sc.ctypes.data_as(ctypes.c_void_p), m1, m2, negs)
+        k1 = sum(int(m1[i]) << (32 * i) for i in range(4)) * (-1 if negs[0] else 1)
+        k2 = sum(int(m2[i]) << (32 * i) for i in range(4)) * (-1 if negs[1] else 1)
+        assert abs(k1) < 1 << 127 and abs(k2) < 1 << 127 and (k1 + k2 * lam - k) % R == 0, k
+    # the full walk with the split: 300 and 2500 points are in the parametrised test above (mode 0 = the product plan); here the
+    # plan itself and a case with points at infinity and unreduced scalars
+    plan = (ctypes.c_uint32 * 8)()
+    n = 700
+    pts = cport.bn254_gen_points(n, 13, 5)
+    pts[5] = 0
+    pts[n - 2] = 0
+    sc = _scalars("top", n, rng)
+    live = [i for i in range(n) if pts[i].any()]
+    want, winf, _ = cport.bn254_msm(pts[live], _reduced(sc[live]), naive=True)
+    got, inf = _run(hostsim, pts, sc)
+    assert inf == winf and np.array_equal(got, want)
+    got2, inf2 = _run(hostsim, pts, sc, mode=2)          # no split, unpacked records: the same point
+    assert inf2 == inf and np.array_equal(got2, got)

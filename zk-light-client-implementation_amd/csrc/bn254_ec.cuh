@@ -29,6 +29,10 @@ struct FpField {
     static ZKLC_M void to_gnark(u32 *w, const T &a) { fp_to_gnark(w, a); }
     // packed record form: the canonical value in [0, p) (internal Montgomery domain) as 8 x 32 bits -- 32 bytes instead of 40
     static constexpr int PACKW = 8;
+    static ZKLC_M T glv_beta() {           // the cube root of unity of the endomorphism (x, y) -> (beta x, y), internal domain
+        const fp b = {{22559598, 38139752, 31972598, 57743016, 2270579, 9149387, 32916771, 55036474, 42603741, 495081}};
+        return b;
+    }
     static ZKLC_M void pack(u32 *w, const T &a) { fp_freeze_words(w, a); }
     static ZKLC_M T unpack(const u32 *w) { return fp_from_words_raw(w); }
     static ZKLC_M void store(i32 *d, const T &a) {
@@ -60,6 +64,7 @@ struct Fp2Field {
     static ZKLC_M T from_gnark(const u32 *w) { return fp2_from_gnark(w); }
     static ZKLC_M void to_gnark(u32 *w, const T &a) { fp2_to_gnark(w, a); }
     static constexpr int PACKW = 16;
+    static ZKLC_M T glv_beta() { return fp2_one(); }      // (no split on G2: never called)
     static ZKLC_M void pack(u32 *w, const T &a) {
         fp_freeze_words(w, a.c0);
         fp_freeze_words(w + 8, a.c1);

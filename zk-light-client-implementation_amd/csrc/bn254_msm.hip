@@ -44,6 +44,34 @@ msm_recode_kernel(const u64 *__restrict__ points, const u64 *__restrict__ scalar
     }
 }
 
+// ---- 1'. the endomorphism split (G1): one lane per POINT: k -> (k1, k2), the digits of both magnitudes, and the two converted point
+// records (x, +-y) / (beta x, +-y) with the signs folded into y (bn254_msm_lane.cuh: msm_glv_split, msm_convert_point_glv)
+template <bool PK>
+__global__ void __launch_bounds__(256)
+msm_glv_prepare_kernel(const u64 *__restrict__ points, const u64 *__restrict__ scalars, msm_plan pl, unsigned short *__restrict__ dig,
+                       i32 *__restrict__ cpoints) {
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pl.n + i < pl.n_pad)                              // the (at most seven) pad items of every digit row
+        for (u32 w = 0; w < pl.windows; w++) dig[(size_t)w * pl.n_pad + pl.n + i] = 0;
+    if (i >= pl.n_pts) return;
+    const bool live = !msm_point_is_inf<8>(points, i);
+    u32 sw[8], m1[8], m2[8], neg1 = 0, neg2 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) sw[k] = m1[k] = m2[k] = 0;
+    if (live) {
+        msm_load_scalar(scalars, i, sw);
+        msm_glv_split(sw, m1, neg1, m2, neg2);
+    }
+    u32 carry1 = 0, carry2 = 0;
+    for (u32 w = 0; w < pl.windows; w++) {
+        int d1 = live ? msm_digit(m1, w, pl.c, carry1) : 0, d2 = live ? msm_digit(m2, w, pl.c, carry2) : 0;
+        dig[(size_t)w * pl.n_pad + i] = (unsigned short)msm_digit_code(d1);
+        dig[(size_t)w * pl.n_pad + pl.n_pts + i] = (unsigned short)msm_digit_code(d2);
+    }
+    const int W = msm_rec<FpField, PK>::WORDS;
+    msm_convert_point_glv<FpField, PK>(cpoints + (size_t)i * W, cpoints + ((size_t)pl.n_pts + i) * W, points, i, neg1, neg2);
+}
+
 // eight digit codes of one lane (16 bytes)
 ZKLC_D void msm_codes8(const unsigned short *row, u32 i, u32 *code) {
     uint4 v = *reinterpret_cast<const uint4 *>(row + i);
@@ -337,12 +365,16 @@ __global__ void __launch_bounds__(msm_cfg<F>::BLOCK) msm_final_kernel(const i32 
 }
 
 // ---------------------------------------------------------------- host
+// A/B switch ZKLC_MSM_GLV=0: no endomorphism split (G1: the plan of rounds 1-3)
+static bool msm_glv_enabled() {
+    static const bool on = !(getenv("ZKLC_MSM_GLV") && getenv("ZKLC_MSM_GLV")[0] == '0');
+    return on;
+}
 template <class F>
-static uint64_t msm_workspace_bytes(uint64_t n) {
+static uint64_t msm_workspace_bytes_plan(const msm_plan &pl) {
     const uint64_t XB = msm_cfg<F>::XYZZ * 4;
-    msm_plan pl = msm_make_plan(n);
     u32 seg_per_window = (pl.buckets_per_window + MSM_SEG - 1) / MSM_SEG;
-    uint64_t total = pl.total_buckets, b = 0;
+    uint64_t total = pl.total_buckets, n = pl.n, b = 0;
     b += total * 4 * 2;                                 // totals (bucket sizes), offsets
     b += (total / SCAN_ITEMS + 2) * 4;                  // scan block sums
     b += total * pl.chunks * 4;                         // per-tile counts / prefixes
@@ -356,6 +388,15 @@ static uint64_t msm_workspace_bytes(uint64_t n) {
     b += (MSM_MAX_HEAVY + 4) * 4;                       // heavy list + counter
     b += 256 * 16;                                      // alignment slack
     return b;
+}
+template <class F>
+static uint64_t msm_workspace_bytes(uint64_t n) {       // enough for either plan (the A/B switch may differ between the two calls)
+    uint64_t a = msm_workspace_bytes_plan<F>(msm_make_plan(n, false));
+    if (F::LIMBS == 10) {
+        uint64_t b = msm_workspace_bytes_plan<F>(msm_make_plan(n, true));
+        a = b > a ? b : a;
+    }
+    return a;
 }
 
 // the sort kernels keep a whole window's counters in LDS: up to 128 KiB of dynamic LDS, above the default 64 KiB limit
@@ -373,12 +414,12 @@ static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points
                            uint64_t *d_out_affine, uint32_t *d_out_inf, void *d_workspace, uint64_t workspace_bytes) {
     const int AFF = msm_cfg<F>::AFF;
     const size_t XB = msm_cfg<F>::XYZZ * 4;
-    if (!ctx || !d_out_affine || !d_out_inf || (n && (!d_points || !d_scalars)) || n >= (1ULL << 31)) return ZKLC_ERR_INVALID_ARG;
+    if (!ctx || !d_out_affine || !d_out_inf || (n && (!d_points || !d_scalars)) || n >= (1ULL << 30)) return ZKLC_ERR_INVALID_ARG;
     if (((uintptr_t)d_points | (uintptr_t)d_scalars) & 15) return ZKLC_ERR_INVALID_ARG;
     ZKLC_HIP(ctx, hipSetDevice(ctx->device));
     ZKLC_HIP(ctx, msm_sort_lds_attr());
     hipStream_t st = zklc_pick_stream(ctx, stream);
-    msm_plan pl = msm_make_plan(n);
+    msm_plan pl = msm_make_plan(n, F::LIMBS == 10 && msm_glv_enabled());
     if (workspace_bytes < msm_workspace_bytes<F>(n) || !d_workspace) return ZKLC_ERR_INVALID_ARG;
     u32 seg_per_window = (pl.buckets_per_window + MSM_SEG - 1) / MSM_SEG;
     // carve the workspace (256-byte aligned pieces)
@@ -396,10 +437,10 @@ static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points
     u32 *tile_cnt = (u32 *)take((size_t)pl.total_buckets * pl.chunks * 4);
     unsigned short *dig = (unsigned short *)take((size_t)pl.n_pad * pl.windows * 2);
     u32 *heavy_list = (u32 *)take(MSM_MAX_HEAVY * 4);
-    u32 *entries = (u32 *)take((size_t)n * pl.windows * 4 + 4);
+    u32 *entries = (u32 *)take((size_t)pl.n * pl.windows * 4 + 4);
     i32 *buckets = (i32 *)take((size_t)pl.total_buckets * XB);
-    i32 *cpoints = (i32 *)take((size_t)n * 2 * F::LIMBS * 4);
-    const u32 slices = (u32)(((uint64_t)n * pl.windows + MSM_SLICE - 1) / MSM_SLICE);
+    i32 *cpoints = (i32 *)take((size_t)pl.n * 2 * F::LIMBS * 4);
+    const u32 slices = (u32)(((uint64_t)pl.n * pl.windows + MSM_SLICE - 1) / MSM_SLICE);
     i32 *partials = (i32 *)take(((size_t)slices + 1) * 2 * XB);
     i32 *seg_out = (i32 *)take((size_t)seg_per_window * pl.windows * XB);
     i32 *win_out = (i32 *)take((size_t)pl.windows * XB);
@@ -407,8 +448,20 @@ static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points
     const size_t lds = (size_t)pl.buckets_per_window * 4;
 
     ZKLC_HIP(ctx, hipMemsetAsync(heavy_count, 0, 16, st));
+    const char *pkv = getenv("ZKLC_MSM_PACKED");          // A/B: 0 = point records of ten 32-bit limbs per coordinate (default packed)
+    const bool packed = !(pkv && pkv[0] == '0');
     if (pl.n) {
-        hipLaunchKernelGGL((msm_recode_kernel<AFF>), dim3((pl.n_pad + 255) / 256), dim3(256), 0, st, d_points, d_scalars, pl, dig);
+        if constexpr (F::LIMBS == 10) {
+            if (pl.glv) {
+                const unsigned grid = (pl.n_pts + 255) / 256;
+                if (packed)
+                    hipLaunchKernelGGL(msm_glv_prepare_kernel<true>, dim3(grid), dim3(256), 0, st, d_points, d_scalars, pl, dig, cpoints);
+                else
+                    hipLaunchKernelGGL(msm_glv_prepare_kernel<false>, dim3(grid), dim3(256), 0, st, d_points, d_scalars, pl, dig, cpoints);
+            }
+        }
+        if (!pl.glv)
+            hipLaunchKernelGGL((msm_recode_kernel<AFF>), dim3((pl.n_pad + 255) / 256), dim3(256), 0, st, d_points, d_scalars, pl, dig);
         hipLaunchKernelGGL(msm_hist_kernel, dim3(pl.chunks, pl.windows), dim3(MSM_SORT_THREADS), lds, st, (const unsigned short *)dig, pl,
                            tile_cnt);
     } else {
@@ -428,12 +481,12 @@ static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points
     if (pl.n) {
         // A/B switches: ZKLC_MSM_PACKED = 0 / 1 (point records of 10 x 32-bit limbs per coordinate / packed 8 x 32 bits, default packed),
         // ZKLC_MSM_WAVES = 1..3: waves per SIMD the G1 slice kernel's register allocation keeps
-        const char *pkv = getenv("ZKLC_MSM_PACKED");
-        const bool packed = !(pkv && pkv[0] == '0');
-        if (packed)
-            hipLaunchKernelGGL((msm_convert_kernel<F, true>), dim3((pl.n + 255) / 256), dim3(256), 0, st, d_points, pl.n, cpoints);
-        else
-            hipLaunchKernelGGL((msm_convert_kernel<F, false>), dim3((pl.n + 255) / 256), dim3(256), 0, st, d_points, pl.n, cpoints);
+        if (!pl.glv) {
+            if (packed)
+                hipLaunchKernelGGL((msm_convert_kernel<F, true>), dim3((pl.n + 255) / 256), dim3(256), 0, st, d_points, pl.n, cpoints);
+            else
+                hipLaunchKernelGGL((msm_convert_kernel<F, false>), dim3((pl.n + 255) / 256), dim3(256), 0, st, d_points, pl.n, cpoints);
+        }
         const char *v = getenv("ZKLC_MSM_WAVES");
         int waves = (v && v[0] >= '1' && v[0] <= '3') ? v[0] - '0' : MSM_SLICE_WAVES_G1;
         if (F::LIMBS != 10) waves = 1;       // the Fp2 kernel needs the whole register file

@@ -11,7 +11,8 @@
 #define MSM_SEG 16u          // buckets per running-sum segment (one lane each)
 
 struct msm_plan {
-    u32 n, n_pad;            // points; digit-row stride (n rounded up to 8)
+    u32 n, n_pad;            // ITEMS (= points, or 2 x points with the endomorphism split); digit-row stride (n rounded up to 8)
+    u32 n_pts, glv;          // input points; 1 = every point enters twice: (k1, P) and (k2, phi(P)) with 127-bit scalars (G1 only)
     u32 c, windows, buckets_per_window, total_buckets;
     u32 chunks, chunk_len;   // the counting sort works on (chunk, window) tiles; chunk_len is a multiple of 8
 };
@@ -66,6 +67,80 @@ ZKLC_HD u32 msm_code_bucket(u32 code, u32 &neg) {
     neg = (code > 0x8000u) ? 1u : 0u;
     u32 mag = neg ? 0x10000u - code : code;
     return mag - 1;
+}
+
+// ---- the endomorphism split (G1, round 4): BN254 has phi(x, y) = (beta x, y) = lambda (x, y) with beta^3 = 1 in Fp and
+// lambda^2 + lambda + 1 = 0 in Fr, so  k P = k1 P + k2 phi(P)  with |k1|, |k2| < 2^127 (Gallant-Lambert-Vanstone): the same number
+// of bucket additions (2 n items x 8 windows of 16 bits instead of n x 16) but HALF the windows -- half the bucket reductions and
+// 112 instead of 240 serial doublings at the end.  (v1, v2) = ((a1, b1), (a2, b2)) is a short basis of the lattice
+// {(x, y): x + y lambda = 0 mod r} (extended Euclid on (r, lambda)); c_i = round(k g_i / 2^256) with g1 = round(2^256 b2 / r),
+// g2 = round(-2^256 b1 / r);  k1 = k - c1 a1 - c2 a2,  k2 = -c1 b1 - c2 b2.  k1 + k2 lambda = k (mod r) holds for ANY integers c1, c2
+// (the rounding only bounds the sizes: |k_i| <= (|v1| + |v2|) / 2 (1 + eps) < 2^126.1), which is why approximate quotients are exact.
+// Constants checked by tests/test_hostsim_msm.py against the oracle's curve arithmetic.
+#define MSM_GLV_MIN_POINTS 256u
+#define MSM_GLV_MAX_POINTS (1u << 21)   // measured (profiles/r04l_*): 2^16 -11 %, 2^18 -14 %, 2^20 -6 %, 2^22 +-0 (the doubled record table costs
+                                        // the gathers of the slice kernel what the halved tail saves): no split above 2^21 points
+ZKLC_HD void msm_mp_muladd(u32 *out, int nout, const u32 *a, int na, const u32 *b, int nb) {      // out += a * b (mod 2^(32 nout))
+    for (int i = 0; i < na; i++) {
+        u64 carry = 0;
+        for (int j = 0; j < nb && i + j < nout; j++) {
+            u64 t = (u64)a[i] * b[j] + out[i + j] + carry;
+            out[i + j] = (u32)t;
+            carry = t >> 32;
+        }
+        for (int k = i + nb; k < nout && carry; k++) {
+            u64 t = (u64)out[k] + carry;
+            out[k] = (u32)t;
+            carry = t >> 32;
+        }
+    }
+}
+// 256-bit two's complement v -> (|v| as 4 words, sign); |v| < 2^127 by the bound above
+ZKLC_HD void msm_glv_magnitude(const u32 *v8, u32 *m4, u32 &neg) {
+    neg = v8[7] >> 31;
+    u64 carry = neg;
+    for (int i = 0; i < 4; i++) {
+        u64 t = (u64)(neg ? ~v8[i] : v8[i]) + carry;
+        m4[i] = (u32)t;
+        carry = t >> 32;
+    }
+}
+// sw: 8 words of a scalar < r  ->  magnitudes (4 words each) and signs of k1, k2
+ZKLC_HD void msm_glv_split(const u32 *sw, u32 *m1, u32 &neg1, u32 *m2, u32 &neg2) {
+    const u32 G1[3] = {0xc7e0b3d7u, 0xd91d232eu, 0x2u}, G2[5] = {0x391eb18eu, 0x7a7bd9d4u, 0xa773d2cfu, 0x4ccef014u, 0x2u};
+    const u32 A1[2] = {0x94d213e3u, 0x89d32568u}, A2[4] = {0x1221250bu, 0x0be4e154u, 0xeeb859fdu, 0x6f4d8248u};
+    const u32 NB1[4] = {0x7d4f1128u, 0x8211bbebu, 0xeeb859fcu, 0x6f4d8248u}, B2[2] = {0x94d213e3u, 0x89d32568u};
+    u32 t[13], c1[3], c2[5];
+    for (int i = 0; i < 13; i++) t[i] = 0;
+    t[7] = 0x80000000u;                                 // + 2^255: round to nearest
+    msm_mp_muladd(t, 11, sw, 8, G1, 3);
+    for (int i = 0; i < 3; i++) c1[i] = t[8 + i];
+    for (int i = 0; i < 13; i++) t[i] = 0;
+    t[7] = 0x80000000u;
+    msm_mp_muladd(t, 13, sw, 8, G2, 5);
+    for (int i = 0; i < 5; i++) c2[i] = t[8 + i];
+    // k1 = k - (c1 a1 + c2 a2),  k2 = c1 |b1| - c2 b2   (mod 2^256; the true values are small signed numbers)
+    u32 s[8], k1[8], k2[8], u[8];
+    for (int i = 0; i < 8; i++) s[i] = 0;
+    msm_mp_muladd(s, 8, c1, 3, A1, 2);
+    msm_mp_muladd(s, 8, c2, 5, A2, 4);
+    u64 borrow = 0;
+    for (int i = 0; i < 8; i++) {
+        u64 d = (u64)sw[i] - s[i] - borrow;
+        k1[i] = (u32)d;
+        borrow = (d >> 32) & 1;
+    }
+    for (int i = 0; i < 8; i++) s[i] = u[i] = 0;
+    msm_mp_muladd(s, 8, c1, 3, NB1, 4);
+    msm_mp_muladd(u, 8, c2, 5, B2, 2);
+    borrow = 0;
+    for (int i = 0; i < 8; i++) {
+        u64 d = (u64)s[i] - u[i] - borrow;
+        k2[i] = (u32)d;
+        borrow = (d >> 32) & 1;
+    }
+    msm_glv_magnitude(k1, m1, neg1);
+    msm_glv_magnitude(k2, m2, neg2);
 }
 
 template <int AFF>  // u64 words per affine point: 8 (G1) or 16 (G2)
@@ -196,6 +271,29 @@ ZKLC_HD void msm_convert_point(i32 *dst, const u64 *points, u32 idx) {
     } else {
         F::store(dst, F::reduce(x));
         F::store(dst + F::LIMBS, F::reduce(y));
+    }
+}
+
+// the two records of point idx under the endomorphism split: item idx = (x, +-y), item n_pts + idx = (beta x, +-y); the signs of
+// k1 / k2 are folded into y, so the digits downstream are those of the magnitudes
+template <class F, bool PK>
+ZKLC_HD void msm_convert_point_glv(i32 *dst1, i32 *dst2, const u64 *points, u32 idx, u32 neg1, u32 neg2) {
+    typename F::T x, y;
+    msm_load_point<F>(points, idx, x, y);
+    x = F::reduce(x);
+    y = F::reduce(y);
+    const typename F::T bx = F::mul(x, F::glv_beta()), ny = F::reduce(F::neg(y));
+    const typename F::T y1 = F::select(y, ny, neg1), y2 = F::select(y, ny, neg2);
+    if (PK) {
+        F::pack(reinterpret_cast<u32 *>(dst1), x);
+        F::pack(reinterpret_cast<u32 *>(dst1) + F::PACKW, y1);
+        F::pack(reinterpret_cast<u32 *>(dst2), bx);
+        F::pack(reinterpret_cast<u32 *>(dst2) + F::PACKW, y2);
+    } else {
+        F::store(dst1, x);
+        F::store(dst1 + F::LIMBS, y1);
+        F::store(dst2, bx);
+        F::store(dst2 + F::LIMBS, y2);
     }
 }
 
@@ -414,18 +512,23 @@ MSM_HOST_DEV u32 msm_pick_window(u64 n) {
     return 4;
 }
 
-MSM_HOST_DEV msm_plan msm_make_plan(u64 n) {
+MSM_HOST_DEV msm_plan msm_make_plan(u64 n_pts, bool g1 = false) {
     msm_plan pl;
+    pl.n_pts = (u32)n_pts;
+    pl.glv = (g1 && n_pts >= MSM_GLV_MIN_POINTS && n_pts <= MSM_GLV_MAX_POINTS) ? 1u : 0u;
+    const u64 n = pl.glv ? 2 * n_pts : n_pts;
     pl.n = (u32)n;
     pl.n_pad = (u32)((n + 7) & ~(u64)7);
     pl.c = msm_pick_window(n);
-    pl.windows = 254 / pl.c + 1;
+    // values below 2^B need W windows with c W >= B + 1 (the top window then never carries out): B = 254, or 127 after the split
+    pl.windows = pl.glv ? (127 / pl.c + 1) : (254 / pl.c + 1);
     pl.buckets_per_window = 1u << (pl.c - 1);
     pl.total_buckets = pl.windows * pl.buckets_per_window;
     // (chunk, window) tiles of the counting sort: enough tiles to fill the chip, chunks of at least 2^13 points
     u32 chunks = (u32)(n >> 13);
     if (chunks < 1) chunks = 1;
     if (chunks > 16) chunks = 16;
+    if (pl.glv && chunks == 16 && n >= (1u << 18)) chunks = 32;       // half the windows: keep (chunks x windows) >= 256 tiles
     pl.chunks = chunks;
     pl.chunk_len = ((pl.n_pad / 8 + chunks - 1) / chunks) * 8;
     if (pl.chunk_len == 0) pl.chunk_len = 8;
