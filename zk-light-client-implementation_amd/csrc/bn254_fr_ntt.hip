@@ -153,15 +153,19 @@ frn_pass_b_kernel(const i32 *__restrict__ mid, u64 *__restrict__ data, const i32
 
 // the resident table block of (log_n, direction), built on first use on `st`
 static int32_t frn_tables(zklc_ctx *ctx, hipStream_t st, const frn_plan &p, bool inverse, const i32 **out) {
+    static std::mutex tab_mutex;                // the build is serialised and complete before the pointer is published
+    std::lock_guard<std::mutex> lk(tab_mutex);
     void *&slot = ctx->fr_ntt_tab[inverse ? 1 : 0][p.log_n];
     if (!slot) {
-        ZKLC_HIP(ctx, hipMalloc(&slot, (size_t)frn_table_elems(p) * 40));
-        hipLaunchKernelGGL(frn_table_consts_kernel, dim3(1), dim3(64), 0, st, (i32 *)slot, p.log_n, (u32)inverse);
+        void *fresh = nullptr;
+        ZKLC_HIP(ctx, hipMalloc(&fresh, (size_t)frn_table_elems(p) * 40));
+        hipLaunchKernelGGL(frn_table_consts_kernel, dim3(1), dim3(64), 0, st, (i32 *)fresh, p.log_n, (u32)inverse);
         u32 ne = frn_table_elems(p) - 4;
-        hipLaunchKernelGGL(frn_table_entries_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, (i32 *)slot, p);
+        hipLaunchKernelGGL(frn_table_entries_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, (i32 *)fresh, p);
         ZKLC_HIP(ctx, hipGetLastError());
         // other streams of this context may use the block right after this call returns
         ZKLC_HIP(ctx, hipStreamSynchronize(st));
+        slot = fresh;
     }
     *out = (const i32 *)slot;
     return ZKLC_OK;
@@ -176,12 +180,11 @@ void zklc_bn254_fr_ntt_fini(zklc_ctx *ctx) {
 }
 
 static int32_t frn_two_pass(zklc_ctx *ctx, hipStream_t st, uint64_t *d_data, uint32_t log_n, bool inverse, uint32_t coset, i32 *mid) {
-    static hipError_t attr = [] {
+    ZKLC_HIP(ctx, zklc_once_per_device([] {
         hipError_t e = hipFuncSetAttribute((const void *)frn_pass_a_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return e;
         return hipFuncSetAttribute((const void *)frn_pass_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    }();
-    ZKLC_HIP(ctx, attr);
+    }));
     frn_plan p = frn_make_plan(log_n);
     const i32 *tab;
     int32_t rc = frn_tables(ctx, st, p, inverse, &tab);

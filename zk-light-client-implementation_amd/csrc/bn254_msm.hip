@@ -401,12 +401,11 @@ static uint64_t msm_workspace_bytes(uint64_t n) {       // enough for either pla
 
 // the sort kernels keep a whole window's counters in LDS: up to 128 KiB of dynamic LDS, above the default 64 KiB limit
 static hipError_t msm_sort_lds_attr() {
-    static hipError_t done = [] {
+    return zklc_once_per_device([] {
         hipError_t e = hipFuncSetAttribute((const void *)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         return hipFuncSetAttribute((const void *)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }();
-    return done;
+    });
 }
 
 template <class F>

@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include "poseidon_gl.cuh"
 #include "goldilocks_ntt_group.cuh"
+#include <mutex>
 #include "zklc_internal.h"
 
 #define NTT_THREADS 256
@@ -593,15 +594,17 @@ static int32_t gl_ntt_run(zklc_ctx *ctx, hipStream_t st, const u64 *in, size_t i
     }
     static const bool radix2 = getenv("ZKLC_NTT_RADIX2") != nullptr;   // A/B switch: the original one-stage-per-barrier loop
     static const bool r8 = getenv("ZKLC_NTT_R8") != nullptr;           // A/B switch: radix-8 groups with a table twiddle per butterfly
-    static const bool lds_ok = [] {     // 72 KB of dynamic LDS is above the default 64 KB cap
+    const bool lds_ok = zklc_once_per_device([] {     // 72 KB of dynamic LDS is above the default 64 KB cap
         const int bytes = ((1 << NTT_TILE_LOG_BIG) + (1 << NTT_TILE_LOG_BIG) / 8) * (int)sizeof(u64);
-        return hipFuncSetAttribute((const void *)gl_ntt_pass_r8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void *)gl_ntt_pass_r8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void *)gl_ntt_pass_g4_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void *)gl_ntt_pass_g4_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void *)gl_ntt_pass_g4_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-               hipFuncSetAttribute((const void *)gl_ntt_pass_g4_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
-    }();
+        const void *fns[6] = {(const void *)gl_ntt_pass_r8_kernel<true>,        (const void *)gl_ntt_pass_r8_kernel<false>,
+                              (const void *)gl_ntt_pass_g4_kernel<true, true>,  (const void *)gl_ntt_pass_g4_kernel<true, false>,
+                              (const void *)gl_ntt_pass_g4_kernel<false, true>, (const void *)gl_ntt_pass_g4_kernel<false, false>};
+        for (const void *f : fns) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }) == hipSuccess;
     if (!lds_ok) return ZKLC_ERR_HIP;
     const bool g4 = !radix2 && !r8;
     const u64 *tw = nullptr;
@@ -650,9 +653,15 @@ static int32_t gl_ntt_run(zklc_ctx *ctx, hipStream_t st, const u64 *in, size_t i
         }
     }
     if (g4) {
+        // resident per (context, logn, direction); built on first use.  The build is serialised and COMPLETE before the pointer is
+        // published (another host thread or stream of the same context must never see a half-built block)
+        static std::mutex twg_mutex;
+        std::lock_guard<std::mutex> twg_lock(twg_mutex);
         void **slot = inverse ? &ctx->gl_twg_inv[logn] : &ctx->gl_twg_fwd[logn];
         if (!*slot) {
-            ZKLC_HIP(ctx, hipMalloc(slot, tab_elems * 8));
+            void *fresh = nullptr;
+            ZKLC_HIP(ctx, hipMalloc(&fresh, tab_elems * 8));
+            void **build = &fresh;
             u64 w = host_gl_pow(GL_POWER_OF_TWO_GENERATOR, 1ULL << (32 - logn));
             if (inverse) w = host_gl_pow(w, GL_P - 2);
             for (int i = 0; i < np; i++) {
@@ -661,11 +670,13 @@ static int32_t gl_ntt_run(zklc_ctx *ctx, hipStream_t st, const u64 *in, size_t i
                     int g = gsz_of[i][j], sf = s0_of[i] + t0;
                     u64 nj = 1ULL << (logn - sf - g), cnt = ((1ULL << g) - 1) * nj;
                     hipLaunchKernelGGL(gl_group_twiddle_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st,
-                                       (u64 *)*slot + goff_of[i][j], w, (u32)g, (u32)sf, nj);
+                                       (u64 *)*build + goff_of[i][j], w, (u32)g, (u32)sf, nj);
                     t0 += g;
                 }
             }
             ZKLC_HIP(ctx, hipGetLastError());
+            ZKLC_HIP(ctx, hipStreamSynchronize(st));       // once per (logn, direction)
+            *slot = fresh;
         }
         tw = (const u64 *)*slot;
     }

@@ -16,6 +16,8 @@
 #include <string.h>
 #include <atomic>
 #include <map>
+#include <memory>
+#include <tuple>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -114,24 +116,45 @@ struct LevelPlan {
     std::vector<u32> order;           // instruction indices sorted by level
     std::vector<u32> level_start;     // order[level_start[l] .. level_start[l + 1]) = level l
 };
+// Plans are cached by the CONTENT of the program (a 64-bit FNV-1a of its words and of its input slots, + lengths): a key on the
+// address would hand a stale plan to a different program that numpy later allocates at the same address.  The cache is small and
+// bounded (a process holds a few dozen recursion shapes); at the bound it is emptied -- plans in use are kept alive by shared_ptr.
 static std::mutex g_plan_mutex;
-static std::map<std::pair<const u32 *, u64>, LevelPlan *> g_plans;
+struct PlanKey {
+    u64 hash, code_len;
+    u32 n_slots, n_inputs;
+    bool operator<(const PlanKey &o) const {
+        return std::tie(hash, code_len, n_slots, n_inputs) < std::tie(o.hash, o.code_len, o.n_slots, o.n_inputs);
+    }
+};
+static std::map<PlanKey, std::shared_ptr<LevelPlan>> g_plans;
+#define ZKLC_MAX_LEVEL_PLANS 256
 
-static const LevelPlan *level_plan(const u32 *code, u64 code_len, u32 n_slots) {
+// nullptr: the program reads a slot that neither an earlier instruction writes nor the inputs provide -- the serial runner reports
+// that as "input not available"; levelled, the reader could land beside its writer.  The caller then uses the serial runner.
+static std::shared_ptr<LevelPlan> level_plan(const u32 *code, u64 code_len, u32 n_slots, const u32 *in_slots, u32 n_inputs) {
+    u64 h = 1469598103934665603ULL;
+    for (u64 i = 0; i < code_len; i++) h = (h ^ code[i]) * 1099511628211ULL;
+    for (u32 i = 0; i < n_inputs; i++) h = (h ^ in_slots[i]) * 1099511628211ULL;
+    const PlanKey key = {h, code_len, n_slots, n_inputs};
     std::lock_guard<std::mutex> lk(g_plan_mutex);
-    auto key = std::make_pair(code, code_len);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) return it->second;
-    LevelPlan *pl = new LevelPlan();
+    std::shared_ptr<LevelPlan> pl = std::make_shared<LevelPlan>();
     std::vector<u32> slot_level(n_slots, 0), level;
     std::vector<char> written(n_slots, 0);
+    for (u32 i = 0; i < n_inputs; i++)
+        if (in_slots[i] < n_slots) written[in_slots[i]] = 1;            // available at level 0
     u64 ip = 0, pp = 0;
     u32 max_level = 0;
     while (ip < code_len) {
         u32 np = code[ip + 1], ni = code[ip + 2], no = code[ip + 3];
         const u32 *is = code + ip + 4, *os = is + ni;
         u32 lv = 0;
-        for (u32 i = 0; i < ni; i++) lv = lv > slot_level[is[i]] ? lv : slot_level[is[i]];
+        for (u32 i = 0; i < ni; i++) {
+            if (!written[is[i]]) return nullptr;                          // read before any writer: not a levelled program
+            lv = lv > slot_level[is[i]] ? lv : slot_level[is[i]];
+        }
         lv += 1;
         for (u32 i = 0; i < no; i++)
             if (written[os[i]] && lv <= slot_level[os[i]]) lv = slot_level[os[i]] + 1;    // a second writer compares: after the first
@@ -158,6 +181,7 @@ static const LevelPlan *level_plan(const u32 *code, u64 code_len, u32 n_slots) {
     pl->order.resize(n);
     std::vector<u32> cursor(count.begin(), count.end() - 1);
     for (u32 i = 0; i < n; i++) pl->order[cursor[level[i]]++] = i;
+    if (g_plans.size() >= ZKLC_MAX_LEVEL_PLANS) g_plans.clear();
     g_plans[key] = pl;
     return pl;
 }
@@ -274,7 +298,7 @@ extern "C" int32_t zklc_plonky2_witness_run(const uint32_t *code, uint64_t code_
     if (threads == 0) threads = 1;
     // one witness, several threads: the levelled form (the serial fold chain); several witnesses: one thread each
     const u32 level_threads = (n_witnesses == 1 && threads > 1) ? (threads > 16 ? 16 : threads) : 1;
-    const LevelPlan *plan = level_threads > 1 ? level_plan(code, code_len, n_slots) : nullptr;
+    const std::shared_ptr<LevelPlan> plan = level_threads > 1 ? level_plan(code, code_len, n_slots, input_slots, n_inputs) : nullptr;
     if (threads > n_witnesses) threads = n_witnesses ? n_witnesses : 1;
     std::atomic<u32> next(0);
     auto worker = [&]() {

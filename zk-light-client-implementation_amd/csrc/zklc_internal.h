@@ -74,6 +74,27 @@ int32_t zklc_stage(zklc_ctx *ctx, int slot, size_t bytes, void **out);
 // *_dev entry points launch on exactly the hipStream_t they are given (NULL = the legacy default stream)
 inline hipStream_t zklc_pick_stream(zklc_ctx *, void *s) { return (hipStream_t)s; }
 
+
+// hipFuncSetAttribute (e.g. more than 64 KiB of dynamic LDS) applies to the CURRENT device only: run `set` once per device of this
+// process, not once per process (a process that drives two GPUs would otherwise launch on the second one without the attribute)
+#include <mutex>
+template <class Fn>
+inline hipError_t zklc_once_per_device(Fn set) {
+    static std::mutex m;
+    static bool done[64];
+    static hipError_t res[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return set();
+    std::lock_guard<std::mutex> lk(m);
+    if (!done[dev]) {
+        res[dev] = set();
+        done[dev] = true;
+    }
+    return res[dev];
+}
+
 // subsystem initialisers (called by zklc_init)
 int32_t zklc_ed25519_init(zklc_ctx *ctx);
 void zklc_ed25519_fini(zklc_ctx *ctx);
