@@ -64,14 +64,19 @@ def load_or_build(name, key, build):
                   file=sys.stderr)
     data, aux = build()
     assert data._program is not None, "compile the witness program before caching a circuit"
-    os.makedirs(d, exist_ok=True)
-    fd, tmp = tempfile.mkstemp(dir=d, suffix=".tmp")
-    try:
+    tmp = None
+    try:                                       # the cache is an optimisation: a read-only or full directory must not stop a proof
+        os.makedirs(d, exist_ok=True)
+        fd, tmp = tempfile.mkstemp(dir=d, suffix=".tmp")
         with os.fdopen(fd, "wb") as f:
             pickle.dump((data, aux), f, protocol=5)
         os.replace(tmp, path)              # atomic: concurrent processes never see a partial entry
-    except Exception:
-        if os.path.exists(tmp):
-            os.unlink(tmp)
-        raise
+    except OSError as e:
+        import sys
+        print("zklc circuit cache: entry %s not written (%s: %s)" % (os.path.basename(path), type(e).__name__, e), file=sys.stderr)
+        if tmp and os.path.exists(tmp):
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
     return data, aux, False
