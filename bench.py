@@ -168,7 +168,7 @@ def pmc_traffic(n):
 VALU_INT_PEAK_TLOPS = 37.7    # measured issue ceiling of the multi-pass integer class (v_mad_u64_u32, carry adds): profiles/r02_valu_ubench.txt
 VALU_FAST_PEAK_TLOPS = 62.0   # measured issue rate of the single-pass class (v_mov / v_add_u32 / v_xor / 32-bit shifts), same file
 # static share of single-pass instructions in each priced kernel (tools/valu_mix.py over the shipped code objects, profiles/r04_valu_mix.txt)
-VALU_FAST_SHARE = {"poseidon": 0.001, "lde": 0.192, "msm": 0.202}
+VALU_FAST_SHARE = {"poseidon": 0.001, "lde": 0.136, "msm": 0.202}
 
 
 def poseidon_pmc():

@@ -250,11 +250,13 @@ ZKLC_D void gl_ntt_group_lds(u64 *tile, const u64 *__restrict__ tabJ, u64 nj, u3
     u64 x[M], t[M - 1 > 0 ? M - 1 : 1];
 #pragma unroll
     for (int m = 1; m < M; m++) t[m - 1] = tabJ[(u64)(m - 1) * nj];
+    // NTT_TJ is additive over disjoint bit fields: the lane's part once, the group-index part is wave-uniform (scalar)
+    const u32 tjb = NTT_TJ(base);
 #pragma unroll
-    for (int m = 0; m < M; m++) x[m] = tile[NTT_TJ(base | ((u32)m << pb_low))];
+    for (int m = 0; m < M; m++) x[m] = tile[tjb + NTT_TJ((u32)m << pb_low)];
     gl_ntt_group_regs<G, DIT, INV>(x, t);
 #pragma unroll
-    for (int m = 0; m < M; m++) tile[NTT_TJ(base | ((u32)m << pb_low))] = x[m];
+    for (int m = 0; m < M; m++) tile[tjb + NTT_TJ((u32)m << pb_low)] = x[m];
 }
 
 template <bool DIT, bool INV>
@@ -285,17 +287,24 @@ gl_ntt_pass_g4_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t 
     // tile load, eight elements of a lane at a time with all eight global loads in flight (one load -> wait -> LDS write per
     // iteration exposed the HBM latency sixteen times per tile: 39 % of the wave cycles were SQ_WAIT_ANY).  The zero padding of an
     // LDE (7 of 8 elements of its first pass) issues no load.
+    // Index arithmetic (round 4): element e = tid | hi with hi a multiple of the (power-of-two) workgroup size; global_index scatters
+    // disjoint bit fields of e to disjoint bit fields of the global index and NTT_TJ is additive over them, so the lane's part is
+    // computed ONCE (g_tid, lds_tid) and the `hi` part of every element is wave-uniform scalar work: one OR per element instead of
+    // re-deriving three bit fields (~12 % of the pass's VALU instructions went into these index computations).
+    const u64 g_tid = global_index(tid);
+    const u32 lds_tid = NTT_TJ(tid);
+    const bool lane_in = tid < (u32)tile_n;               // tiles smaller than the workgroup (small transforms)
     {
         constexpr int LD = 8;
         const u64 lim = 1ULL << p.log_in;
-        for (u32 e0 = tid; e0 < (u32)tile_n; e0 += LD * n_threads) {
+        for (u32 hi0 = 0; hi0 < (u32)tile_n; hi0 += LD * n_threads) {
             u64 g[LD], v[LD], sh[LD], sl[LD];
 #pragma unroll
             for (int q = 0; q < LD; q++) {
-                const u32 e = e0 + q * n_threads;
-                g[q] = global_index(e < (u32)tile_n ? e : tid);
+                const u32 hi = hi0 + q * n_threads;                      // wave-uniform
+                g[q] = hi < (u32)tile_n ? (g_tid | global_index(hi)) : g_tid;
                 v[q] = 0;
-                if (g[q] < lim) v[q] = src[g[q]];          // predicated, still all in flight: nothing below waits before the batch is issued
+                if (lane_in && g[q] < lim) v[q] = src[g[q]];          // predicated, still all in flight: nothing below waits before the batch is issued
             }
             if (p.scale_shift) {
 #pragma unroll
@@ -307,11 +316,11 @@ gl_ntt_pass_g4_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t 
             }
 #pragma unroll
             for (int q = 0; q < LD; q++) {
-                const u32 e = e0 + q * n_threads;
-                if (e >= (u32)tile_n) continue;
+                const u32 hi = hi0 + q * n_threads;
+                if (hi >= (u32)tile_n || !lane_in) continue;
                 u64 x = g[q] < lim ? v[q] : 0;
                 if (p.scale_shift) x = gl_mul(x, gl_mul(sh[q], sl[q]));
-                tile[NTT_TJ(e)] = x;
+                tile[lds_tid + NTT_TJ(hi)] = x;
             }
         }
     }
@@ -346,18 +355,18 @@ gl_ntt_pass_g4_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t 
 
     {
         constexpr int LD = 8;
-        for (u32 e0 = tid; e0 < (u32)tile_n; e0 += LD * n_threads) {
+        for (u32 hi0 = 0; hi0 < (u32)tile_n; hi0 += LD * n_threads) {
             u64 v[LD];
 #pragma unroll
             for (int q = 0; q < LD; q++) {
-                const u32 e = e0 + q * n_threads;
-                v[q] = tile[NTT_TJ(e < (u32)tile_n ? e : tid)];
+                const u32 hi = hi0 + q * n_threads;
+                v[q] = tile[(lane_in ? lds_tid : 0u) + (hi < (u32)tile_n ? NTT_TJ(hi) : 0u)];
             }
 #pragma unroll
             for (int q = 0; q < LD; q++) {
-                const u32 e = e0 + q * n_threads;
-                if (e >= (u32)tile_n) continue;
-                dst[global_index(e)] = p.out_scale != 1 ? gl_mul(v[q], p.out_scale) : v[q];
+                const u32 hi = hi0 + q * n_threads;
+                if (hi >= (u32)tile_n || !lane_in) continue;
+                dst[g_tid | global_index(hi)] = p.out_scale != 1 ? gl_mul(v[q], p.out_scale) : v[q];
             }
         }
     }
