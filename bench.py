@@ -552,6 +552,7 @@ def run_bn254_extras(ctx, dev, reduce_max, barrier, world):
                                  "published_cpu": "30 s per Groth16 proof on a 16-core Ryzen 9 7950X (gnark-plonky2-verifier/README.md:35-39; "
                                                   "the only number the reference publishes for this step; its circuit size is not stated)",
                                  "note": "2^22 wires / constraints, operands handed over as host arrays (PCIe inside), synthetic key"}
+    gp.close()
     return out
 
 

@@ -140,15 +140,19 @@ ZKLC_HD ec_xyzz<F> ec_double_affine(const typename F::T &x, const typename F::T 
     return r;
 }
 
-// the exceptional cases of p + (x2, y2): p at infinity, P = Q (doubling) and P = -Q.  Kept out of line: the bucket loops of the MSM
-// meet them once per bucket (the first point) or never, and inlined they doubled the loop's code and put its result through scratch.
+// the exceptional cases of p + (x2, y2): p at infinity (-> the point itself), P = Q (-> its double) and P = -Q (-> infinity); none
+// of them needs p.  Kept out of line: the bucket loops of the MSM meet them once per bucket (the first point) or never, and inlined
+// they doubled the loop's code.  The operands travel BY VALUE (registers): taken by reference they had to live in memory, and the
+// compiler hoisted the stores of the copies above the rare branch -- six scratch stores (80 bytes) on EVERY addition of the slice
+// kernel, 2.8 GB of write traffic per 2^22 multi-exponentiation (round 4, found in the WRITE_SIZE counter of the G2 kernel).
 template <class F>
 #if defined(__HIPCC__)
 __device__ __attribute__((noinline))
 #else
 static
 #endif
-void ec_add_affine_special(ec_xyzz<F> &r, const ec_xyzz<F> &p, const typename F::T &x2, const typename F::T &y2, u32 p_inf, u32 same_y) {
+ec_xyzz<F> ec_add_affine_special(typename F::T x2, typename F::T y2, u32 p_inf, u32 same_y) {
+    ec_xyzz<F> r;
     if (p_inf) {
         r.X = F::reduce(x2);
         r.Y = F::reduce(y2);
@@ -159,19 +163,20 @@ void ec_add_affine_special(ec_xyzz<F> &r, const ec_xyzz<F> &p, const typename F:
     } else {
         r = ec_infinity<F>();
     }
+    return r;
 }
 
-// p + (x2, y2), (x2, y2) affine and finite (lazy from_gnark values allowed); neg = 1 adds (x2, -y2)
+// the general case of p + (x2, y2) (madd-2008-s) and the flags of the exceptional ones: `special` = p at infinity or same x
+// (P = +-Q), `same_y` = P = Q.  The result is meaningless when `special` is set.
 template <class F>
-ZKLC_HD ec_xyzz<F> ec_add_affine(const ec_xyzz<F> &p, const typename F::T &x2, const typename F::T &y2in, u32 neg) {
+ZKLC_HD ec_xyzz<F> ec_madd_core(const ec_xyzz<F> &p, const typename F::T &x2, const typename F::T &y2, u32 &p_inf, u32 &special, u32 &same_y) {
     typedef typename F::T T;
-    T y2 = F::select(y2in, F::neg(y2in), neg);
     T U2 = F::mul(x2, p.ZZ);
     T S2 = F::mul(y2, p.ZZZ);
     T Pp = F::sub(U2, p.X);
     T R = F::sub(S2, p.Y);
-    u32 p_inf = ec_is_inf(p);
-    u32 special = p_inf | F::is_zero(Pp);  // same x: P = +-Q
+    p_inf = ec_is_inf(p);
+    special = p_inf | F::is_zero(Pp);  // same x: P = +-Q
     T PP = F::sqr(Pp);
     T PPP = F::mul(Pp, PP);
     T Q = F::mul(p.X, PP);
@@ -180,12 +185,18 @@ ZKLC_HD ec_xyzz<F> ec_add_affine(const ec_xyzz<F> &p, const typename F::T &x2, c
     r.Y = F::sub(F::mul(R, F::sub(Q, r.X)), F::mul(p.Y, PPP));
     r.ZZ = F::mul(p.ZZ, PP);
     r.ZZZ = F::mul(p.ZZZ, PPP);
-    if (special) {      // copies: only THEY have their address taken (the loop's own values stay in registers)
-        ec_xyzz<F> pc = p, rc;
-        T xc = x2, yc = y2;
-        ec_add_affine_special<F>(rc, pc, xc, yc, p_inf, F::is_zero(R));
-        r = rc;
-    }
+    same_y = 0;
+    if (special) same_y = F::is_zero(R);
+    return r;
+}
+// p + (x2, y2), (x2, y2) affine and finite (lazy from_gnark values allowed); neg = 1 adds (x2, -y2)
+template <class F>
+ZKLC_HD ec_xyzz<F> ec_add_affine(const ec_xyzz<F> &p, const typename F::T &x2, const typename F::T &y2in, u32 neg) {
+    typedef typename F::T T;
+    T y2 = F::select(y2in, F::neg(y2in), neg);
+    u32 p_inf, special, same_y;
+    ec_xyzz<F> r = ec_madd_core<F>(p, x2, y2, p_inf, special, same_y);
+    if (special) r = ec_add_affine_special<F>(x2, y2, p_inf, same_y);
     return r;
 }
 

@@ -339,6 +339,35 @@ ZKLC_HD ec_xyzz<F> msm_select_xyzz(const ec_xyzz<F> &a, const ec_xyzz<F> &b, u32
     return r;
 }
 
+// the exceptional additions of the slice loop (P = +-Q: adversarial inputs only; an accumulator at infinity after P + (-P)), out of
+// line, taking the RECORD ADDRESS instead of the operands: by value the 2 x LIMBS words went through the stack and the compiler
+// hoisted those stores above the rare branch -- scratch stores on EVERY addition (2.8 GB of writes per 2^22 multi-exponentiation)
+template <class F, bool PK>
+#if defined(__HIPCC__)
+__device__ __attribute__((noinline))
+#else
+static
+#endif
+ec_xyzz<F> msm_add_special(const i32 *cpoints, u32 ent, u32 p_inf, u32 same_y) {
+    msm_cpoint<F> raw;
+    msm_fetch_cpoint<F, PK>(raw, cpoints, ent >> 1);
+    typename F::T x, y;
+    msm_cpoint_xy<F, PK>(raw, x, y);
+    y = F::select(y, F::neg(y), ent & 1);
+    ec_xyzz<F> r;
+    if (p_inf) {
+        r.X = F::reduce(x);
+        r.Y = F::reduce(y);
+        r.ZZ = F::one();
+        r.ZZZ = F::one();
+    } else if (same_y) {
+        r = ec_double_affine<F>(F::reduce(x), F::reduce(y));
+    } else {
+        r = ec_infinity<F>();
+    }
+    return r;
+}
+
 // offsets[0 .. T): exclusive scan of the bucket sizes; E = number of entries.  One call = one lane.
 template <class F, bool PK>
 ZKLC_HD void msm_slice_lane(const i32 *cpoints, const u32 *entries, const u32 *offsets, u32 T, u32 E, u32 lane, i32 *buckets,
@@ -378,7 +407,9 @@ ZKLC_HD void msm_slice_lane(const i32 *cpoints, const u32 *entries, const u32 *o
         started.X = x;
         started.Y = y;
         started.ZZ = started.ZZZ = F::one();
-        ec_xyzz<F> sum = ec_add_affine<F>(acc, x, y, 0);
+        u32 p_inf, special, same_y;
+        ec_xyzz<F> sum = ec_madd_core<F>(acc, x, y, p_inf, special, same_y);
+        if (special & (fresh ^ 1)) sum = msm_add_special<F, PK>(cpoints, ent_cur, p_inf, same_y);
         acc = msm_select_xyzz<F>(sum, started, fresh);
         fresh = 0;
         if (e + 1 == seg_end) {                        // segment complete (a few lanes of a wave per iteration)

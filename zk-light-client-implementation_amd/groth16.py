@@ -101,7 +101,27 @@ class Groth16Prover:
         self.ws2 = torch.empty(int(lib.zklc_bn254_g2_msm_workspace_bytes(self.d_B2.shape[0])), dtype=torch.uint8, device=self.dev)
         self.wsn = torch.empty(int(lib.zklc_bn254_fr_ntt_workspace_bytes(self.log_n)), dtype=torch.uint8, device=self.dev)
         self.den = np.array(fr_to_mont_words(pow((pow(5, self.n, R) - 1) % R, R - 2, R)), dtype=np.uint64)
+        # resident operands of the Montgomery -> regular conversion of h (a pointwise (a * 1_raw - 0) * 1: see prove_words)
+        self.one_raw = torch.zeros((self.n, 4), dtype=torch.int64, device=self.dev)
+        self.one_raw[:, 0] = 1
+        self.zero = torch.zeros((self.n, 4), dtype=torch.int64, device=self.dev)
+        # the G2 multi-exponentiation runs on its own context (= HIP stream) beside the G1 ones: its slice kernel keeps one wave per
+        # SIMD (363 VGPRs) and its serial tail a handful of lanes, both of which the G1 kernels fill
+        from .context import Context
+        self.ctx2 = Context(ctx.device_id)
+        torch.cuda.synchronize(self.dev)
         self.last_ms = {}
+
+    def close(self):
+        if self.ctx2 is not None:
+            self.ctx2.close()
+            self.ctx2 = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _ntt(self, d, flags, coset):
         self.ctx._check(self.ctx._lib.zklc_bn254_fr_ntt_dev(self.ctx._h, self.ctx.stream_ptr(), d.data_ptr(), self.log_n, flags, coset,
@@ -151,37 +171,35 @@ class Groth16Prover:
         w_reg = np.ascontiguousarray(w_reg, dtype=np.uint64).reshape(self.n_wires, 4)
         d_h = self.compute_h(*abc_mont)
         t1 = time.perf_counter()
-        # h comes back in Montgomery form; the MSM wants regular scalars: one more pass through the host for this size class would
-        # cost PCIe, so the conversion is a multiplication by 1 on the device: (h * 1_regular) leaves h / 2^256 ... done by the
-        # same pointwise kernel: a <- (a * b - c) * scale with b = 1 (Montgomery of 1 is 2^256: use b = raw 1), c = 0, scale = raw 1
-        one_raw = torch.zeros((self.n, 4), dtype=torch.int64, device=self.dev)
-        one_raw[:, 0] = 1                                     # the Montgomery form of 2^-256: multiplying by it strips one factor 2^256
-        zero = torch.zeros((self.n, 4), dtype=torch.int64, device=self.dev)
+        # h comes back in Montgomery form; the MSM wants regular scalars: the conversion is a multiplication by 1 on the device with the
+        # pointwise kernel  a <- (a * b - c) * scale,  b = raw 1 (the Montgomery form of 2^-256: strips one factor 2^256), c = 0, scale = 1
         mont_one = np.array(fr_to_mont_words(1), dtype=np.uint64)
-        torch.cuda.current_stream(self.dev).synchronize()     # torch filled one_raw / zero on ITS stream; the kernels run on ctx's
-        self.ctx._check(self.ctx._lib.zklc_bn254_fr_mul_sub_scale_dev(self.ctx._h, self.ctx.stream_ptr(), d_h.data_ptr(), one_raw.data_ptr(),
-                                                                      zero.data_ptr(), mont_one.ctypes.data, self.n))
+        self.ctx._check(self.ctx._lib.zklc_bn254_fr_mul_sub_scale_dev(self.ctx._h, self.ctx.stream_ptr(), d_h.data_ptr(), self.one_raw.data_ptr(),
+                                                                      self.zero.data_ptr(), mont_one.ctypes.data, self.n))
         tail = lambda *xs: np.array([fr_to_regular_words(x) for x in xs], dtype=np.uint64)
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(self.dev)
-        sc_a = up(np.concatenate([w_reg if self.keep_a is None else w_reg[self.keep_a], tail(1, r)]))
-        sc_b = up(np.concatenate([w_reg if self.keep_b is None else w_reg[self.keep_b], tail(1, s)]))
-        torch.cuda.current_stream(self.dev).synchronize()
+        # the witness crosses PCIe ONCE; the three scalar vectors are assembled from it on the device
+        d_w = up(w_reg)
+        pick = lambda keep: d_w if keep is None else d_w[torch.from_numpy(np.nonzero(keep)[0]).to(self.dev)]
+        sc_a = torch.cat([pick(self.keep_a), up(tail(1, r))])
+        sc_b = torch.cat([pick(self.keep_b), up(tail(1, s))])
+        bs2 = torch.zeros(17, dtype=torch.int64, device=self.dev)
+        torch.cuda.current_stream(self.dev).synchronize()     # torch built the operands on ITS stream; the kernels run on the contexts'
+        self.ctx2._check(self.ctx._lib.zklc_bn254_g2_msm_dev(self.ctx2._h, self.ctx2.stream_ptr(), self.d_B2.data_ptr(), sc_b.data_ptr(),
+                                                             self.d_B2.shape[0], bs2.data_ptr(), bs2.data_ptr() + 128, self.ws2.data_ptr(),
+                                                             self.ws2.numel()))
         ar, ar_inf = self._msm1(self.d_A, sc_a, self.d_A.shape[0])
         bs1, bs1_inf = self._msm1(self.d_B1, sc_b, self.d_B1.shape[0])
-        bs2 = torch.zeros(17, dtype=torch.int64, device=self.dev)
-        torch.cuda.current_stream(self.dev).synchronize()
-        self.ctx._check(self.ctx._lib.zklc_bn254_g2_msm_dev(self.ctx._h, self.ctx.stream_ptr(), self.d_B2.data_ptr(), sc_b.data_ptr(),
-                                                            self.d_B2.shape[0], bs2.data_ptr(), bs2.data_ptr() + 128, self.ws2.data_ptr(),
-                                                            self.ws2.numel()))
         # Krs: the points Ar and Bs1 of this proof go into the two free slots before delta
         nk = self.d_KZ.shape[0]
         self.ctx.synchronize()                                # Ar, Bs1, h are complete before torch touches them
         self.d_KZ[nk - 3] = ar
         self.d_KZ[nk - 2] = bs1
-        sc_k = torch.cat([up(w_reg[1 + self.n_public:]), d_h[:self.n - 1], up(tail(s, r, (R - r * s % R) % R))])
+        sc_k = torch.cat([d_w[1 + self.n_public:], d_h[:self.n - 1], up(tail(s, r, (R - r * s % R) % R))])
         torch.cuda.current_stream(self.dev).synchronize()
         krs, krs_inf = self._msm1(self.d_KZ, sc_k, nk)
         self.ctx.synchronize()
+        self.ctx2.synchronize()
         t2 = time.perf_counter()
         if int(ar_inf[0]) or int(krs_inf[0]) or int(bs2[16]) or int(bs1_inf[0]):
             raise ValueError("groth16: a proof element is the point at infinity (degenerate key or witness)")
