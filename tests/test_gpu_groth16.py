@@ -73,3 +73,67 @@ def test_proving_key_with_infinity_points_removed(zctx):
     full = Groth16Prover(zctx, pk).prove(w, abc, 12345, 67890)
     assert Groth16Prover(zctx, compact).prove(w, abc, 12345, 67890) == full
     assert full == G.proof_to_uint256x8(G.prove(pk, r1cs, w, 12345, 67890))
+
+
+def _twist_point_outside_g2():
+    """a point of E'(Fp2) found by solving for y: with a cofactor of ~2^254 it is (overwhelmingly) not of order r"""
+    for x0 in range(1, 50):
+        r0, r1 = F._g2_rhs(x0, 1)
+        for hint in (False, True):
+            try:
+                y0, y1 = F._sqrt_fp2(r0, r1, hint)
+            except F.ProofInvalid:
+                continue
+            pt = ((x0, 1), (y0, y1))
+            assert B.g2_add(B.g2_mul(G.R - 1, pt), pt) is not None        # [r] pt != O (g2_mul reduces its scalar modulo r)
+            return pt
+    raise AssertionError("no twist point found")
+
+
+def test_groth16_verify_on_the_gpu(zctx):
+    """`groth16.Verify` (cmd/web-api.go:84) over the MSM + pairing kernels: accepts what the KAT-pinned verifier restatement accepts,
+    rejects a changed public input / proof word, and refuses points that are not group elements before any pairing."""
+    from zklc_amd.groth16 import Groth16Verifier
+    n_pub = 3
+    r1cs, wit = G.square_chain_r1cs(60, n_public=n_pub)
+    pk, vk = G.setup(r1cs, n_pub, (0x1234567891, 0xabcdef12345, 0x777766665555, 0x3133731337, 0x42424242))
+    pubs = [5, 6, 7]
+    w = wit(pubs, 11)
+    proof = G.proof_to_uint256x8(G.prove(pk, r1cs, w, 0x1234, 0x5678))
+    assert G.verify(vk, ((proof[0], proof[1]), ((proof[3], proof[2]), (proof[5], proof[4])), (proof[6], proof[7])), pubs)
+    ver = Groth16Verifier(zctx, vk)
+    assert ver.verify(proof, pubs) is True
+    assert ver.verify(proof, [5, 6, 8]) is False
+    assert ver.verify(proof, [5 + G.R, 6, 7]) is True           # public inputs are field elements
+    # kSum against the oracle's group arithmetic
+    l = vk["K"][0]
+    for x, pt in zip(pubs, vk["K"][1:]):
+        l = B.add(l, B.mul(x, pt))
+    lw, linf = ver.public_input_point(pubs)
+    assert not linf and [int(v) for v in lw] == g1_words(l)
+    with pytest.raises(ValueError):
+        ver.verify(proof, [5, 6])
+    # A replaced by another valid G1 point: the equation fails; by a point off the curve: refused
+    bad = list(proof)
+    two = B.mul(2, B.G1)
+    bad[0], bad[1] = two
+    assert ver.verify(bad, pubs) is False
+    bad[1] = (bad[1] + 1) % F.P_BN254
+    with pytest.raises(F.ProofInvalid):
+        ver.verify(bad, pubs)
+    # B on the twist but outside the r-torsion subgroup: refused by the [r - 1] B = -B test on the G2 MSM kernel
+    (x0, x1), (y0, y1) = _twist_point_outside_g2()
+    bad = list(proof)
+    bad[2], bad[3], bad[4], bad[5] = x1, x0, y1, y0
+    with pytest.raises(F.ProofInvalid, match="subgroup"):
+        ver.verify(bad, pubs)
+    # the point at infinity in the proof: refused
+    bad = list(proof)
+    bad[6] = bad[7] = 0
+    with pytest.raises(F.ProofInvalid):
+        ver.verify(bad, pubs)
+    # a verifying key with a point outside G2 is refused when the verifier is built
+    vk_bad = dict(vk)
+    vk_bad["gamma2"] = ((x0, x1), (y0, y1))
+    with pytest.raises(F.ProofInvalid):
+        Groth16Verifier(zctx, vk_bad)

@@ -208,3 +208,97 @@ class Groth16Prover:
         proof = [f(a_w[0:4]), f(a_w[4:8]), f(b_w[4:8]), f(b_w[0:4]), f(b_w[12:16]), f(b_w[8:12]), f(k_w[0:4]), f(k_w[4:8])]
         self.last_ms = {"compute_h": (t1 - t0) * 1e3, "msm": (t2 - t1) * 1e3}
         return proof
+
+
+def _g1_check(pt, what):
+    """affine G1 point (x, y) or None: coordinates reduced and on y^2 = x^3 + 3 (the cofactor of G1 is 1: on the curve = in the group)"""
+    from .formats import ProofInvalid
+    if pt is None:
+        return
+    x, y = int(pt[0]), int(pt[1])
+    if not (0 <= x < P and 0 <= y < P):
+        raise ProofInvalid("%s: coordinate not reduced" % what)
+    if (y * y - x * x * x - 3) % P:
+        raise ProofInvalid("%s: not on the curve" % what)
+
+
+def _g2_check_curve(pt, what):
+    from .formats import ProofInvalid, _g2_rhs
+    if pt is None:
+        return
+    (x0, x1), (y0, y1) = pt
+    if not all(0 <= int(v) < P for v in (x0, x1, y0, y1)):
+        raise ProofInvalid("%s: coordinate not reduced" % what)
+    r0, r1 = _g2_rhs(int(x0), int(x1))
+    if (y0 * y0 - y1 * y1 - r0) % P or (2 * y0 * y1 - r1) % P:
+        raise ProofInvalid("%s: not on the twist curve" % what)
+
+
+def g2_neg(pt):
+    return None if pt is None else (pt[0], ((P - pt[1][0]) % P, (P - pt[1][1]) % P))
+
+
+class Groth16Verifier:
+    """`groth16.Verify` (gnark-plonky2-verifier/cmd/web-api.go:84; gnark v0.9.1 backend/groth16/bn254/verify.go, un-vendored) over
+    the kernels: the proof's points are validated the way gnark validates them (`Proof.isValid`: Ar, Krs, Bs in their subgroups;
+    the decoder has already put them on the curve), the public inputs are folded into one G1 point by the MSM kernel
+    (kSum = K[0] + sum_i x_i K[i + 1]), and  e(Ar, Bs) e(Krs, -delta) e(kSum, -gamma) e(alpha, -beta) = 1  is one launch of the
+    pairing kernel.  The G2 subgroup test is a multi-exponentiation too: [r - 1] B = -B holds exactly for the points of order
+    dividing r (r - 1 < r: the kernel's reduction of scalars modulo r does not touch it, and its addition formulas hold on the whole
+    twist curve).
+
+    vk: dict with alpha1 (G1), beta2, gamma2, delta2 (G2) and K (list of n_public + 1 G1 points) as affine integer tuples --
+    the layout of oracle.groth16.setup / of `formats.vk_from_gnark_bytes`.  The key's points are validated once, here."""
+
+    def __init__(self, ctx, vk):
+        self.ctx = ctx
+        self.n_public = len(vk["K"]) - 1
+        if self.n_public < 0:
+            raise ValueError("verifying key without K[0]")
+        _g1_check(vk["alpha1"], "vk.alpha1")
+        for i, k in enumerate(vk["K"]):
+            _g1_check(k, "vk.K[%d]" % i)
+        for name in ("beta2", "gamma2", "delta2"):
+            _g2_check_curve(vk[name], "vk." + name)
+            self._g2_subgroup(vk[name], "vk." + name)
+        self.k_words = np.array([g1_words(p) for p in vk["K"]], dtype=np.uint64).reshape(-1, 8)
+        self.alpha_words = g1_words(vk["alpha1"])
+        self.neg_g2_words = [g2_words(g2_neg(vk[name])) for name in ("delta2", "gamma2", "beta2")]
+
+    def _g2_subgroup(self, pt, what):
+        from .formats import ProofInvalid
+        if pt is None:
+            return
+        out, inf = self.ctx.bn254_g2_msm(np.array([g2_words(pt)], dtype=np.uint64), np.array([fr_to_regular_words(R - 1)], dtype=np.uint64))
+        if inf or [int(v) for v in out] != g2_words(g2_neg(pt)):
+            raise ProofInvalid("%s: not in the r-torsion subgroup of the twist" % what)
+
+    def public_input_point(self, public_inputs):
+        """kSum as 8 words in gnark's layout + the infinity flag"""
+        if len(public_inputs) != self.n_public:
+            raise ValueError("invalid witness size: %d public inputs, the key has %d" % (len(public_inputs), self.n_public))
+        sc = np.array([fr_to_regular_words(1)] + [fr_to_regular_words(int(x)) for x in public_inputs], dtype=np.uint64)
+        return self.ctx.bn254_g1_msm(self.k_words, sc)
+
+    def verify(self, proof8, public_inputs):
+        """proof8: the eight integers of gnark's WriteRawTo / Verifier.sol order (A.x, A.y, B.x1, B.x0, B.y1, B.y0, C.x, C.y).
+        Returns True / False for the pairing equation; raises formats.ProofInvalid for a proof whose points are not valid group
+        elements (gnark: an error before any pairing) and ValueError for a wrong number of public inputs."""
+        from .formats import ProofInvalid
+        p = [int(v) for v in proof8]
+        if len(p) != 8:
+            raise ValueError("a Groth16 proof has eight words")
+        a, c = (p[0], p[1]), (p[6], p[7])
+        b = ((p[3], p[2]), (p[5], p[4]))
+        if a == (0, 0) or c == (0, 0) or b == ((0, 0), (0, 0)):
+            # gnark-crypto encodes infinity as all-zero coordinates; e(O, .) = 1 would drop a factor of the equation
+            raise ProofInvalid("a proof element is the point at infinity")
+        _g1_check(a, "proof.Ar")
+        _g1_check(c, "proof.Krs")
+        _g2_check_curve(b, "proof.Bs")
+        self._g2_subgroup(b, "proof.Bs")
+        l_words, l_inf = self.public_input_point(public_inputs)
+        g1 = np.array([[g1_words(a), g1_words(c), [0] * 8 if l_inf else [int(v) for v in l_words], self.alpha_words]], dtype=np.uint64)
+        g2 = np.array([[g2_words(b)] + self.neg_g2_words], dtype=np.uint64)
+        ok, _ = self.ctx.bn254_pairing_check(g1, g2, 4)
+        return bool(int(ok[0]))
