@@ -47,3 +47,30 @@ def test_cache_round_trip(tmp_path, monkeypatch):
     for key, n in ((2, 64), (1, 10)):
         d, w, _ = CC.load_or_build("sha256", key, _build(n))
         assert d._program is not None
+
+
+def test_concurrent_misses_build_once(tmp_path):
+    """the ranks of a multi-GPU job start together on a cold cache: one of them builds an entry, the others wait and load it"""
+    import subprocess
+    import sys
+    import textwrap
+    script = textwrap.dedent("""
+        import os, sys, time
+        sys.path.insert(0, %r)
+        from zklc_amd.plonky2 import sha256 as SHA
+        from zklc_amd.plonky2 import circuit_cache as CC
+        def build():
+            open(os.path.join(%r, "built-%%d" %% os.getpid()), "w").close()
+            time.sleep(1.0)                      # the others arrive while this one is building
+            data, words = SHA.sha256_circuit(10)
+            data.witness_program(list(words))
+            return data, words
+        data, words, hit = CC.load_or_build("sha256", "conc", build)
+        print("hit" if hit else "built", data.n)
+    """) % (str(__import__("pathlib").Path(__file__).resolve().parents[1]), str(tmp_path))
+    env = dict(__import__("os").environ, ZKLC_CIRCUIT_CACHE=str(tmp_path / "cache"))
+    procs = [subprocess.Popen([sys.executable, "-c", script], env=env, stdout=subprocess.PIPE, text=True) for _ in range(3)]
+    outs = [p.communicate(timeout=300)[0].split() for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    assert sorted(o[0] for o in outs) == ["built", "hit", "hit"] and len({o[1] for o in outs}) == 1
+    assert len(list(tmp_path.glob("built-*"))) == 1

@@ -7,6 +7,9 @@ the gate list, the constants and sigma matrices, the witness program (instructio
 
     ZKLC_CIRCUIT_CACHE=<dir>   enables it; unset = no file is read or written.
 
+Processes that miss the same entry at the same time (the ranks of a multi-GPU job on a cold cache) build it ONCE: the first takes an
+advisory lock beside the entry, the others wait for it and load the result.
+
 A cache entry is ONE pickle (protocol 5, numpy buffers inline) of (CircuitData without its builder, aux) so that the Target objects
 shared between `aux` and the witness program's input list stay the same objects.  The file name carries the caller's key and a
 digest of this package's circuit-building sources: any change to them invalidates every entry.  The directory is a LOCAL cache and
@@ -53,15 +56,49 @@ def load_or_build(name, key, build):
         return data, aux, False
     tag = hashlib.sha256(repr((name, key)).encode()).hexdigest()[:16]
     path = os.path.join(d, "%s-%s-%s.circuit" % (name, tag, _sources_digest()))
-    if os.path.exists(path):
-        try:
-            with open(path, "rb") as f:
-                data, aux = pickle.load(f)
-            return data, aux, True
-        except Exception as e:      # a truncated or foreign file: rebuild and replace it -- and say so, once per entry
-            import sys
-            print("zklc circuit cache: entry %s discarded (%s: %s), rebuilding" % (os.path.basename(path), type(e).__name__, e),
-                  file=sys.stderr)
+    got = _load(path)
+    if got is not None:
+        return got[0], got[1], True
+    # one builder per entry and machine: the ranks of a multi-GPU job start together on a cold cache, and eight concurrent builds
+    # of the same circuit are eight times the host memory and time of one.  The others wait on an advisory lock and load the entry.
+    lock = _lock(path)
+    try:
+        if lock is not None:
+            got = _load(path)
+            if got is not None:
+                return got[0], got[1], True
+        return _build_and_store(d, path, build)
+    finally:
+        if lock is not None:
+            lock.close()                       # releases the flock
+
+
+def _load(path):
+    if not os.path.exists(path):
+        return None
+    try:
+        with open(path, "rb") as f:
+            return pickle.load(f)
+    except Exception as e:          # a truncated or foreign file: rebuild and replace it -- and say so, once per entry
+        import sys
+        print("zklc circuit cache: entry %s discarded (%s: %s), rebuilding" % (os.path.basename(path), type(e).__name__, e),
+              file=sys.stderr)
+        return None
+
+
+def _lock(path):
+    """exclusive advisory lock on <entry>.lock, or None when the directory cannot hold one (read-only, no flock: build unlocked)"""
+    try:
+        import fcntl
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        f = open(path + ".lock", "a")
+        fcntl.flock(f, fcntl.LOCK_EX)
+        return f
+    except (OSError, ImportError):
+        return None
+
+
+def _build_and_store(d, path, build):
     data, aux = build()
     assert data._program is not None, "compile the witness program before caching a circuit"
     tmp = None
