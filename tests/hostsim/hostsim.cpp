@@ -384,6 +384,30 @@ void hostsim_p2_eval_gate(u32 type, const u32 *params, const u64 *extra, const u
     (void)n_wires;
     (void)n_consts;
 }
+// the opt-in whole-round / lazy-partial-round evaluator of the Poseidon gate (ZKLC_P2_POSEIDON_GATE=lazy; host forms of its pieces)
+void hostsim_p2_eval_poseidon_lazy(const u64 *wires, const u64 *alpha, u32 nch, u64 *acc_out) {
+    p2_vars v;
+    v.wires = wires;
+    v.consts = wires;
+    v.stride = 1;
+    v.p = 0;
+    v.nsel = 0;
+    static u32 tab[P2_MAX_CH][1024 * 6];
+    p2_consumer out;
+    out.nch = (int)nch;
+    for (int c = 0; c < P2_MAX_CH; c++) {
+        u64 a = c < (int)nch ? alpha[c] : 0, pw = 1;
+        for (int i = 0; i < 1024; i++) {
+            gl_limbs22(pw, &tab[c][6 * i]);
+            pw = gl_mul(pw, a);
+        }
+        out.apow[c] = tab[c];
+    }
+    out.reset(0);
+    p2_eval_poseidon_lazy(v, out);
+    for (u32 c = 0; c < nch; c++) acc_out[c] = out.result((int)c);
+}
+
 // the U32AddMany LDS-tile evaluator (p2_quotient_addmany_tile_kernel) walked for ONE LDE point: the four waves of the workgroup one
 // after the other per phase, the tile arrays with the kernel's [column][64 lanes] layout (lane 0 used).  variants: n x (num_addends,
 // num_ops); slots[4][2] = the host plan (position in the list or 0xFFFFFFFF).  out[v * nch + c] = sum_i alpha_c^i constraint_i of

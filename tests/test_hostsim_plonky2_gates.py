@@ -59,6 +59,53 @@ def test_gate_evaluator_matches_oracle(hostsim, g):
         assert _call(hostsim, g, wires, consts, pih, alphas) == want
 
 
+def test_poseidon_gate_lazy_form_equals_the_round_by_round_form(hostsim):
+    """p2_eval_poseidon_lazy (opt-in: full rounds as whole-round pieces, the 22 partial rounds as linear forms of the S-box wires over
+    the PGL_LAZY_* tables, loose values) against p2_eval_poseidon (the default: canonical, round by round) and the oracle, on random wires, on
+    wires at the edges of the field, and on a SATISFYING assignment (a real permutation: every constraint zero)."""
+    g = G.PoseidonGate()
+    og = OG.gate_from_id(g.id())
+    lazy = hostsim.hostsim_p2_eval_poseidon_lazy
+    lazy.restype = None
+    lazy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    rng = random.Random(77)
+    edge = [0, 1, P - 1, P - 2, (1 << 32) - 1, 1 << 32, P - (1 << 32), (1 << 63)]
+    for trial in range(40):
+        if trial < 30:
+            wires = [rng.randrange(P) for _ in range(g.num_wires)]
+        else:
+            wires = [rng.choice(edge) for _ in range(g.num_wires)]
+        wires[24] = rng.randrange(2) if trial % 2 else wires[24]
+        alphas = [rng.randrange(P), rng.randrange(P)]
+        got = _call(hostsim, g, wires, [], [0] * 4, alphas)
+        out = np.zeros(2, dtype=np.uint64)
+        wa, aa = np.array(wires, dtype=np.uint64), np.array(alphas, dtype=np.uint64)      # kept alive across the call
+        lazy(wa.ctypes.data, aa.ctypes.data, 2, out.ctypes.data)
+        assert got == [int(x) for x in out], trial
+        cs = og.eval(OG.BaseK, [], wires, [0] * 4)
+        assert got == [OG.reduce_with_powers(OG.BaseK, cs, a) for a in alphas], trial
+    # satisfying rows from the witness generator of the gate (host function of the product library): every constraint is zero
+    from zklc_amd.plonky2.prover import poseidon_gate_rows
+    from oracle import poseidon_gl as OP
+    ins = np.array([[rng.randrange(P) for _ in range(12)] for _ in range(4)], dtype=np.uint64)
+    rows = poseidon_gate_rows(ins, np.array([0, 1, 0, 1], dtype=np.uint64))
+    for inp, sw, row in zip(ins, (0, 1, 0, 1), rows):
+        x = [int(t) for t in inp]
+        if sw:
+            x = x[4:8] + x[:4] + x[8:]
+        assert [int(t) for t in row[12:24]] == OP.permute(x)
+        assert _call(hostsim, g, [int(t) for t in row], [], [0] * 4, [rng.randrange(P), rng.randrange(P)]) == [0, 0]
+        broken = [int(t) for t in row]
+        broken[65 + 13] = (broken[65 + 13] + 1) % P        # one S-box wire of the second partial block
+        assert _call(hostsim, g, broken, [], [0] * 4, [rng.randrange(P), rng.randrange(P)]) != [0, 0]
+        for wires_, zero in ((row, True), (np.array(broken, dtype=np.uint64), False)):
+            wa = np.ascontiguousarray(wires_, dtype=np.uint64)
+            aa = np.array([rng.randrange(P), rng.randrange(P)], dtype=np.uint64)
+            out = np.zeros(2, dtype=np.uint64)
+            lazy(wa.ctypes.data, aa.ctypes.data, 2, out.ctypes.data)
+            assert ([int(t) for t in out] == [0, 0]) == zero
+
+
 def test_filter_matches_oracle(hostsim):
     f = hostsim.hostsim_p2_filter
     f.restype = ctypes.c_uint64

@@ -632,6 +632,25 @@ def load_constants():
             Kq[10] = (Kq[10] + consts["rc26"][0]) % P
             Kv = [(x + consts["rc26"][j + 1]) % P for j, x in enumerate(Kv)]
         consts["blocks"].append({"w": w, "v": v, "c": c, "K": Kq, "Kv": Kv})
+    # the same lazy blocks as plain tables for the C++ evaluator of the Poseidon GATE (plonky2_gates.cuh: the S-box inputs of the
+    # partial rounds are wires there, so the rounds of a block are independent): limbs22 slots in natural order
+    def slot(k):
+        k %= P
+        return limbs22(k) + limbs22((k << 32) % P)
+    lz = {"w": [], "c": [], "v": [], "k": [], "kv": []}
+    for blk in consts["blocks"]:
+        for q in range(11):
+            for i in range(11):
+                lz["w"] += slot(blk["w"][q][i])
+            for k in range(11):
+                lz["c"] += slot(blk["c"][q][k]) if k < q else [0] * 6
+            lz["k"] += limbs22(blk["K"][q] % P)
+        for j in range(11):                      # [j][k]: the eleven slots one output word needs are consecutive
+            for k in range(11):
+                lz["v"] += slot(blk["v"][k][j])
+        for j in range(11):
+            lz["kv"] += limbs22(blk["Kv"][j] % P)
+    consts["lazy_tables"] = lz
     t_rc = []
     for layer in nxt:
         for c in layer:
@@ -661,6 +680,12 @@ def main():
              "// PGL_ASM_FINIT / PGL_ASM_PBLOCKS: multiply-accumulate slots {ka, kb, kc, k'a, k'b, k'c} (22-bit limbs of k and of 2^32 k mod p)",
              "// in the order the statements consume them, four slots per fetch (generator: MacStream).",
              c_table("PGL_ASM_RC", tables["rc"]), c_table("PGL_ASM_FINIT", tables["finit"]), c_table("PGL_ASM_PBLOCKS", tables["pblocks"]),
+             "// The lazy blocks of the partial rounds once more as plain tables (C++ evaluator of the Poseidon gate): slot = {ka, kb, kc, k'a, k'b, k'c};",
+             "// PGL_LAZY_W[b][q][i], PGL_LAZY_C[b][q][k] (k < q, zero otherwise), PGL_LAZY_V[b][j][k]: 11 x 11 slots per block b;",
+             "// PGL_LAZY_K[b][q], PGL_LAZY_KV[b][j]: three 22-bit limbs of the collected constants.",
+             c_table("PGL_LAZY_W", consts["lazy_tables"]["w"]), c_table("PGL_LAZY_C", consts["lazy_tables"]["c"]),
+             c_table("PGL_LAZY_V", consts["lazy_tables"]["v"]), c_table("PGL_LAZY_K", consts["lazy_tables"]["k"]),
+             c_table("PGL_LAZY_KV", consts["lazy_tables"]["kv"]),
              "#if defined(__HIP_DEVICE_COMPILE__)"]
     stats = []
     prog, ops, nops = build_fullround()

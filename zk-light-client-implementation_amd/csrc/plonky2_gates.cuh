@@ -27,7 +27,8 @@ enum p2_gate_type {
     P2_NOOP = 0, P2_CONSTANT, P2_PUBLIC_INPUT, P2_ARITHMETIC, P2_ARITHMETIC_EXT, P2_MUL_EXT, P2_BASE_SUM, P2_POSEIDON,
     P2_POSEIDON_MDS, P2_RANDOM_ACCESS, P2_REDUCING, P2_REDUCING_EXT, P2_EXPONENTIATION, P2_COSET_INTERPOLATION,
     P2_U32_ARITHMETIC, P2_U32_ADD_MANY, P2_U32_SUBTRACTION, P2_U32_RANGE_CHECK, P2_COMPARISON,
-    P2_U32_INTERLEAVE, P2_UNINTERLEAVE_TO_U32, P2_UNINTERLEAVE_TO_B32, P2_NUM_GATE_TYPES
+    P2_U32_INTERLEAVE, P2_UNINTERLEAVE_TO_U32, P2_UNINTERLEAVE_TO_B32, P2_NUM_GATE_TYPES,
+    P2_POSEIDON_LAZY = 100       // not a gate of the ABI: the A/B evaluator of P2_POSEIDON (ZKLC_P2_POSEIDON_GATE=lazy)
 };
 
 // mirrors zklc_plonky2_gate of include/zklc.h
@@ -258,7 +259,114 @@ ZKLC_D void p2_eval_base_sum(const V &v, u32 num_limbs, u32 base, p2_consumer &o
     for (; i < num_limbs; i++) out.emit(p2_range_product(v.w(1 + i), base));
 }
 
-// poseidon_gate.go:84-181
+// the unrolled rounds below read ~130 dwords of table each: left alone, the scheduler hoists the scalar loads of later rounds over
+// earlier ones and spills SGPRs through v_writelane / v_readlane (1 700 of them in the first build)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define P2_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define P2_SCHED_FENCE() ((void)0)
+#endif
+// poseidon_gate.go:84-181, the OPT-IN form (ZKLC_P2_POSEIDON_GATE=lazy).  The same 123 constraints as p2_eval_poseidon below with
+// ~20 % fewer instructions: the S-box inputs of every round but the first are WIRES, so
+//   * the eight full rounds are the hand-scheduled statements of the hash kernel (poseidon_gl_asm.inc; the constraint
+//     "computed - wire" and the switch to the wire value sit between two statements) -- on the host the loose C++ forms;
+//   * the 22 partial rounds are not a chain: z_k = wire_k^7 is known up front, and in the lazy form of the hash kernel the value a
+//     round computes for the next S-box input is a linear form  25 z_q + K_q + <u, w_q> + sum_{k<q} z_k c_q[k]  of the block's inputs --
+//     carry-free multiply-accumulates over the 22-bit-limb tables PGL_LAZY_* (six v_mad_u64_u32 per product, one reduction per
+//     constraint instead of one per product);
+//   * constraints are emitted as loose values (the consumer multiplies 32-bit halves).
+// Measured (profiles/r04t_*): proof bytes equal to the C prover's, quotient phase of the 2^18 x 234 shape 12.76 -> 12.51 ms -- a
+// tenth of what the instruction count promises: the statements clobber s[32:100], the compiler keeps its long-lived scalars (table
+// and alpha-power pointers) in spilled lanes (1 100 v_readlane), and the unrolled partial rounds make 110 KB of code for a 64 KB
+// instruction cache.  Not the default until the partial rounds are a generated statement too.
+template <class V>
+ZKLC_D void p2_eval_poseidon_lazy(const V &v, p2_consumer &out) {
+    u64 swap = v.w(24);
+    out.emit(gl_mul(swap, gl_sub(swap, 1)));
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 lhs = v.w(i), rhs = v.w(i + 4), delta = v.w(25 + i);
+        out.emit(gl_sub(gl_mul(swap, gl_sub(rhs, lhs)), delta));
+        s[i] = gl_add(lhs, delta);
+        s[i + 4] = gl_sub(rhs, delta);
+    }
+#pragma unroll
+    for (int i = 8; i < 12; i++) s[i] = v.w(i);
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add_lc(s[i], PGL_RC[i]);
+    // eight iterations "constraints of this round's S-box inputs, then the round": it = 0..3 the first half (the 4th merged with the
+    // initial matrix and followed by the partial rounds), it = 4..7 the second half; every round leaves the NEXT S-box inputs
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (int it = 0; it < 8; it++) {
+        if (it != 0) {
+            const u32 w0 = it < 4 ? 29 + 12 * (it - 1) : 87 + 12 * (it - 4);
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                u64 sin = v.w(w0 + i);
+                out.emit(gl_sub(s[i], sin));
+                s[i] = sin;
+            }
+        }
+        if (it != 3) {
+            pgl_gate_full_round(s, it);
+            continue;
+        }
+        pgl_gate_full_round_init(s);
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+        for (int b = 0; b < 2; b++) {
+            u64 z[11];
+#if defined(__HIPCC__)
+#pragma clang loop unroll(full)
+#endif
+            for (int q = 0; q < 11; q++) {
+                u64 sin = v.w(65 + 11 * b + q);
+                out.emit(gl_sub(s[0], sin));
+                z[q] = pgl_sbox_l(sin);
+                gl_acc3 acc;
+                const u32 kq = (11 * b + q) * 3, row = (11 * b + q) * 66;
+                acc.c0 = PGL_LAZY_K[kq] + (u64)(u32)z[q] * 25;
+                acc.c1 = PGL_LAZY_K[kq + 1] + (u64)(u32)(z[q] >> 32) * (25u << 10);      // 2^32 = 2^22 2^10
+                acc.c2 = PGL_LAZY_K[kq + 2];
+#pragma unroll
+                for (int i = 0; i < 11; i++) {
+                    gl_acc3_mul(acc, s[1 + i], PGL_LAZY_W + row + 6 * i);
+                    if ((i & 3) == 3) P2_SCHED_FENCE();      // table fetches in groups of four slots (24 SGPRs), like the hash kernel's
+                }
+#pragma unroll
+                for (int k = 0; k < q; k++) {
+                    gl_acc3_mul(acc, z[k], PGL_LAZY_C + row + 6 * k);
+                    if ((k & 3) == 3) P2_SCHED_FENCE();
+                }
+                s[0] = gl_acc3_reduce(acc);
+                P2_SCHED_FENCE();          // keep the table fetches of a round inside the round (SGPR budget)
+            }
+#pragma unroll
+            for (int j = 0; j < 11; j++) {
+                gl_acc3 acc;
+                const u32 kv = (11 * b + j) * 3;
+                acc.c0 = PGL_LAZY_KV[kv] + (u64)(u32)s[1 + j];
+                acc.c1 = PGL_LAZY_KV[kv + 1] + ((u64)(u32)(s[1 + j] >> 32) << 10);
+                acc.c2 = PGL_LAZY_KV[kv + 2];
+#pragma unroll
+                for (int k = 0; k < 11; k++) {
+                    gl_acc3_mul(acc, z[k], PGL_LAZY_V + (11 * b + j) * 66 + 6 * k);
+                    if ((k & 3) == 3) P2_SCHED_FENCE();
+                }
+                s[1 + j] = gl_acc3_reduce(acc);
+                P2_SCHED_FENCE();
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) out.emit(gl_sub(s[i], v.w(12 + i)));
+}
+
+// poseidon_gate.go:84-181, round by round in canonical arithmetic: the default evaluator
 template <class V>
 ZKLC_D void p2_eval_poseidon(const V &v, p2_consumer &out) {
     u64 swap = v.w(24);
