@@ -385,7 +385,7 @@ void hostsim_p2_eval_gate(u32 type, const u32 *params, const u64 *extra, const u
     (void)n_consts;
 }
 // the opt-in whole-round / lazy-partial-round evaluator of the Poseidon gate (ZKLC_P2_POSEIDON_GATE=lazy; host forms of its pieces)
-void hostsim_p2_eval_poseidon_lazy(const u64 *wires, const u64 *alpha, u32 nch, u64 *acc_out) {
+void hostsim_p2_eval_poseidon_lazy(const u64 *wires, const u64 *alpha, u32 nch, u64 *acc_out, u32 mode) {
     p2_vars v;
     v.wires = wires;
     v.consts = wires;
@@ -404,7 +404,10 @@ void hostsim_p2_eval_poseidon_lazy(const u64 *wires, const u64 *alpha, u32 nch, 
         out.apow[c] = tab[c];
     }
     out.reset(0);
-    p2_eval_poseidon_lazy(v, out);
+    if (mode & 1)
+        p2_eval_poseidon_lazy<p2_vars, 1>(v, out);
+    else
+        p2_eval_poseidon_lazy<p2_vars, 0>(v, out);
     for (u32 c = 0; c < nch; c++) acc_out[c] = out.result((int)c);
 }
 

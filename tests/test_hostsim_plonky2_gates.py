@@ -67,7 +67,7 @@ def test_poseidon_gate_lazy_form_equals_the_round_by_round_form(hostsim):
     og = OG.gate_from_id(g.id())
     lazy = hostsim.hostsim_p2_eval_poseidon_lazy
     lazy.restype = None
-    lazy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    lazy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
     rng = random.Random(77)
     edge = [0, 1, P - 1, P - 2, (1 << 32) - 1, 1 << 32, P - (1 << 32), (1 << 63)]
     for trial in range(40):
@@ -80,8 +80,9 @@ def test_poseidon_gate_lazy_form_equals_the_round_by_round_form(hostsim):
         got = _call(hostsim, g, wires, [], [0] * 4, alphas)
         out = np.zeros(2, dtype=np.uint64)
         wa, aa = np.array(wires, dtype=np.uint64), np.array(alphas, dtype=np.uint64)      # kept alive across the call
-        lazy(wa.ctypes.data, aa.ctypes.data, 2, out.ctypes.data)
-        assert got == [int(x) for x in out], trial
+        for mode in (0, 1):       # unrolled / rolled partial rounds
+            lazy(wa.ctypes.data, aa.ctypes.data, 2, out.ctypes.data, mode)
+            assert got == [int(x) for x in out], (trial, mode)
         cs = og.eval(OG.BaseK, [], wires, [0] * 4)
         assert got == [OG.reduce_with_powers(OG.BaseK, cs, a) for a in alphas], trial
     # satisfying rows from the witness generator of the gate (host function of the product library): every constraint is zero
@@ -102,8 +103,9 @@ def test_poseidon_gate_lazy_form_equals_the_round_by_round_form(hostsim):
             wa = np.ascontiguousarray(wires_, dtype=np.uint64)
             aa = np.array([rng.randrange(P), rng.randrange(P)], dtype=np.uint64)
             out = np.zeros(2, dtype=np.uint64)
-            lazy(wa.ctypes.data, aa.ctypes.data, 2, out.ctypes.data)
-            assert ([int(t) for t in out] == [0, 0]) == zero
+            for mode in (0, 1):
+                lazy(wa.ctypes.data, aa.ctypes.data, 2, out.ctypes.data, mode)
+                assert ([int(t) for t in out] == [0, 0]) == zero
 
 
 def test_filter_matches_oracle(hostsim):

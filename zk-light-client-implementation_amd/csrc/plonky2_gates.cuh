@@ -28,7 +28,7 @@ enum p2_gate_type {
     P2_POSEIDON_MDS, P2_RANDOM_ACCESS, P2_REDUCING, P2_REDUCING_EXT, P2_EXPONENTIATION, P2_COSET_INTERPOLATION,
     P2_U32_ARITHMETIC, P2_U32_ADD_MANY, P2_U32_SUBTRACTION, P2_U32_RANGE_CHECK, P2_COMPARISON,
     P2_U32_INTERLEAVE, P2_UNINTERLEAVE_TO_U32, P2_UNINTERLEAVE_TO_B32, P2_NUM_GATE_TYPES,
-    P2_POSEIDON_LAZY = 100       // not a gate of the ABI: the A/B evaluator of P2_POSEIDON (ZKLC_P2_POSEIDON_GATE=lazy)
+    P2_POSEIDON_LAZY = 100       // 100 + MODE, not gates of the ABI: the A/B evaluators of P2_POSEIDON (ZKLC_P2_POSEIDON_GATE=lazy | lazy1)
 };
 
 // mirrors zklc_plonky2_gate of include/zklc.h
@@ -279,8 +279,15 @@ ZKLC_D void p2_eval_base_sum(const V &v, u32 num_limbs, u32 base, p2_consumer &o
 // tenth of what the instruction count promises: the statements clobber s[32:100], the compiler keeps its long-lived scalars (table
 // and alpha-power pointers) in spilled lanes (1 100 v_readlane), and the unrolled partial rounds make 110 KB of code for a 64 KB
 // instruction cache.  Not the default until the partial rounds are a generated statement too.
-template <class V>
+// MODE bit 0: the partial rounds as ROLLED loops over per-lane arrays in LDS (z_k and the block's inputs u_i: a few hundred
+// instructions of code instead of 8 000 unrolled ones, 60 spill instructions instead of 1 500) -- measured SLOWER (2.86 ms against
+// 2.73 unrolled and 2.80 of the default: latency of the per-iteration table fetches at three waves per SIMD, 45 KB of LDS per
+// workgroup); bit 1 (full rounds from the loose C++ forms instead of the statements) is not instantiated: 6.1 ms.
+// profiles/r04y_poseidon_gate_variants.txt
+#define P2_LAZY_THREADS 256
+template <class V, int MODE>
 ZKLC_D void p2_eval_poseidon_lazy(const V &v, p2_consumer &out) {
+    constexpr bool ROLLED = (MODE & 1) != 0, ASM = (MODE & 2) == 0;
     u64 swap = v.w(24);
     out.emit(gl_mul(swap, gl_sub(swap, 1)));
     u64 s[12];
@@ -311,10 +318,74 @@ ZKLC_D void p2_eval_poseidon_lazy(const V &v, p2_consumer &out) {
             }
         }
         if (it != 3) {
-            pgl_gate_full_round(s, it);
+            pgl_gate_full_round<ASM>(s, it);
             continue;
         }
-        pgl_gate_full_round_init(s);
+        pgl_gate_full_round_init<ASM>(s);
+        if constexpr (ROLLED) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            __shared__ u64 lz_sh[22 * P2_LAZY_THREADS];
+            u64 *lz = lz_sh + threadIdx.x;
+#define P2_LZ(k) lz[(k) * P2_LAZY_THREADS]
+#else
+            u64 lz[22];
+#define P2_LZ(k) lz[k]
+#endif
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+            for (int b = 0; b < 2; b++) {
+#pragma unroll
+                for (int i = 0; i < 11; i++) P2_LZ(11 + i) = s[1 + i];
+                u64 s0 = s[0];
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+                for (int q = 0; q < 11; q++) {
+                    u64 sin = v.w(65 + 11 * b + q);
+                    out.emit(gl_sub(s0, sin));
+                    u64 zq = pgl_sbox_l(sin);
+                    P2_LZ(q) = zq;
+                    gl_acc3 acc;
+                    const u32 kq = (11 * b + q) * 3, row = (11 * b + q) * 66;
+                    acc.c0 = PGL_LAZY_K[kq] + (u64)(u32)zq * 25;
+                    acc.c1 = PGL_LAZY_K[kq + 1] + (u64)(u32)(zq >> 32) * (25u << 10);
+                    acc.c2 = PGL_LAZY_K[kq + 2];
+#pragma unroll
+                    for (int i = 0; i < 11; i++) {
+                        gl_acc3_mul(acc, P2_LZ(11 + i), PGL_LAZY_W + row + 6 * i);
+                        if ((i & 3) == 3) P2_SCHED_FENCE();
+                    }
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+                    for (int k = 0; k < q; k++) gl_acc3_mul(acc, P2_LZ(k), PGL_LAZY_C + row + 6 * k);
+                    s0 = gl_acc3_reduce(acc);
+                }
+                s[0] = s0;
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+                for (int j = 0; j < 11; j++) {
+                    gl_acc3 acc;
+                    const u32 kv = (11 * b + j) * 3;
+                    const u64 uj = P2_LZ(11 + j);
+                    acc.c0 = PGL_LAZY_KV[kv] + (u64)(u32)uj;
+                    acc.c1 = PGL_LAZY_KV[kv + 1] + ((u64)(u32)(uj >> 32) << 10);
+                    acc.c2 = PGL_LAZY_KV[kv + 2];
+#pragma unroll
+                    for (int k = 0; k < 11; k++) {
+                        gl_acc3_mul(acc, P2_LZ(k), PGL_LAZY_V + (11 * b + j) * 66 + 6 * k);
+                        if ((k & 3) == 3) P2_SCHED_FENCE();
+                    }
+                    P2_LZ(11 + j) = gl_acc3_reduce(acc);
+                }
+#pragma unroll
+                for (int i = 0; i < 11; i++) s[1 + i] = P2_LZ(11 + i);
+            }
+#undef P2_LZ
+            continue;
+        }
 #if defined(__HIPCC__)
 #pragma unroll 1
 #endif
