@@ -1,0 +1,47 @@
+"""Host-side pieces of zklc_amd/pipeline.py that need no GPU: `BlockWindow` = the arguments of `prove_block_bft`
+(near_bft_finality/src/prove_bft/bft.rs:38-62) read from the mainnet fixtures, its approval sets (bft.rs:264-316, :317-500) and the
+public inputs of the final proofs (bft.rs:470-500)."""
+import glob
+import json
+import os
+
+import pytest
+
+from zklc_amd import signatures as SG
+from zklc_amd.pipeline import BlockWindow
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "block_window_*.json")))
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=os.path.basename)
+def test_block_window_from_the_fixtures(path):
+    win = BlockWindow.from_fixture(json.load(open(path)))
+    n = len(win.blocks)
+    assert n in (5, 6)
+    args, kw = win.bft_args()
+    assert len(args) == 5 and args[4] is win.blocks and (n == 6) == bool(kw)
+    sets = win.approval_sets()
+    assert len(sets) == n - 4
+    b = win.blocks
+    # the approvals of a block's successor header sign (parent hash, parent height, target height) of the block being finalised
+    msg, approvals, validators = sets[0]
+    assert msg == SG.generate_signed_message(b[4][0]["height"], b[3][0]["height"], b[3][0]["prev_hash"])
+    assert len(msg) == 41 and msg[0] == 0 and msg[1:33] == b[3][0]["prev_hash"]
+    assert approvals is b[3][0]["approvals"] and validators is win.validators and len(approvals) == len(validators)
+    if n == 6:
+        msg1, approvals1, validators1 = sets[1]
+        assert msg1[1:33] == b[4][0]["prev_hash"] and approvals1 is b[4][0]["approvals"] and validators1 is win.validators_n_1
+    pis = win.expected_public_inputs()
+    assert len(pis) == n - 4 and all(len(p) == 97 and p[0] == (1 if n == 6 else 0) for p in pis)
+    assert bytes(pis[0][1:33]) == b[4][0]["hash"] and bytes(pis[0][33:65]) == win.ep2_last_block[1]
+    # the hash of a block is the hash of its borsh bytes' pieces: the fixture's fields are consistent with its bytes
+    from zklc_amd import header_bphash as H
+    if hasattr(H, "block_hash_from_bytes"):
+        assert H.block_hash_from_bytes(b[4][1]) == b[4][0]["hash"]
+
+
+def test_block_window_rejects_other_lengths():
+    win = BlockWindow.from_fixture(json.load(open(FIXTURES[0])))
+    with pytest.raises(ValueError, match="Invalid blocks.len"):
+        BlockWindow(win.ep2_last_block, win.ep1_first_block, win.blocks[:4], win.validators)

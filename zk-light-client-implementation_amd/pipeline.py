@@ -3,7 +3,7 @@
 Reference: near_bft_finality/src/prove_bft/bft.rs:38-500 (`prove_block_bft`), prove_block_data/signatures.rs:43-141
 (`prove_approvals`; :144-274 is its NATS fan-out, which this replaces on a node), bin/prove_block.rs:279-287 (the BN128 wrap).
 `prove_bft.BlockProver` is the reference's sequential driver restated; this module runs the SAME nodes of the SAME DAG -- the
-proofs are byte-identical to the sequential driver's (tests/test_gpu_pipeline.py) -- on concurrent host threads, each with its own
+proofs are byte-identical to the sequential driver's (tests/test_gpu_stream_pipeline.py) -- on concurrent host threads, each with its own
 zklc context (= HIP stream), so that the GPU always has several proofs in flight:
 
   signature stage (per approval set)
