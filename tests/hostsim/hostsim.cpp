@@ -404,7 +404,9 @@ void hostsim_p2_eval_poseidon_lazy(const u64 *wires, const u64 *alpha, u32 nch, 
         out.apow[c] = tab[c];
     }
     out.reset(0);
-    if (mode & 1)
+    if (mode == 2)
+        p2_eval_poseidon_loose(v, out);
+    else if (mode & 1)
         p2_eval_poseidon_lazy<p2_vars, 1>(v, out);
     else
         p2_eval_poseidon_lazy<p2_vars, 0>(v, out);

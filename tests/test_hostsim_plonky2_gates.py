@@ -80,7 +80,7 @@ def test_poseidon_gate_lazy_form_equals_the_round_by_round_form(hostsim):
         got = _call(hostsim, g, wires, [], [0] * 4, alphas)
         out = np.zeros(2, dtype=np.uint64)
         wa, aa = np.array(wires, dtype=np.uint64), np.array(alphas, dtype=np.uint64)      # kept alive across the call
-        for mode in (0, 1):       # unrolled / rolled partial rounds
+        for mode in (0, 1, 2):    # lazy with unrolled / rolled partial rounds, loose round by round
             lazy(wa.ctypes.data, aa.ctypes.data, 2, out.ctypes.data, mode)
             assert got == [int(x) for x in out], (trial, mode)
         cs = og.eval(OG.BaseK, [], wires, [0] * 4)
@@ -103,7 +103,7 @@ def test_poseidon_gate_lazy_form_equals_the_round_by_round_form(hostsim):
             wa = np.ascontiguousarray(wires_, dtype=np.uint64)
             aa = np.array([rng.randrange(P), rng.randrange(P)], dtype=np.uint64)
             out = np.zeros(2, dtype=np.uint64)
-            for mode in (0, 1):
+            for mode in (0, 1, 2):
                 lazy(wa.ctypes.data, aa.ctypes.data, 2, out.ctypes.data, mode)
                 assert ([int(t) for t in out] == [0, 0]) == zero
 

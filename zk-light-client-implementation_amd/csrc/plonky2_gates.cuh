@@ -28,7 +28,8 @@ enum p2_gate_type {
     P2_POSEIDON_MDS, P2_RANDOM_ACCESS, P2_REDUCING, P2_REDUCING_EXT, P2_EXPONENTIATION, P2_COSET_INTERPOLATION,
     P2_U32_ARITHMETIC, P2_U32_ADD_MANY, P2_U32_SUBTRACTION, P2_U32_RANGE_CHECK, P2_COMPARISON,
     P2_U32_INTERLEAVE, P2_UNINTERLEAVE_TO_U32, P2_UNINTERLEAVE_TO_B32, P2_NUM_GATE_TYPES,
-    P2_POSEIDON_LAZY = 100       // 100 + MODE, not gates of the ABI: the A/B evaluators of P2_POSEIDON (ZKLC_P2_POSEIDON_GATE=lazy | lazy1)
+    P2_POSEIDON_LAZY = 100,      // 100 + MODE, not gates of the ABI: the A/B evaluators of P2_POSEIDON (ZKLC_P2_POSEIDON_GATE=lazy | lazy1)
+    P2_POSEIDON_LOOSE = 110      // ZKLC_P2_POSEIDON_GATE=loose
 };
 
 // mirrors zklc_plonky2_gate of include/zklc.h
@@ -432,6 +433,101 @@ ZKLC_D void p2_eval_poseidon_lazy(const V &v, p2_consumer &out) {
                 P2_SCHED_FENCE();
             }
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) out.emit(gl_sub(s[i], v.w(12 + i)));
+}
+
+// poseidon_gate.go:84-181, round by round like the default evaluator below but in the LOOSE arithmetic of the C++ permutation
+// (poseidon_gl.cuh: no canonicalisation between operations, the dot products of the partial rounds accumulated in 160 bits and
+// reduced once, constraints emitted as loose values).  Same loop structure and code size as the default.  Opt-in
+// (ZKLC_P2_POSEIDON_GATE=loose) until it has been through the whole GPU suite.
+template <class V>
+ZKLC_D void p2_eval_poseidon_loose(const V &v, p2_consumer &out) {
+    u64 swap = v.w(24);
+    out.emit(gl_mul(swap, gl_sub(swap, 1)));
+    u64 s[12];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        u64 lhs = v.w(i), rhs = v.w(i + 4), delta = v.w(25 + i);
+        out.emit(gl_sub(gl_mul(swap, gl_sub(rhs, lhs)), delta));
+        s[i] = gl_add(lhs, delta);
+        s[i + 4] = gl_sub(rhs, delta);
+    }
+#pragma unroll
+    for (int i = 8; i < 12; i++) s[i] = v.w(i);
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = gl_add_lc(s[i], PGL_RC[12 * r + i]);
+        if (r != 0) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                u64 sin = v.w(29 + 12 * (r - 1) + i);
+                out.emit(gl_sub(s[i], sin));
+                s[i] = sin;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) s[i] = pgl_sbox_l(s[i]);
+        pgl_mds_l(s);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) s[i] = gl_add_lc(s[i], PGL_FP_FIRST[i]);
+    {
+        // t[d] = sum_{r=1..11} s[r] * INIT[r-1][d-1]; one output per iteration, rotated into place (static register indices)
+        u64 t[12];
+#pragma unroll
+        for (int d = 1; d < 12; d++) t[d] = 0;
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+        for (int d = 1; d < 12; d++) {
+            gl_acc160 acc = {0, 0, 0};
+#pragma unroll
+            for (int r = 1; r < 12; r++) gl_acc_mul(acc, s[r], PGL_FP_INIT[(r - 1) * 11 + d - 1]);
+#pragma unroll
+            for (int q = 1; q < 11; q++) t[q] = t[q + 1];
+            t[11] = gl_acc_reduce(acc);
+        }
+#pragma unroll
+        for (int i = 1; i < 12; i++) s[i] = t[i];
+    }
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (int r = 0; r < 22; r++) {
+        u64 sin = v.w(65 + r);
+        out.emit(gl_sub(s[0], sin));
+        u64 s0 = gl_add_lc(pgl_sbox_l(sin), PGL_FP_RC[r]);  // the 22nd constant is zero (poseidon_gate.go:151-155)
+        gl_acc160 acc = {0, 0, 0};
+        gl_acc_mul(acc, s0, 25);
+#pragma unroll
+        for (int j = 1; j < 12; j++) gl_acc_mul(acc, s[j], PGL_FP_WHATS[r * 11 + j - 1]);
+#pragma unroll
+        for (int j = 1; j < 12; j++) {
+            u64 lo, hi;                                      // s[j] + s0 * v < 2^128: one reduction of the sum
+            gl_mul_wide(s0, PGL_FP_VS[r * 11 + j - 1], lo, hi);
+            u64 l2 = lo + s[j];
+            hi += (l2 < lo);
+            s[j] = gl_reduce128_loose(l2, hi);
+        }
+        s[0] = gl_acc_reduce(acc);
+    }
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            u64 x = gl_add_lc(s[i], PGL_RC[12 * (26 + r) + i]);
+            u64 sin = v.w(87 + 12 * r + i);
+            out.emit(gl_sub(x, sin));
+            s[i] = pgl_sbox_l(sin);
+        }
+        pgl_mds_l(s);
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) out.emit(gl_sub(s[i], v.w(12 + i)));

@@ -275,7 +275,9 @@ __global__ void __launch_bounds__(P2_THREADS) p2_quotient_gate_kernel(p2_quotien
         p2_gate gate = a.gates[g];
         gate.type = TYPE;
         out.reset(a.nch + a.nch * (a.npp + 1));   // the gate constraints follow the Z1 and partial-product terms
-        if constexpr (TYPE >= P2_POSEIDON_LAZY)
+        if constexpr (TYPE == P2_POSEIDON_LOOSE)
+            p2_eval_poseidon_loose(v, out);
+        else if constexpr (TYPE >= P2_POSEIDON_LAZY)
             p2_eval_poseidon_lazy<p2_vars, TYPE - P2_POSEIDON_LAZY>(v, out);   // only these instantiations carry the opt-in evaluators
         else
             p2_eval_gate(gate, v, a.extra, out);
@@ -609,6 +611,7 @@ static p2_gate_kernel_fn p2_gate_kernel_of(u32 type) {
     // A/B switch ZKLC_P2_POSEIDON_GATE=lazy: the whole-round / lazy-partial-round evaluator of the Poseidon gate (plonky2_gates.cuh:
     // measured 2 % of the quotient phase, validated on the byte-parity tests only -- opt-in)
     static const char *pg = getenv("ZKLC_P2_POSEIDON_GATE");
+    if (type == P2_POSEIDON && pg && !strcmp(pg, "loose")) return p2_quotient_gate_kernel<P2_POSEIDON_LOOSE>;
     if (type == P2_POSEIDON && pg && !strncmp(pg, "lazy", 4)) {
         // lazy: statements + unrolled partial rounds; lazy1: the partial rounds as rolled loops over per-lane LDS arrays
         return pg[4] == '1' ? p2_quotient_gate_kernel<P2_POSEIDON_LAZY + 1> : p2_quotient_gate_kernel<P2_POSEIDON_LAZY>;
