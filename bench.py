@@ -730,6 +730,8 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
 
     def block_done(r):
         tele_steps.append(dict(tele.mark(), rss_mb=rss_mb()))
+    import resource
+    cpu_all = time.process_time()
     t_all = time.perf_counter()
     if overlap:
         # exactly K complete Block_i proofs; consecutive blocks overlap by the tail of the earlier one (BlockPipeline.prove_stream)
@@ -743,6 +745,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                 block_done(r)
     barrier()
     total_s = reduce_max(time.perf_counter() - t_all)
+    cpu_all = time.process_time() - cpu_all        # user + system seconds of THIS rank's process (all threads) over the timed blocks
     block_s = total_s / steps
     tele.close()
     tele_all = {k: round(sum(t[k] for t in tele_steps if k in t) / max(1, sum(1 for t in tele_steps if k in t)), 1)
@@ -781,7 +784,9 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                       "dag_thread_counts": dict(lastr.dag_counts), "keys_stakes_thread_seconds": lastr.keys_stakes_s,
                       "wrap_proof_bytes": len(wraw), "blocks_checked": len(res_list),
                       "final_proof_verified": True, "final_proof_verify_s_untimed": t_v,
-                      "first_block_s_incl_circuit_construction": t_setup}
+                      "first_block_s_incl_circuit_construction": t_setup,
+                      "host_cpu_s_per_block": cpu_all / steps, "host_cores_busy": cpu_all / max(total_s, 1e-9),
+                      "peak_rss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0}
     if world > 1 and not strong_only and not args.no_strong_section:
         # the STRONG form of the block measured in the same run, so that one SCALE run holds both: all ranks prove
         # ONE block per step (signature shards, local folds, a binary-tree fold over the ranks, the header proofs on the other ranks,
@@ -886,7 +891,8 @@ def compact_line(full):
     blk = full.get("block_i")
     if blk:
         b = {k: r3(blk[k]) for k in ("seconds_per_block", "blocks_timed", "blocks_checked", "blocks_overlapped", "approvals", "streams",
-                                     "witness_on", "first_block_s_incl_circuit_construction", "rss_mb_after") if k in blk}
+                                     "witness_on", "first_block_s_incl_circuit_construction", "rss_mb_after", "host_cpu_s_per_block",
+                                     "host_cores_busy", "peak_rss_mb") if k in blk}
         b["per_step_s"] = [r3(x, 3) for x in blk.get("per_step_s", [])][:64]
         tm = blk.get("telemetry_mean") or {}
         b["gpu"] = {k: tm[k] for k in ("sclk_mhz", "power_w", "busy_pct", "temp_c") if k in tm}
@@ -923,9 +929,11 @@ def main():
     ap.add_argument("--verify-warmup", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=8192, help="Block_i approval sets per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-ed25519", action="store_true",
-                    help="also time ONE complete CPU proof of the Ed25519 circuit with the oracle's C prover (minutes of host time); "
-                         "without it that shape's CPU time is the measured wires commitment, the other stages scaled")
+    ap.add_argument("--cpu-baseline-ed25519", action="store_true", default=True,
+                    help="(default) time ONE complete CPU proof of the Ed25519 circuit with the oracle's C prover on the host cores "
+                         "(~40 s + 10 s preprocessing on 16 cores, ~12 GB of host memory): the block's CPU baseline is then MEASURED")
+    ap.add_argument("--no-cpu-baseline-ed25519", dest="cpu_baseline_ed25519", action="store_false",
+                    help="skip that proof: the Ed25519 shape's CPU time is then the measured wires commitment, the other stages scaled")
     ap.add_argument("--no-stages", action="store_true", help="only the headline C2 measurement")
     ap.add_argument("--msm-log", type=int, default=22, help="log2 of the MSM size per GPU")
     ap.add_argument("--no-prove", action="store_true", help="skip the plonky2 proof stage")
@@ -938,8 +946,9 @@ def main():
                     "a block's tail with the next block's signature proofs)")
     ap.add_argument("--no-strong-section", action="store_true", help="multi-GPU runs: skip the extra strong-scaling blocks after the weak region")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo lets several ranks share one GPU)")
-    ap.add_argument("--c5-validators", type=int, default=0, help="also run the C5 stage: a synthetic epoch of this many validators "
-                    "(1000 in BASELINE configs[4]; ~65 s on one MI355X), reported under stages.prove.c5_synthetic_epoch")
+    ap.add_argument("--c5-validators", type=int, default=200, help="the C5 stage: a synthetic epoch of this many validators through "
+                    "BlockPipeline.prove_approvals (default 200: ~13 s on one MI355X; 1000 = BASELINE configs[4], ~63 s; 0 skips it), "
+                    "reported under stages.prove.c5_synthetic_epoch")
     ap.add_argument("--host-witness", action="store_true", help="Ed25519-circuit witnesses from the host interpreter (threads + PCIe) instead of the GPU")
     ap.add_argument("--witness-batch", type=int, default=32, help="signatures per device witness batch (<= 64; 0.5 GB of HBM each)")
     ap.add_argument("--detail", default=os.environ.get("ZKLC_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json")),
@@ -1079,7 +1088,8 @@ def main():
                            "proofs_per_block": dict(blk["dag_thread_counts"], ed25519_circuit=blk["approvals"],
                                                     fold_and_closing_recursions=blk["approvals"], keys_stakes_and_its_hash=3, bn128_wrap=1),
                            "msm_2p22_melem_per_s": r3(stages["msm"]["value"])},
-                "roofline": dict(mk["roofline"], kernel="gl_hash_leaves_kernel (Poseidon leaf hashing: ~50 % of the kernel time of a block)",
+                "roofline": dict(mk["roofline"], kernel="gl_hash_leaves_kernel (Poseidon leaf hashing: 53 % of one proof stream's kernel time, ~20 % of the "
+                                        "summed kernel time of the overlapped block trace, the largest single kernel in both)",
                                  kernel_ms=mk["ms"]),
                 "final_proof_verified": blk["final_proof_verified"],
                 "block_i": blk, "stages": dict(stages, ed25519_verify=verify),

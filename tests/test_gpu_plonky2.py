@@ -364,3 +364,52 @@ def test_full_block_proof_on_a_mainnet_window(zctx, block_prover):
     assert bi2[2] == bi[2]
     print("full Block_i proof, circuits resident, sequential host driver: %.1f s; seconds %s"
           % (time.time() - t0, {k: round(v, 1) for k, v in bp.seconds.items()}))
+
+
+QUOTIENT_VARIANTS = [{}, {"ZKLC_P2_POSEIDON_GATE": "plain"}, {"ZKLC_P2_POSEIDON_GATE": "lazy"}, {"ZKLC_P2_POSEIDON_GATE": "lazy1"},
+                     {"ZKLC_P2_ADDMANY": "pergate"}, {"ZKLC_P2_ADDMANY": "multi"}, {"ZKLC_P2_GATE_LAUNCH": "single"},
+                     {"ZKLC_P2_QUOTIENT": "fused"}, {"ZKLC_MERKLE_FUSED": "0"}]
+
+_VARIANT_CHILD = r'''
+import hashlib, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, %(tests)r)
+import zklc_amd
+from zklc_amd.plonky2 import HASH_GL
+from test_gpu_plonky2 import _synthetic
+data, wires, pis = _synthetic("ed25519", 13, seed=5, npi=16)
+with zklc_amd.Context(0) as ctx:
+    prover = data.prover(ctx, HASH_GL)
+    print("DIGEST " + hashlib.sha256(prover.prove_bytes(wires, pis)).hexdigest())
+    prover.close()
+'''
+
+
+def test_every_quotient_evaluator_variant_gives_the_same_proof_bytes(zctx):
+    """The library reads its A/B switches once per process (ZKLC_P2_POSEIDON_GATE = loose (default) / plain / lazy / lazy1,
+    ZKLC_P2_ADDMANY = tile (default) / pergate / multi, per-gate launches, the fused quotient kernel, the per-level Merkle form):
+    one child process per setting proves the 2^13 x 234 slice of the Ed25519 shape (all 20 gate types) and every one must give
+    the bytes of the C prover (crypto/plonky2_u32/src/gates/add_many_u32.rs:270-284 and the Poseidon gate are the evaluators that
+    have variants)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from oracle import cport
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data, wires, pis = _synthetic("ed25519", 13, seed=5, npi=16)
+    want, _ = cport.plonky2_prove(data, wires, pis)
+    want = hashlib.sha256(want).hexdigest()
+    code = _VARIANT_CHILD % {"root": root, "tests": os.path.join(root, "tests")}
+    keys = sorted({k for v in QUOTIENT_VARIANTS for k in v})
+    procs = []
+    for var in QUOTIENT_VARIANTS:
+        env = {k: v for k, v in os.environ.items() if k not in keys}
+        env.update(var)
+        procs.append((var, subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                            env=env, cwd=root)))
+    for var, p in procs:
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, (var, se[-2000:])
+        got = next(ln for ln in so.splitlines() if ln.startswith("DIGEST "))[7:]
+        assert got == want, "proof bytes under %r differ from the C prover's" % (var,)

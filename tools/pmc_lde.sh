@@ -1,20 +1,21 @@
 #!/bin/bash
-# PMC passes of the C3 coset LDE (tools/lde_only.py: 234 x 2^17 -> 2^20): SQ counters, FETCH_SIZE, WRITE_SIZE in separate rocprofv3
+# PMC passes of the coset LDE (tools/lde_only.py: 234 x 2^LOGN -> 2^(LOGN+3), LOGN = $2, default 17 = C3; 18 = the product shape): SQ counters, FETCH_SIZE, WRITE_SIZE in separate rocprofv3
 # runs (--pmc only); writes gpurun_out/<tag>_lde_pmc.json (copy to profiles/lde_pmc_latest.json: bench.py reads it)
 set -u
 TAG=${1:-r03}
+LOGN=${2:-17}
 export TMPDIR=/tmp
 for pass in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_LDS" "FETCH_SIZE" "WRITE_SIZE"; do
   rm -rf gpurun_out/pmc_tmp
-  timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d gpurun_out/pmc_tmp -o pmc -- python tools/lde_only.py 3 > gpurun_out/${TAG}_pmc_lde.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d gpurun_out/pmc_tmp -o pmc -- python tools/lde_only.py 3 $LOGN > gpurun_out/${TAG}_pmc_lde.log 2>&1
   f=$(find gpurun_out/pmc_tmp -name '*counter_collection.csv' | head -1)
   cp "$f" "gpurun_out/${TAG}_pmc_lde_$(echo $pass | cut -d' ' -f1).csv"
 done
 rm -rf gpurun_out/pmc_tmp
-python - "$TAG" <<'PY'
+python - "$TAG" "$LOGN" <<'PY'
 import csv, json, sys, collections
 tag = sys.argv[1]
-out = {"shape": "234 x 2^17 -> 2^20", "kernels": {}}
+out = {"shape": "234 x 2^%d -> 2^%d" % (int(sys.argv[2]), int(sys.argv[2]) + 3), "kernels": {}}
 for name in ("SQ_INSTS_VALU", "FETCH_SIZE", "WRITE_SIZE"):
     per = collections.defaultdict(lambda: collections.defaultdict(dict))
     for r in csv.DictReader(open("gpurun_out/%s_pmc_lde_%s.csv" % (tag, name))):

@@ -152,6 +152,29 @@ struct Case {
     int ops_per_iter;  // per lane per loop iteration
 };
 
+// shader clock in MHz read from the hwmon `freq1_input` of the busiest card (Hz), 0 when sysfs has none
+#include <dirent.h>
+#include <string>
+static double read_sclk_mhz() {
+    double best = 0;
+    for (int card = 0; card < 64; card++) {
+        std::string base = "/sys/class/drm/card" + std::to_string(card) + "/device/hwmon";
+        DIR *d = opendir(base.c_str());
+        if (!d) continue;
+        while (dirent *e = readdir(d)) {
+            if (e->d_name[0] == '.') continue;
+            std::string f = base + "/" + e->d_name + "/freq1_input";
+            if (FILE *fp = fopen(f.c_str(), "r")) {
+                double hz = 0;
+                if (fscanf(fp, "%lf", &hz) == 1 && hz * 1e-6 > best) best = hz * 1e-6;
+                fclose(fp);
+            }
+        }
+        closedir(d);
+    }
+    return best;
+}
+
 int main() {
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
@@ -174,26 +197,35 @@ int main() {
         {"v_mov_b32_e32", k_mov_e32, 32},
         {"v_fma_f64", k_fma_f64, 32},          {"v_mul_f64", k_mul_f64, 32},
         {"v_add_f64", k_add_f64, 32},
+        {"v_fma_f32 (again, last)", k_fma_f32, 32},
     };
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    double fma_rate = 0;
+    // WARM-UP (round 5): ~0.5 s of work before anything is timed, so that the first case does not run on an idle clock (the round-2
+    // table had v_fma_f32 first and cold: 52 T, below the v_mov measured later in the same run)
+    for (int r = 0; r < 200; r++) hipLaunchKernelGGL(k_fma_f32, dim3(blocks), dim3(threads), 0, 0, out, 7u + r);
+    hipDeviceSynchronize();
+    printf("sclk after warm-up: %.0f MHz (hwmon freq1_input)\n", read_sclk_mhz());
+    const double simds = (double)p.multiProcessorCount * 4;
+    const int REPS = 24;
     for (auto &c : cases) {
-        hipLaunchKernelGGL(c.fn, dim3(blocks), dim3(threads), 0, 0, out, 12345u);  // warm
+        for (int r = 0; r < 4; r++) hipLaunchKernelGGL(c.fn, dim3(blocks), dim3(threads), 0, 0, out, 12345u);  // warm
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        for (int r = 0; r < 3; r++) hipLaunchKernelGGL(c.fn, dim3(blocks), dim3(threads), 0, 0, out, 12345u + r);
+        for (int r = 0; r < REPS / 2; r++) hipLaunchKernelGGL(c.fn, dim3(blocks), dim3(threads), 0, 0, out, 12345u + r);
+        hipStreamSynchronize(0);
+        double mhz = read_sclk_mhz();                       // sampled in the middle of the timed launches' window
+        for (int r = REPS / 2; r < REPS; r++) hipLaunchKernelGGL(c.fn, dim3(blocks), dim3(threads), 0, 0, out, 12345u + r);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
-        double ops = 3.0 * (double)blocks * threads * ITERS * c.ops_per_iter;
+        double ops = (double)REPS * blocks * threads * ITERS * c.ops_per_iter;
         double rate = ops / (ms * 1e-3);
-        if (fma_rate == 0) fma_rate = rate;
-        // v_fma_f32 = 2 cycles per wave-instruction per SIMD
-        printf("%-34s %8.2f Tlane-ops/s   %6.2f cyc/wave-instr/SIMD (fma_f32 = 2)\n", c.name, rate / 1e12,
-               2.0 * fma_rate / rate);
+        // cycles per wave-instruction per SIMD from the SAMPLED clock: sclk * SIMDs / (wave-instructions per second)
+        double cyc = mhz > 0 ? mhz * 1e6 * simds / (rate / 64.0) : 0;
+        printf("%-34s %8.2f Tlane-ops/s   sclk %5.0f MHz   %6.2f cyc/wave-instr/SIMD\n", c.name, rate / 1e12, mhz, cyc);
     }
     {
         // latency: 1 wave per SIMD
@@ -207,7 +239,7 @@ int main() {
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         double ns_per = ms * 1e6 / ((double)ITERS * 32);
-        printf("v_mad_u64_u32 dependent chain: %.2f ns per instruction (1 wave/SIMD)\n", ns_per);
+        printf("v_mad_u64_u32 dependent chain: %.2f ns per instruction (1 wave/SIMD), sclk %.0f MHz\n", ns_per, read_sclk_mhz());
     }
     return 0;
 }

@@ -608,10 +608,12 @@ static bool p2_amt_make_plan(const p2_gate *gates, const p2_gate_list &list, p2_
 
 typedef void (*p2_gate_kernel_fn)(p2_quotient_args, p2_gate_list);
 static p2_gate_kernel_fn p2_gate_kernel_of(u32 type) {
-    // A/B switch ZKLC_P2_POSEIDON_GATE=lazy: the whole-round / lazy-partial-round evaluator of the Poseidon gate (plonky2_gates.cuh:
-    // measured 2 % of the quotient phase, validated on the byte-parity tests only -- opt-in)
+    // ZKLC_P2_POSEIDON_GATE: the evaluator of the Poseidon gate.  Default (round 5) = `loose`: the plain evaluator's loop structure in
+    // the loose arithmetic of the hash kernel's C++ permutation (2.80 -> 2.53 ms per Ed25519 proof); `plain` = the canonical-value
+    // form that was the default until round 4; `lazy` / `lazy1` = the whole-round / lazy-partial-round forms (plonky2_gates.cuh).
+    // All four give the same field values: tests/test_gpu_plonky2.py proves one circuit under each and compares the bytes.
     static const char *pg = getenv("ZKLC_P2_POSEIDON_GATE");
-    if (type == P2_POSEIDON && pg && !strcmp(pg, "loose")) return p2_quotient_gate_kernel<P2_POSEIDON_LOOSE>;
+    if (type == P2_POSEIDON && (!pg || !pg[0] || !strcmp(pg, "loose"))) return p2_quotient_gate_kernel<P2_POSEIDON_LOOSE>;
     if (type == P2_POSEIDON && pg && !strncmp(pg, "lazy", 4)) {
         // lazy: statements + unrolled partial rounds; lazy1: the partial rounds as rolled loops over per-lane LDS arrays
         return pg[4] == '1' ? p2_quotient_gate_kernel<P2_POSEIDON_LAZY + 1> : p2_quotient_gate_kernel<P2_POSEIDON_LAZY>;

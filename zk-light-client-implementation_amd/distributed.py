@@ -24,9 +24,9 @@ def msm_sharded(local_msm, combine_msm, points_shard, scalars_shard, group=None,
     import torch
     import torch.distributed as dist
     out, inf = local_msm(points_shard, scalars_shard)
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return out, inf
+    world = dist.get_world_size(group)       # an initialised world of ONE still runs the collective (the RCCL smoke of a 1-GPU box)
     mine = torch.zeros(9, dtype=torch.int64, device=device)
     mine[:8] = torch.from_numpy(np.asarray(out, dtype=np.uint64).view(np.int64).copy()).to(mine.device)
     mine[8] = 1 if inf else 0
@@ -46,9 +46,9 @@ def gather_bytes(chunks, group=None, device=None):
     is ~190 KB, so a padded all_gather of a few MB per rank is far below what xGMI moves in a millisecond)."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return [list(chunks)]
+    world = dist.get_world_size(group)
     lens = torch.tensor([len(chunks)] + [len(c) for c in chunks], dtype=torch.int64, device=device)
     n_max = torch.tensor([lens.numel()], dtype=torch.int64, device=device)
     dist.all_reduce(n_max, op=dist.ReduceOp.MAX, group=group)
@@ -208,6 +208,22 @@ def tree_fold(local, combine, group=None, device=None):
                 local = combine(local, other)
         step *= 2
     return local
+
+
+def all_ok(ok, group=None, device=None):
+    """every rank's success flag AND-ed over the ranks (one MIN all-reduce of an int32): the strong form calls this before every
+    exchange, so that a rank that failed makes ALL ranks raise instead of feeding a partial aggregate to the others"""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=_comm_device(device))
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t[0]))
+
+
+class RemoteRankFailed(RuntimeError):
+    """another rank of the strong form reported a failure (its own exception is raised there)"""
 
 
 def gather_objects(obj, dst=0, group=None, device=None):

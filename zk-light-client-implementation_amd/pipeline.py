@@ -174,6 +174,7 @@ class BlockPipeline:
         self.rpw = RecursionProver(self.dag_ctx, HASH_BN128) if wrap else None
         self._ed = {}
         self._lock = threading.Lock()
+        self._sig_failed = False
         self.last = None
 
     # ------------------------------------------------------------------------------------------------ circuits
@@ -223,6 +224,7 @@ class BlockPipeline:
 
     def _fail(self, st, e):
         st["errors"].append(e)
+        self._sig_failed = True
         for s in st["sets"]:
             for fut in (s.future, s.ks_future):
                 if not fut.done():
@@ -261,7 +263,7 @@ class BlockPipeline:
             for s in st["sets"]:
                 ent, n_mine = s.ed, len(s.my_sigs)
                 # a small first chunk (one signature per prover stream) so that proving starts after one witness time
-                bounds = [0, min(n_mine, max(1, self.nthreads - 1))] if first else [0]
+                bounds = [0, min(n_mine, self.wchunk, max(1, self.nthreads - 1))] if first else [0]
                 first = False
                 while bounds[-1] < n_mine:
                     bounds.append(min(n_mine, bounds[-1] + self.wchunk))
@@ -269,15 +271,23 @@ class BlockPipeline:
                     idx = s.my_sigs[c0:c1]
                     if not idx:
                         continue
-                    sl = ent.free_slots.get()
+                    sl = None
+                    while sl is None:              # a failed block wakes the producer: no blocking get()
+                        if st["errors"]:
+                            return
+                        try:
+                            sl = ent.free_slots.get(timeout=0.05)
+                        except queue.Empty:
+                            pass
                     if st["errors"]:
                         ent.free_slots.put(sl)
                         return
                     t_ = time.perf_counter()
                     fills = [s.fills[i] for i in idx]
                     if self.dev_wit:
-                        pis = ent.dwit.run(ent.d_bufs[sl].data_ptr(), fills, stream=self.wit_ctx.stream_ptr())
+                        pis = ent.dwit.run(ent.d_bufs[sl].data_ptr(), fills, stream=self.wit_ctx.stream_ptr(), capacity=self.wchunk)
                     else:
+                        assert len(idx) <= self.wchunk
                         _, pis = ent.data.generate_witness_native(fills, out=ent.views[sl][:len(idx)], threads=len(idx))
                     st["res"].witness_s += time.perf_counter() - t_
                     with self._lock:
@@ -297,15 +307,19 @@ class BlockPipeline:
                     return
                 s, i, sl, k, pis = item
                 ent = s.ed
-                if self.dev_wit:
-                    s.ed_proofs[i] = ent.provers[w].prove_dev(ent.d_bufs[sl][k].data_ptr(), pis, stream=self.ed_ctxs[w].stream_ptr())
-                else:
-                    s.ed_proofs[i] = ent.provers[w].prove_host_ptr(ent.views[sl][k].ctypes.data, pis)
-                s.ed_done[i].set()
-                with self._lock:
-                    ent.slot_left[sl] -= 1
-                    if ent.slot_left[sl] == 0:
-                        ent.free_slots.put(sl)
+                try:
+                    if st["errors"]:
+                        continue                   # drain: the block already failed, only the slot accounting matters
+                    if self.dev_wit:
+                        s.ed_proofs[i] = ent.provers[w].prove_dev(ent.d_bufs[sl][k].data_ptr(), pis, stream=self.ed_ctxs[w].stream_ptr())
+                    else:
+                        s.ed_proofs[i] = ent.provers[w].prove_host_ptr(ent.views[sl][k].ctypes.data, pis)
+                    s.ed_done[i].set()
+                finally:
+                    with self._lock:
+                        ent.slot_left[sl] -= 1
+                        if ent.slot_left[sl] == 0:
+                            ent.free_slots.put(sl)
         except Exception as e:
             self._fail(st, e)
 
@@ -381,9 +395,25 @@ class BlockPipeline:
             th.start()
         return ths
 
+    def _reset_slots(self, ent):
+        """every wire-matrix buffer free again (a block that failed mid-way may have left a slot half-consumed)"""
+        with self._lock:
+            while True:
+                try:
+                    ent.free_slots.get_nowait()
+                except queue.Empty:
+                    break
+            for sl in range(self.nbuf):
+                ent.slot_left[sl] = 0
+                ent.free_slots.put(sl)
+
     def _start_signature_stage(self, st):
         st["res"].t0 = time.perf_counter()
         self._precheck(st)
+        if self._sig_failed:                     # the previous signature stage ended in an error: its slot accounting is void
+            for ent in self._ed.values():
+                self._reset_slots(ent)
+            self._sig_failed = False
         return self._start([(self._witness_producer, (st,))] + [(self._ed_worker, (st, w)) for w in range(len(self.ed_ctxs))])
 
     def _begin_dag_stage(self, st):
@@ -405,6 +435,17 @@ class BlockPipeline:
         if st["errors"]:
             raise st["errors"][0]
 
+    def _strong_checkpoint(self, st, pending):
+        """strong form: AND of the ranks' success flags before an exchange.  If any rank failed, every rank fails its block (the
+        futures the DAG / fold threads wait on get the exception), joins its threads and raises -- the failing rank its own error,
+        the others RemoteRankFailed."""
+        if DIST.all_ok(not st["errors"], device=self.comm_device):
+            return
+        if not st["errors"]:
+            self._fail(st, DIST.RemoteRankFailed("rank %d: another rank failed its part of the block" % self.rank))
+        self._join(pending)
+        self._raise(st)
+
     # ------------------------------------------------------------------------------------------------ public API
     def prove_block_bft(self, window, strong=False):
         """ONE block, every stage concurrently -> BlockResult (rank 0 in the strong form; the other ranks return None)."""
@@ -423,9 +464,9 @@ class BlockPipeline:
         if strong:
             # (1) the header proofs and the keys / stakes proofs of the other ranks travel to rank 0 (point-to-point, ~150 KB each)
             self._join(side)
-            ok = not st["errors"]
+            self._strong_checkpoint(st, sig + dag)    # a rank whose header / keys-stakes job failed fails the block on EVERY rank
             mine = {"headers": st.get("headers", {}),
-                    "ks": [s.ks_future.result() for s in st["sets"]] if (self.rank == ks_rank and ok) else None}
+                    "ks": [s.ks_future.result() for s in st["sets"]] if self.rank == ks_rank else None}
             parts = DIST.gather_objects(mine if self.rank != 0 else None, 0, device=self.comm_device)
             if self.rank == 0:
                 merged = {}
@@ -437,10 +478,11 @@ class BlockPipeline:
                 st["hdr_future"].set_result(merged)
             # (2) local folds -> binary tree over the ranks -> closing proof on rank 0, per approval set
             self._join(sig)
+            self._strong_checkpoint(st, dag)          # .. and so does a failed signature stage: no partial aggregate is folded
             combine = lambda x, y: (lambda rc_p: (rc_p[0].common, rc_p[0].verifier_only, rc_p[1]))(self.rp.recursive_proof(x, y, raw=True))
             for s in st["sets"]:
-                total = DIST.tree_fold(None if st["errors"] else s.local_agg, combine, device=self.comm_device)
-                if self.rank == 0 and not st["errors"]:
+                total = DIST.tree_fold(s.local_agg, combine, device=self.comm_device)   # None = a rank without signatures
+                if self.rank == 0:
                     self._close_set(st, s, total)
             self._join(dag)
         else:

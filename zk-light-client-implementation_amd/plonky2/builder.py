@@ -1123,13 +1123,16 @@ class DeviceWitness:
         pr = self.data._program
         return np.array([[int(w[t]) for t in pr["input_targets"]] for w in inputs_list], dtype=np.uint64).reshape(len(inputs_list), -1)
 
-    def run(self, d_wires_ptr, inputs_list=None, input_values=None, stream=None):
-        """d_wires_ptr: device address of a ZERO-INITIALISED uint64 [k, num_wires, n] buffer (reusable: the same cells are written
-        every time).  Returns the public inputs uint64 [k, n_pi]; raises AssertionError if a witness does not exist."""
+    def run(self, d_wires_ptr, inputs_list=None, input_values=None, stream=None, capacity=64):
+        """d_wires_ptr: device address of a ZERO-INITIALISED uint64 [capacity, num_wires, n] buffer (reusable: the same cells are
+        written every time); `capacity` = the witnesses the buffer holds, a larger batch raises instead of writing past it.
+        Returns the public inputs uint64 [k, n_pi]; raises AssertionError if a witness does not exist."""
         import ctypes
         vals = self.input_matrix(inputs_list) if input_values is None else np.ascontiguousarray(input_values, dtype=np.uint64).reshape(-1, self.n_inputs)
         k = vals.shape[0]
-        assert 1 <= k <= 64 and vals.shape[1] == self.n_inputs
+        assert vals.shape[1] == self.n_inputs
+        if not 1 <= k <= min(64, int(capacity)):
+            raise ValueError("witness batch of %d for a buffer of %d witnesses (<= 64 per call)" % (k, min(64, int(capacity))))
         pis = np.zeros((k, max(self.n_pi, 1)), dtype=np.uint64)
         status = np.zeros(k, dtype=np.int32)
         err = ctypes.create_string_buffer(200 * k)

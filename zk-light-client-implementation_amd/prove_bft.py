@@ -192,11 +192,21 @@ class BlockProver:
         witnesses on the GPU) -- byte-identical proofs, a fraction of the time; its contexts and circuits are created on first use."""
         if pipelined:
             from .pipeline import BlockPipeline, BlockWindow
+            if header_proofs is not None:
+                raise ValueError("prove_block_bft(pipelined=True) proves its own header proofs: header_proofs must be None")
+            if self.ctx is None:
+                raise ValueError("prove_block_bft(pipelined=True) needs a BlockProver constructed over a zklc Context")
             if self._pipeline is None:
+                # the pipeline owns its own contexts, resident circuits and a nested BlockProver (beside this object's sequential
+                # provers: ~2x the resident set; construct a BlockPipeline directly when only the pipelined form is wanted)
                 self._pipeline = BlockPipeline(self.ctx.device_id, wrap=False)
             res = self._pipeline.prove_block_bft(BlockWindow(
                 (ep2_last_block_bytes, ep2_last_block_hash), (ep1_first_block_bytes, ep1_first_block_hash), blocks, validators,
                 (ep3_last_block_bytes, ep3_last_block_hash) if ep3_last_block_bytes is not None else None, validators_n_1))
+            for k, v in res.dag_counts.items():
+                self.counts[k] = self.counts.get(k, 0) + v
+            for k, v in res.dag_seconds.items():
+                self.seconds[k] = self.seconds.get(k, 0.0) + v
             return res.block, res.block_n_1
         jobs = self.header_jobs(ep2_last_block_bytes, ep2_last_block_hash, ep1_first_block_bytes, ep1_first_block_hash, blocks,
                                 ep3_last_block_bytes, ep3_last_block_hash)

@@ -22,14 +22,18 @@ class _AliasFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
             return None
         real = importlib.import_module(_REAL + fullname[len(__name__):])
         spec = importlib.machinery.ModuleSpec(fullname, self, is_package=hasattr(real, "__path__"))
-        spec._zklc_real = real
+        spec.loader_state = (real, real.__spec__, getattr(real, "__loader__", None))
         return spec
 
     def create_module(self, spec):
-        return spec._zklc_real
+        return spec.loader_state[0]
 
     def exec_module(self, module):
-        pass
+        # importlib has just stamped the ALIAS spec / loader on the real module: put the real ones back, so that
+        # __package__ == __spec__.parent holds (relative imports, importlib.reload, inspect keep working)
+        alias = module.__spec__
+        if alias is not None and getattr(alias, "loader_state", None) and alias.loader_state[0] is module:
+            module.__spec__, module.__loader__ = alias.loader_state[1], alias.loader_state[2]
 
 
 sys.meta_path.insert(0, _AliasFinder())
