@@ -83,10 +83,81 @@ def match_columns(constants, sigmas, fixture, max_points=None):
     return ok, len(pts)
 
 
-def build_wrap(inner_common, num_public_inputs=97):
-    from zklc_amd.plonky2.recursion import recursive_circuit
-    data, _ = recursive_circuit([inner_common], num_public_inputs)
+VARIANTS = {
+    "baseline": "the mirror as shipped: plonky2's check order, fused gate evaluators (gate_circuits.CircuitK), operation memo, "
+                "constants sorted into ConstantGate rows at build time, PI hash + PublicInputGate at build time",
+    "literal": "gate constraints through gate_circuits.LiteralK: one builder operation per field operation, a constant factor as "
+               "constant_extension + mul_extension, nothing fused",
+    "no-memo": "no cache of identical extension operations (plonky2's arithmetic_results map switched off)",
+    "literal+no-memo": "both of the above",
+    "const-first-use": "constants handed to the constant generators in first-use order instead of ascending value",
+    "pi-gate-first": "public-input hash and PublicInputGate as the FIRST rows (registered before verify_proof) instead of at build time",
+}
+
+
+def build_wrap(inner_common, num_public_inputs=97, variant="baseline"):
+    """the wrap circuit (recursion.rs:36-94 over the Block_i circuit's common data) under one of the layout VARIANTS"""
+    from zklc_amd.plonky2 import recursion as R
+    from zklc_amd.plonky2 import gate_circuits as GC
+    from zklc_amd.plonky2 import gates as G
+    from zklc_amd.plonky2.builder import Target, standard_recursion_config
+    assert variant in VARIANTS, variant
+
+    class B(R.RecursiveCircuitBuilder):
+        pass
+    b = B(standard_recursion_config())
+    if "literal" in variant:
+        b.k_adapter = GC.LiteralK
+    if "no-memo" in variant:
+        class NoMemo(dict):
+            def get(self, k, d=None):
+                return d
+
+            def __setitem__(self, k, v):
+                pass
+        b._ext_memo = NoMemo()
+    if variant == "const-first-use":
+        real_sorted = sorted
+
+        def place(self=b):
+            import builtins
+            builtins_sorted = builtins.sorted
+            try:      # _place_constants sorts the (value, target) items: keep the insertion order of the dict instead
+                builtins.sorted = lambda it, *a, **k: list(it)
+                R.CircuitBuilder._place_constants(self)
+            finally:
+                builtins.sorted = builtins_sorted
+        b._place_constants = place
+        del real_sorted
+    if variant == "pi-gate-first":
+        pis = b.add_virtual_targets(num_public_inputs)
+        for t in pis:
+            b.register_public_input(t)
+        pi_hash = b.hash_n_to_hash_no_pad(b.public_inputs)
+        pi_row = b.add_gate(G.PublicInputGate())
+        for i in range(4):
+            b.connect(pi_hash[i], Target(pi_row, i))
+        keep = list(b.public_inputs)
+        pt = R.add_virtual_proof_with_pis(b, inner_common)
+        vt = R.add_virtual_verifier_data(b, inner_common)
+        R.verify_proof(b, pt, vt, inner_common)
+        b.public_inputs = []             # build() would hash them again: the gate is already placed
+        b._place_constants()
+        while len(b.rows) & (len(b.rows) - 1):
+            b.add_gate(G.NoopGate())
+        b.public_inputs = keep
+        from zklc_amd.plonky2.builder import CircuitData
+        return CircuitData(b)
+    data, _ = R.recursive_circuit([inner_common], num_public_inputs, builder=b)
     return data
+
+
+def gate_rows(data):
+    rows = {}
+    for g, _ in data.builder.rows:
+        k = g.id().split(" {")[0].split("(")[0]
+        rows[k] = rows.get(k, 0) + 1
+    return rows
 
 
 def report(data, fixture, max_points=4):
@@ -102,10 +173,10 @@ def main():
     if "--inner" in sys.argv:
         inner = sys.argv[sys.argv.index("--inner") + 1]
     fixture = json.load(open(os.path.join(ROOT, "tests", "golden", "plonky2_wrap_instance_points.json")))
-    data = build_wrap(json.load(open(inner)))
-    rows = {}
-    for g, _ in data.builder.rows:
-        rows[g.id().split(" {")[0].split("(")[0]] = rows.get(g.id().split(" {")[0].split("(")[0], 0) + 1
+    variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else "baseline"
+    data = build_wrap(json.load(open(inner)), variant=variant)
+    rows = gate_rows(data)
+    print("variant %s: %s" % (variant, VARIANTS[variant]))
     print("wrap circuit: 2^%d rows, %d used; gate rows: %s" % (data.degree_bits, sum(v for k, v in rows.items() if k != "NoopGate"), rows))
     r = report(data, fixture)
     print("columns equal to the reference's wrap circuit at %d points: selectors %d/%d, gate constants %d/%d, sigmas %d/%d" % (

@@ -438,9 +438,12 @@ __global__ void __launch_bounds__(256) gl_merkle_level_kernel(const u64 *__restr
 #define PGL_COOP_GROUPS 16   // 16-lane groups per 256-thread workgroup
 __device__ __forceinline__ u64 pgl_coop_mds(u64 s, u32 g, u64 *grp) {
     const u32 C[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
-    __syncthreads();            // the previous layer's reads are done
+    // A 16-lane group lives inside ONE wave and owns its 12 LDS words: the LDS queue of a wave is in order, so the exchange needs no
+    // workgroup barrier (round 5: two s_barrier per layer x 30 layers were most of a cooperative permutation's latency) -- only the
+    // compiler must keep the order: previous layer's reads, this layer's writes, this layer's reads.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (g < 12) grp[g] = s;
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     u64 sl = 0, sh = 0;
     const u32 gg = g < 12 ? g : 0;
 #pragma unroll
@@ -459,7 +462,7 @@ __device__ __forceinline__ u64 pgl_coop_mds(u64 s, u32 g, u64 *grp) {
     u64 h = (sh >> 32) + (l < sl);
     return gl_reduce128_loose(l, h);
 }
-// permutes the group's state in place; every lane of the workgroup must call it (barriers inside)
+// permutes the group's state in place; all 16 lanes of the group must call it (wave-local exchange through `grp`)
 __device__ __forceinline__ u64 pgl_coop_permute(u64 s, u32 g, u64 *grp) {
     const u32 gg = g < 12 ? g : 0;
 #pragma unroll 1
@@ -486,6 +489,40 @@ gl_merkle_level_coop_kernel(const u64 *__restrict__ children, u64 *__restrict__ 
     u64 s = g < 8 ? children[(size_t)node * 8 + g] : 0;
     s = pgl_coop_permute(s, g, sh[grp]);
     if (live && g < 4) parents[(size_t)node * 4 + g] = s;
+}
+// Up to FIVE levels in one launch (round 5): a workgroup owns 32 consecutive digests of level L and hashes them down -- 16 parents,
+// 8, 4, 2, 1 -- writing every level where the per-level kernels would (the openings read them).  The levels of a tree are stored
+// one after the other (zklc_gl_merkle_tree_words), level L + j at `lvl[j]`; `nlev` <= 5 levels are produced.  Between two levels
+// the digests cross waves through LDS (one barrier per level); inside a permutation the exchange is wave-local.
+struct gl_subtree_levels {
+    u64 *lvl[6];          // lvl[0] = the children (read), lvl[1..nlev] = the parents' levels (written)
+};
+__global__ void __launch_bounds__(256)
+gl_merkle_subtree_coop_kernel(gl_subtree_levels L, u32 n_children, u32 nlev) {
+    __shared__ u64 sh[PGL_COOP_GROUPS][12];
+    __shared__ u64 dig[32][4];
+    const u32 g = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const u32 base = blockIdx.x * 32;                       // first child of this workgroup
+    if (threadIdx.x < 128) {
+        u32 c = base + (threadIdx.x >> 2);
+        dig[threadIdx.x >> 2][threadIdx.x & 3] = c < n_children ? L.lvl[0][(size_t)c * 4 + (threadIdx.x & 3)] : 0;
+    }
+    __syncthreads();
+    u32 width = 16;                                         // parents of this workgroup at the current level
+#pragma unroll 1
+    for (u32 j = 1; j <= nlev; j++, width >>= 1) {
+        const bool live = grp < width;
+        const u32 node = live ? grp : 0;
+        u64 s = g < 8 ? dig[2 * node + (g >> 2)][g & 3] : 0;
+        s = pgl_coop_permute(s, g, sh[grp]);
+        __syncthreads();                                    // every group has read its two children
+        const u32 gnode = (base >> j) + node;
+        if (live && g < 4) {
+            dig[node][g] = s;
+            if (gnode < (n_children >> j)) L.lvl[j][(size_t)gnode * 4 + g] = s;
+        }
+        __syncthreads();
+    }
 }
 // leaf digests (hash_or_noop of `width` elements), one 16-lane group per leaf; same addressing as gl_hash_leaves_kernel
 __global__ void __launch_bounds__(256)
@@ -825,10 +862,30 @@ int32_t zklc_gl_merkle_commit_strided(zklc_ctx *ctx, hipStream_t st, const uint6
         hipLaunchKernelGGL(gl_hash_leaves_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_mat, (size_t)stride, (size_t)leaf_stride,
                            width, n, d_tree);
     ZKLC_HIP(ctx, hipGetLastError());
+    // ZKLC_MERKLE_FUSED=0 keeps one launch per level (A/B and the variant parity test)
+    static const bool fused = !(getenv("ZKLC_MERKLE_FUSED") && getenv("ZKLC_MERKLE_FUSED")[0] == '0');
     u64 *level = d_tree;
-    for (u32 l = 0; l < log_leaves - cap_height; l++) {
+    const u32 total = log_leaves - cap_height;
+    for (u32 l = 0; l < total;) {
         u32 parents = n >> (l + 1);
         u64 *next = level + (4ULL << (log_leaves - l));
+        if (coop && fused && parents <= PGL_COOP_MAX_NODES && parents >= 16 && total - l >= 2) {
+            // the cooperative levels in groups of up to five per launch: a workgroup hashes 32 digests down to one
+            u32 nlev = total - l < 5 ? total - l : 5;
+            while (nlev > 1 && ((2 * parents) >> nlev) == 0) nlev--;
+            gl_subtree_levels L;
+            u64 *p = level;
+            for (u32 j = 0; j <= nlev; j++) {
+                L.lvl[j] = p;
+                p += 4ULL << (log_leaves - l - j);
+            }
+            for (u32 j = nlev + 1; j < 6; j++) L.lvl[j] = nullptr;
+            hipLaunchKernelGGL(gl_merkle_subtree_coop_kernel, dim3((2 * parents + 31) / 32), dim3(256), 0, st, L, 2 * parents, nlev);
+            ZKLC_HIP(ctx, hipGetLastError());
+            level = L.lvl[nlev];
+            l += nlev;
+            continue;
+        }
         if (coop && parents <= PGL_COOP_MAX_NODES)
             hipLaunchKernelGGL(gl_merkle_level_coop_kernel, dim3((parents + PGL_COOP_GROUPS - 1) / PGL_COOP_GROUPS), dim3(256), 0, st,
                                (const u64 *)level, next, parents);
@@ -836,6 +893,7 @@ int32_t zklc_gl_merkle_commit_strided(zklc_ctx *ctx, hipStream_t st, const uint6
             hipLaunchKernelGGL(gl_merkle_level_kernel, dim3((parents + 255) / 256), dim3(256), 0, st, (const u64 *)level, next, parents);
         ZKLC_HIP(ctx, hipGetLastError());
         level = next;
+        l++;
     }
     return ZKLC_OK;
 }

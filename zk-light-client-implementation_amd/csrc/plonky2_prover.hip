@@ -517,19 +517,25 @@ __global__ void __launch_bounds__(64 * P2_AMT_WAVES) p2_quotient_addmany_tile_ke
         else
             p2_amt_routed<1>(acc, pv, na, ops, apow, (int)a.nch, k0);
     }
-    // ---- limb columns hi-1 .. lo in phases of P2_AMT_COLS
+    // ---- limb columns hi-1 .. lo in phases of P2_AMT_COLS.  Round 5: the columns of phase k + 1 are REQUESTED (global loads into
+    // registers) right after the barrier that publishes phase k's tile, so their latency passes under the consumption of phase k
+    // instead of in front of the next barrier (r04: SQ_WAIT_ANY 49 % of the wave cycles, VALU 58 % of the issue ceiling).
     const u32 per_wave = P2_AMT_COLS / P2_AMT_WAVES;  // 12 = three asm batches of four range products
+    u64 wn[per_wave];
+    u32 top = plan.hi, base = top - plan.lo > P2_AMT_COLS ? top - P2_AMT_COLS : plan.lo;
+#pragma unroll
+    for (u32 j = 0; j < per_wave; j++) {
+        const u32 first = base + wave * per_wave;
+        const u32 col = first + j < top ? first + j : top - 1;              // clamped: a duplicate of the last column, not stored
+        wn[j] = W[(size_t)col * N];
+    }
 #pragma unroll 1
-    for (u32 top = plan.hi; top > plan.lo;) {
-        const u32 base = top - plan.lo > P2_AMT_COLS ? top - P2_AMT_COLS : plan.lo;
+    while (true) {
         {
             u64 w[per_wave], rp[per_wave];
             const u32 first = base + wave * per_wave;
 #pragma unroll
-            for (u32 j = 0; j < per_wave; j++) {
-                const u32 col = first + j < top ? first + j : top - 1;      // clamped: a duplicate of the last column, not stored
-                w[j] = W[(size_t)col * N];
-            }
+            for (u32 j = 0; j < per_wave; j++) w[j] = wn[j];
             p2_range_products4<per_wave>(w, rp);
 #pragma unroll
             for (u32 j = 0; j < per_wave; j++)
@@ -539,10 +545,23 @@ __global__ void __launch_bounds__(64 * P2_AMT_WAVES) p2_quotient_addmany_tile_ke
                 }
         }
         __syncthreads();
+        const u32 ntop = base;
+        const bool more = ntop > plan.lo;
+        const u32 nbase = !more ? plan.lo : (ntop - plan.lo > P2_AMT_COLS ? ntop - P2_AMT_COLS : plan.lo);
+        if (more) {
+            const u32 first = nbase + wave * per_wave;
+#pragma unroll
+            for (u32 j = 0; j < per_wave; j++) {
+                const u32 col = first + j < ntop ? first + j : ntop - 1;
+                wn[j] = W[(size_t)col * N];
+            }
+        }
         if (OPS[0]) p2_amt_consume<0>(acc, comb, OPS[0], L0[0], base, top, tw, trp, lane, apow, (int)a.nch, k0);
         if (OPS[1]) p2_amt_consume<1>(acc, comb, OPS[1], L0[1], base, top, tw, trp, lane, apow, (int)a.nch, k0);
         __syncthreads();
-        top = base;
+        if (!more) break;
+        top = ntop;
+        base = nbase;
     }
     // ---- filter_v * sum_v per wave, the waves' sums through LDS, one read-modify-write of the output per point
     u64 sum[P2_MAX_CH];

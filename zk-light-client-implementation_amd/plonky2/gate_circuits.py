@@ -124,6 +124,37 @@ class CircuitK:
         return [("t", e) for e in self.b.mds_ext([self.mat(v) for v in state])]
 
 
+class LiteralK(CircuitK):
+    """DIAGNOSTIC adapter (tools/wrap_instance.py --literal, profiles/r05_wrap_instance_hypotheses.txt): every K operation becomes
+    ONE builder operation at once -- mul -> mul_extension, add / sub -> add_extension / sub_extension, a constant factor ->
+    constant_extension + mul_extension (plonky2's `mul_const_extension`) -- with no fusing of a product into the following addition.
+    Not used by any prover path: it answers "how many rows would an unfused evaluator take" in the hypothesis log."""
+
+    def mat(self, v):
+        return self.b.constant_ext(v[1]) if v[0] == "c" else v[1]
+
+    def scale(self, c, v):
+        c %= P
+        if v[0] == "c":
+            return ("c", c * v[1] % P)
+        return ("t", self.b.mul_ext(self.b.constant_ext(c), self.mat(v)))
+
+    def mul(self, x, y):
+        if x[0] == "c" and y[0] == "c":
+            return ("c", x[1] * y[1] % P)
+        return ("t", self.b.mul_ext(self.mat(x), self.mat(y)))
+
+    def add(self, x, y):
+        if x[0] == "c" and y[0] == "c":
+            return ("c", (x[1] + y[1]) % P)
+        return ("t", self.b.add_ext(self.mat(x), self.mat(y)))
+
+    def sub(self, x, y):
+        if x[0] == "c" and y[0] == "c":
+            return ("c", (x[1] - y[1]) % P)
+        return ("t", self.b.sub_ext(self.mat(x), self.mat(y)))
+
+
 # ---- the degree-2 extension algebra over K (pairs of K values, X^2 = 7): quadratic_extension_algebra.go
 def _alg(w, start):
     return (w[start], w[start + 1])

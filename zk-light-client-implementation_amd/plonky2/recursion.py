@@ -79,6 +79,7 @@ class RecursiveCircuitBuilder(CircuitBuilder):
     def __init__(self, config=None):
         super().__init__(config or standard_recursion_config())
         self._aext_slot, self._mext_slot, self._ext_memo = {}, {}, {}
+        self.k_adapter = None
 
     # ---- extension targets: pairs of targets
     def add_virtual_ext(self):
@@ -687,7 +688,7 @@ def _eval_vanishing_poly(b, common, pt, ch, pih, zeta_pow_n):
     n = 1 << common["fri_params"]["degree_bits"]
     one = b.one_ext()
     # gate constraints
-    K = CircuitK(b)
+    K = (b.k_adapter or CircuitK)(b)       # k_adapter: a diagnostic hook of tools/wrap_instance.py (never set by a prover)
     sel = common["selectors_info"]
     groups = [(g["start"], g["end"]) for g in sel["groups"]]
     nsel = len(groups)
@@ -817,10 +818,11 @@ def verify_proof(b, pt, vt, common):
     return ch
 
 
-def recursive_circuit(inners, num_public_inputs=0):
+def recursive_circuit(inners, num_public_inputs=0, builder=None):
     """The circuit of `recursive_proof` (recursion.rs:16-97) for one or two inner circuits given by their common data.
-    Returns (CircuitData, targets): targets["proofs"][i], targets["verifier_data"][i], targets["public_inputs"]."""
-    b = RecursiveCircuitBuilder(standard_recursion_config())
+    Returns (CircuitData, targets): targets["proofs"][i], targets["verifier_data"][i], targets["public_inputs"].
+    `builder`: a RecursiveCircuitBuilder to build into (the layout experiments of tools/wrap_instance.py pass modified ones)."""
+    b = builder or RecursiveCircuitBuilder(standard_recursion_config())
     pts, vts = [], []
     for common in inners:
         pt = add_virtual_proof_with_pis(b, common)
