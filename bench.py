@@ -572,6 +572,14 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     pipe = BlockPipeline(torch.cuda.current_device(), prove_streams=args.prove_streams, witness_batch=args.witness_batch,
                          host_witness=args.host_witness, rank=rank, world=world, comm_device=dev, host_threads=host_cores())
 
+    # cold start: the cacheable circuits the run needs (Ed25519, the SHA-256 circuits of the header chains) that are not in the
+    # circuit cache yet are built by worker processes side by side, not one after the other under this process's GIL
+    win_ = BlockWindow.from_fixture(json.load(open(os.path.join(ROOT, "tests", "golden", "block_window_HPi5.json"))))
+    c1_msg_len = len(bytes.fromhex(json.load(open(os.path.join(ROOT, "tests", "golden", "ed25519_near_c1_small.json")))["msg"]))
+    out["circuit_prewarm"] = pipe.prewarm(win_, extra_msg_lens=[c1_msg_len])
+    if world > 1:
+        barrier()
+
     def time_proof(prover, wires, pis, sp, bits):
         d_w = torch.from_numpy(np.ascontiguousarray(wires).view(np.int64)).to(dev)
         fn = lambda: prover.prove_dev(d_w.data_ptr(), pis, stream=sp)

@@ -74,3 +74,22 @@ def test_concurrent_misses_build_once(tmp_path):
     assert all(p.returncode == 0 for p in procs)
     assert sorted(o[0] for o in outs) == ["built", "hit", "hit"] and len({o[1] for o in outs}) == 1
     assert len(list(tmp_path.glob("built-*"))) == 1
+
+
+def test_prewarm_builds_missing_entries_in_child_processes(tmp_path, monkeypatch):
+    """circuit_cache.prewarm (cold start, round 5): missing entries are built by child interpreters side by side and found by
+    build_cached afterwards; present entries are skipped; without a cache directory it is a no-op; an unknown kind is reported,
+    never raised"""
+    from zklc_amd.plonky2 import circuit_cache as CC
+    from zklc_amd.plonky2 import sha256
+    monkeypatch.setenv("ZKLC_CIRCUIT_CACHE", str(tmp_path))
+    rep = CC.prewarm([("sha256", 64), ("sha256", 130), ("sha256", 64)], processes=2, timeout_s=300)
+    assert rep["missing"] == 2 and rep["built"] == 2 and rep["failed"] == [], rep        # 64 and 130 bytes: two and three blocks
+    data, words, from_cache = sha256.build_cached(64)
+    assert from_cache and data._program is not None and len(words) == 16 * sha256.block_num_of(64)
+    again = CC.prewarm([("sha256", 64), ("sha256", 130)])
+    assert again["missing"] == 0 and again["built"] == 0
+    bad = CC.prewarm([("nonsense", 1)])
+    assert bad["failed"] and bad["built"] == 0
+    monkeypatch.delenv("ZKLC_CIRCUIT_CACHE")
+    assert "skipped" in CC.prewarm([("sha256", 64)])

@@ -45,3 +45,27 @@ def test_block_window_rejects_other_lengths():
     win = BlockWindow.from_fixture(json.load(open(FIXTURES[0])))
     with pytest.raises(ValueError, match="Invalid blocks.len"):
         BlockWindow(win.ep2_last_block, win.ep1_first_block, win.blocks[:4], win.validators)
+
+
+def test_prewarm_jobs_of_the_mainnet_window():
+    """pipeline.prewarm_jobs: the cacheable circuits of a window -- the approval message's Ed25519 circuit and one SHA-256 circuit
+    per hashed message length (inner_lite, every inner_rest, the 64-byte joins, the borsh validator list, valid_keys)"""
+    import hashlib
+    from zklc_amd.pipeline import BlockWindow, prewarm_jobs
+    from zklc_amd.plonky2.sha256 import block_num_of
+    load_golden = lambda name: json.load(open(os.path.join(GOLDEN, name)))
+    win = BlockWindow.from_fixture(load_golden("block_window_HPi5.json"))
+    jobs = prewarm_jobs(win, extra_msg_lens=[17])
+    assert [j for j in jobs if j[0] == "ed25519"] == [("ed25519", 17), ("ed25519", 41)]
+    sha = [n for k, n in jobs if k == "sha256"]
+    assert 208 in sha and 64 in sha and 33 * 73 in sha
+    assert 4 + sum(len(v) for v in win.validators) in sha
+    # every header's inner_rest: hash(header) = sha256(sha256(sha256(inner_lite) || sha256(inner_rest)) || prev_hash) pins the slicing
+    for f, raw in win.blocks:
+        lite, rest = raw[33:33 + 208], raw[33 + 208:len(raw) - 65]
+        assert len(rest) in sha
+        inner = hashlib.sha256(hashlib.sha256(lite).digest() + hashlib.sha256(rest).digest()).digest()
+        assert hashlib.sha256(inner + raw[1:33]).digest() == f["hash"]
+    assert len({block_num_of(n) for n in sha}) <= len(sha)
+    epoch = BlockWindow.from_fixture(load_golden("block_window_epoch_CRTZ.json"))
+    assert len([j for j in prewarm_jobs(epoch) if j[0] == "sha256"]) >= 6

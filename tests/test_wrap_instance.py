@@ -111,3 +111,52 @@ def test_gpu_verifier_data_equals_golden(zctx):
     finally:
         rp.close()
     assert mine == load_golden("plonky2_wrap_instance_points.json")["verifier_data"]
+
+
+def test_nearest_codeword_decoder_recovers_a_planted_difference():
+    """tools/wrap_decode.py (the DISTANCE of round 5's hypothesis log, profiles/r05_wrap_instance_hypotheses.txt): columns that
+    differ from the 'reference' in 60 common rows are corrected exactly by the joint decoder (radius 67), a single column with 40
+    differing rows by the one-column decoder (radius 44), and 60 rows are beyond the one-column radius"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wrap_decode", os.path.join(sys_path_tools, "wrap_decode.py"))
+    WD = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(WD)
+    fx = load_golden("plonky2_wrap_instance_points.json")
+    pts = WD.Points(fx)
+    neq = sum(2 if x[1] else 1 for x in pts.x)
+    assert (neq, WD.radius(neq, 1), WD.radius(neq, 3)) == (90, 44, 67)
+    rng = np.random.default_rng(1)
+    n = 1 << fx["degree_bits"]
+    cand = rng.integers(0, 6, size=(3, n)).astype(np.uint64)
+    ref = cand.copy()
+    rows = rng.choice(n, 60, replace=False)
+    for c in range(3):
+        ref[c, rows] = (ref[c, rows] + rng.integers(1, 5, size=60).astype(np.uint64)) % np.uint64(7)
+    ref[0, rows[:5]] = 2**32 - 1                      # UNUSED_SELECTOR-sized jumps as well
+    vals = [pts.evaluate(ref[c]) for c in range(3)]
+    for j in range(len(pts.x)):
+        pts.values[j] = [vals[c][j] for c in range(3)]
+    res = [pts.residuals(cand[c], c) for c in range(3)]
+    got = WD.decode(pts, res, WD.radius(neq, 3))
+    assert got is not None and sorted(got[0]) == sorted(rows.tolist())
+    assert all(WD.signed(got[1][c][r]) == int(ref[c, r]) - int(cand[c, r]) for c in range(3) for r in got[0])
+    assert WD.decode(pts, [res[0]], WD.radius(neq, 1)) is None            # 60 rows: beyond one column's radius
+    ref2 = cand[1].copy()
+    ref2[rows[:40]] += np.uint64(3)
+    v2 = pts.evaluate(ref2)
+    for j in range(len(pts.x)):
+        pts.values[j] = [v2[j]]
+    g1 = WD.decode(pts, [pts.residuals(cand[1], 0)], WD.radius(neq, 1))
+    assert g1 is not None and sorted(g1[0]) == sorted(rows[:40].tolist())
+
+
+def test_layout_variants_and_the_row_budget(wrap):
+    """the variants of the hypothesis log build; the unfused evaluators overflow the reference's 2^12 rows (refuted by the row budget)"""
+    wi, data, fx = wrap
+    inner = load_golden("block_i_common_2p13.json")
+    assert set(wi.VARIANTS) >= {"baseline", "literal", "no-memo", "const-first-use", "pi-gate-first"}
+    lit = wi.build_wrap(inner, variant="literal")
+    assert lit.degree_bits == 13 and data.degree_bits == 12
+    assert wi.gate_rows(lit)["PoseidonGate"] == wi.gate_rows(data)["PoseidonGate"] == 2972
+    pif = wi.build_wrap(inner, variant="pi-gate-first")
+    assert pif.degree_bits == 12 and wi.gate_rows(pif) == wi.gate_rows(data)

@@ -1,5 +1,6 @@
 // Context management for libzklc_mi355.so (C ABI declared in include/zklc.h).
 #include "zklc_internal.h"
+#include <cstdlib>
 #include <new>
 
 int32_t zklc_stage(zklc_ctx *ctx, int slot, size_t bytes, void **out) {
@@ -51,6 +52,17 @@ extern "C" int32_t zklc_init_priority(zklc_ctx **out, int32_t device_id, int32_t
         return code;
     };
     if (hipSetDevice(device_id) != hipSuccess) return fail(ZKLC_ERR_NO_DEVICE);
+    {
+        // Round 5: a proving thread that waits for its stream (~10 waits per proof) was measured at 1.00 host cores busy -- the
+        // runtime's default wait spins (profiles/r05d_host_cpu_probe.txt), six cores per rank with the pipeline's six threads.
+        // Ask the device for blocking waits (the thread sleeps on the completion interrupt); ZKLC_SPIN_WAIT=1 keeps the default.
+        // Best effort: a runtime that refuses the flag on an active device leaves the waits as they were.
+        static const bool spin = getenv("ZKLC_SPIN_WAIT") && getenv("ZKLC_SPIN_WAIT")[0] == '1';
+        if (!spin) {
+            (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+            (void)hipGetLastError();
+        }
+    }
     int prio_low = 0, prio_high = 0;   // numerically lower = higher priority
     if (high_priority && hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_high = 0;
     if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, high_priority ? prio_high : 0) != hipSuccess)

@@ -91,6 +91,26 @@ class BlockWindow:
                 [1] + list(b[5][0]["hash"]) + list(self.ep3_last_block[1]) + list(self.ep2_last_block[1])]
 
 
+def prewarm_jobs(windows, extra_msg_lens=()):
+    """[(kind, message length)] of the cacheable circuits the block proofs of `windows` use: the Ed25519 circuit of every approval
+    message length (prove_crypto/ed25519.rs:18-42) and the SHA-256 circuit (prove_crypto/sha256.rs:62-83) of every message the DAG
+    hashes -- inner_lite (208 B), inner_rest of every header (block_finality.rs:98-198), the two 64-byte joins of a header-hash
+    chain (header_bphash.rs:34-111), the borsh validator list (bp_hash, :121-139) and valid_keys (signatures.rs:107-112)."""
+    from .prove_bft import INNER_LITE_BYTES, PK_HASH_BYTES, SIG_BYTES, TYPE_BYTE
+    ed, sha = set(int(x) for x in extra_msg_lens), {INNER_LITE_BYTES, 2 * PK_HASH_BYTES}
+    for w in ([windows] if isinstance(windows, BlockWindow) else list(windows)):
+        vlists = [w.validators] + ([w.validators_n_1] if w.validators_n_1 else [])
+        for validators in vlists:
+            sha.add(4 + sum(len(v) for v in validators))
+        for msg, approvals, _ in w.approval_sets():
+            ed.add(len(msg))
+            sha.add(33 * sum(1 for a in approvals if len(a) == 66))
+        heads = [raw for _, raw in w.blocks] + [x[0] for x in (w.ep2_last_block, w.ep1_first_block, w.ep3_last_block) if x]
+        for raw in heads:
+            sha.add(len(raw) - (TYPE_BYTE + PK_HASH_BYTES + INNER_LITE_BYTES) - TYPE_BYTE - SIG_BYTES)
+    return [("ed25519", n) for n in sorted(ed)] + [("sha256", n) for n in sorted(sha) if n > 0]
+
+
 class _EdCircuit:
     """the reference's per-signature circuit for one message length (prove_crypto/ed25519.rs:18-42), resident once per prover stream,
     with its device witness interpreter and the double-buffered wire matrices"""
@@ -186,18 +206,10 @@ class BlockPipeline:
         if ent is not None:
             return ent
         import torch
-        from .plonky2 import CircuitBuilder, HASH_GL, wide_ecc_config
+        from .plonky2 import HASH_GL
         from .plonky2 import ed25519_circuit as E
-        from .plonky2.circuit_cache import load_or_build
-
-        def build():
-            b = CircuitBuilder(wide_ecc_config())
-            targets = E.ed25519_circuit(b, 8 * msg_len)
-            data = b.build()
-            data.witness_program(list(targets["msg"]) + list(targets["sig"]) + list(targets["pk"]))
-            return data, targets
         ent = _EdCircuit()
-        ent.data, ent.targets, _ = load_or_build("ed25519", (msg_len, sorted(wide_ecc_config().items(), key=str)), build)
+        ent.data, ent.targets, _ = E.build_cached(msg_len)
         ent.provers = [ent.data.prover(c, HASH_GL) for c in self.ed_ctxs]
         ent.common, ent.vd = ent.data.common_data(), ent.provers[0].verifier_data()
         nw, n_rows = ent.data.config["num_wires"], ent.data.n
@@ -215,6 +227,18 @@ class BlockPipeline:
             ent.views = [p.numpy().view(np.uint64) for p in ent.pinned]
         self._ed[msg_len] = ent
         return ent
+
+    def prewarm(self, windows, extra_msg_lens=(), processes=None, timeout_s=900):
+        """Cold start (round 5): the circuits a window needs that are NOT in the circuit cache yet (prewarm_jobs) are built by
+        WORKER PROCESSES side by side (circuit construction is host Python: threads of one process share the GIL and build them
+        one after the other, 180 s for the mainnet window; processes take the longest single build) and land in the cache, from
+        which the pipeline then loads them.  A no-op without ZKLC_CIRCUIT_CACHE, when nothing is missing, or on a rank other
+        than 0 (the other ranks wait on the entries' locks).  Never raises: what a worker did not build is built in this process
+        on first use, as before.  Returns the report of circuit_cache.prewarm."""
+        from .plonky2 import circuit_cache as CC
+        if self.rank != 0:
+            return {"skipped": "rank %d" % self.rank}
+        return CC.prewarm(prewarm_jobs(windows, extra_msg_lens), processes=processes, timeout_s=timeout_s)
 
     # ------------------------------------------------------------------------------------------------ one block's state
     def _new_state(self, sets, strong):

@@ -122,7 +122,8 @@ class CircuitBuilder:
         assert self.config["num_wires"] <= 256, "target keys pack the column into 8 bits"
         self.rows = []            # (gate, constants)
         self.n_virtual = 0
-        self.parent = {}          # union-find over target keys
+        self._conn_a, self._conn_b = [], []      # copy constraints as recorded: pairs of target keys (append only)
+        self._classes = None      # (number of pairs resolved, {key: root} of the non-root connected keys, sorted keys, their roots)
         self.generators = []      # (input targets, fn(values) -> [(target, value)])
         self.public_inputs = []
         self._const_targets = {}
@@ -151,19 +152,51 @@ class CircuitBuilder:
     def register_public_input(self, t):
         self.public_inputs.append(t)
 
-    def _find(self, k):
-        p = self.parent
-        root = k
-        while p.get(root, root) != root:
-            root = p[root]
-        while p.get(k, k) != root:
-            p[k], k = root, p[k]
-        return root
-
+    # Copy constraints (plonky2 `connect` -> the disjoint-set forest of `wire_partition`).  Round 5: `connect` only RECORDS the pair
+    # (the Ed25519 circuit makes 4.4 M of them; a Python union-find per call was a quarter of its construction time); the classes
+    # are resolved once, when something first asks for them, as the connected components of the recorded graph
+    # (scipy.sparse.csgraph).  The root of a class is its smallest key -- nothing depends on which member it is.
     def connect(self, a, b):
-        ra, rb = self._find(a.k), self._find(b.k)
-        if ra != rb:
-            self.parent[ra] = rb
+        self._conn_a.append(a.k)
+        self._conn_b.append(b.k)
+
+    def _resolve_classes(self):
+        n_pairs = len(self._conn_a)
+        if self._classes is not None and self._classes[0] == n_pairs:
+            return self._classes
+        if n_pairs == 0:
+            self._classes = (0, {}, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
+            return self._classes
+        from scipy.sparse import coo_matrix
+        from scipy.sparse.csgraph import connected_components
+        a = np.array(self._conn_a, dtype=np.int64)
+        b = np.array(self._conn_b, dtype=np.int64)
+        keys, inv = np.unique(np.concatenate([a, b]), return_inverse=True)
+        ia, ib = inv[:n_pairs], inv[n_pairs:]
+        g = coo_matrix((np.ones(n_pairs, dtype=np.int8), (ia, ib)), shape=(len(keys), len(keys)))
+        _, label = connected_components(g, directed=False)
+        # root = the smallest key of the class: keys are sorted, so the first occurrence of a label is its minimum
+        first = np.full(int(label.max()) + 1, len(keys), dtype=np.int64)
+        np.minimum.at(first, label, np.arange(len(keys), dtype=np.int64))
+        roots = keys[first[label]]
+        nonroot = roots != keys
+        parent = dict(zip(keys[nonroot].tolist(), roots[nonroot].tolist()))
+        self._classes = (n_pairs, parent, keys, roots)
+        return self._classes
+
+    @property
+    def parent(self):
+        """{key: class root} for every connected key that is not itself the root of its class (the shape the union-find had)"""
+        return self._resolve_classes()[1]
+
+    def _find(self, k):
+        return self._resolve_classes()[1].get(k, k)
+
+    def class_arrays(self):
+        """(keys, roots) of the non-root connected keys as sorted int64 arrays (what CircuitData and the program compiler need)"""
+        _, _, keys, roots = self._resolve_classes()
+        nonroot = roots != keys
+        return keys[nonroot], roots[nonroot]
 
     def add_gate(self, gate, constants=()):
         assert gate.num_wires <= self.config["num_wires"], "gate %s needs %d wires" % (gate.id(), gate.num_wires)
@@ -714,9 +747,7 @@ class CircuitData:
         # which plonky2's `wire_partition` (plonk/permutation_argument.rs) walks the wires: for row { for column }
         sig_col = np.tile(np.arange(routed, dtype=np.int64)[:, None], (1, n))
         sig_row = np.tile(np.arange(n, dtype=np.int64)[None, :], (routed, 1))
-        pk = np.fromiter(b.parent.keys(), dtype=np.int64, count=len(b.parent))
-        find = b._find
-        pr = np.fromiter((find(k) for k in b.parent), dtype=np.int64, count=len(b.parent))
+        pk, pr = b.class_arrays()
         wk, wr = pk[pk < VIRTUAL_BASE], pr[pk < VIRTUAL_BASE]
         root_wires = np.unique(pr[pr < VIRTUAL_BASE])          # a class root has no parent entry: add it to its own class
         wk, wr = np.concatenate([wk, root_wires]), np.concatenate([wr, root_wires])
@@ -891,11 +922,7 @@ class CircuitData:
         in_k = np.array([t.k for t in in_targets], dtype=np.int64)
         pi_k = np.array([t.k for t in b.public_inputs], dtype=np.int64)
         # copy classes: key -> root for the keys that were ever connected, identity for the rest
-        pk = np.fromiter(b.parent.keys(), dtype=np.int64, count=len(b.parent))
-        find = b._find
-        pr = np.fromiter((find(k) for k in b.parent), dtype=np.int64, count=len(b.parent))
-        o = np.argsort(pk, kind="stable")
-        pk, pr = pk[o], pr[o]
+        pk, pr = b.class_arrays()                      # sorted by key
 
         def roots(keys):
             if len(pk) == 0 or len(keys) == 0:

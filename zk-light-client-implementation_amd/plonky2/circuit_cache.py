@@ -54,8 +54,7 @@ def load_or_build(name, key, build):
     if d is None:
         data, aux = build()
         return data, aux, False
-    tag = hashlib.sha256(repr((name, key)).encode()).hexdigest()[:16]
-    path = os.path.join(d, "%s-%s-%s.circuit" % (name, tag, _sources_digest()))
+    path = _entry_path(name, key)
     got = _load(path)
     if got is not None:
         return got[0], got[1], True
@@ -117,3 +116,99 @@ def _build_and_store(d, path, build):
             except OSError:
                 pass
     return data, aux, False
+
+
+# ------------------------------------------------------------------------------------------------ out-of-process builds
+def _entry_path(name, key):
+    d = cache_dir()
+    tag = hashlib.sha256(repr((name, key)).encode()).hexdigest()[:16]
+    return os.path.join(d, "%s-%s-%s.circuit" % (name, tag, _sources_digest()))
+
+
+def _job_key(kind, arg):
+    """the (name, key) pair `build_cached` of the circuit's module uses -- kept beside it so that a miss here is a miss there"""
+    from .builder import standard_recursion_config, wide_ecc_config
+    if kind == "ed25519":
+        return "ed25519", (int(arg), sorted(wide_ecc_config().items(), key=str))
+    if kind == "sha256":
+        from .sha256 import block_num_of
+        return "sha256", (block_num_of(int(arg)), sorted(standard_recursion_config().items(), key=str))
+    raise ValueError("prewarm: unknown circuit kind %r" % (kind,))
+
+
+def build_job(kind, arg):
+    """what a prewarm worker runs (also: `python -m zklc_amd.plonky2.circuit_cache ed25519 41`): build one circuit into the cache"""
+    if kind == "ed25519":
+        from .ed25519_circuit import build_cached
+    elif kind == "sha256":
+        from .sha256 import build_cached
+    else:
+        raise ValueError("unknown circuit kind %r" % (kind,))
+    return build_cached(int(arg))[2]
+
+
+def prewarm(jobs, processes=None, timeout_s=900):
+    """jobs: [(kind, arg)] with kind in {"ed25519", "sha256"} and arg = the message length in bytes.  The entries missing from the
+    cache are built by child interpreters (one per entry, at most `processes` at a time; CPU only -- no GPU context is created in
+    them), largest first.  Returns {"missing": n, "built": n, "failed": [...], "seconds": s}; never raises."""
+    import subprocess
+    import sys
+    import time
+    t0 = time.perf_counter()
+    rep = {"missing": 0, "built": 0, "failed": [], "seconds": 0.0}
+    try:
+        if cache_dir() is None:
+            rep["skipped"] = "ZKLC_CIRCUIT_CACHE is not set"
+            return rep
+        seen, todo = set(), []
+        for kind, arg in jobs:
+            name, key = _job_key(kind, arg)
+            path = _entry_path(name, key)
+            if path in seen or os.path.exists(path):
+                continue
+            seen.add(path)
+            todo.append((kind, int(arg), path))
+        rep["missing"] = len(todo)
+        if not todo:
+            return rep
+        todo.sort(key=lambda j: (j[0] != "ed25519", -j[1]))          # the longest builds first
+        cores = len(os.sched_getaffinity(0))
+        procs_max = max(1, min(len(todo), processes or max(1, cores // 2), 12))
+        os.makedirs(cache_dir(), exist_ok=True)
+        root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        code = ("import sys; sys.path.insert(0, %r); import zklc_amd; from zklc_amd.plonky2 import circuit_cache as C; "
+                "C.build_job(sys.argv[1], sys.argv[2])" % root)
+        env = dict(os.environ, OMP_NUM_THREADS="2", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        running, pending = [], list(todo)
+        deadline = time.perf_counter() + timeout_s
+        while pending or running:
+            while pending and len(running) < procs_max:
+                job = pending.pop(0)
+                running.append((job, subprocess.Popen([sys.executable, "-c", code, job[0], str(job[1])], env=env,
+                                                      stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)))
+            time.sleep(0.2)
+            still = []
+            for job, p in running:
+                if p.poll() is None:
+                    if time.perf_counter() > deadline:
+                        p.kill()
+                        p.communicate()
+                        rep["failed"].append((job[0], job[1], "timeout"))
+                    else:
+                        still.append((job, p))
+                    continue
+                err = p.communicate()[1]
+                if p.returncode == 0 and os.path.exists(job[2]):
+                    rep["built"] += 1
+                else:
+                    rep["failed"].append((job[0], job[1], (err or "")[-300:]))
+            running = still
+    except Exception as e:          # an optimisation: the in-process build on first use remains
+        rep["failed"].append(("prewarm", 0, repr(e)[:300]))
+    rep["seconds"] = time.perf_counter() - t0
+    return rep
+
+
+if __name__ == "__main__":
+    import sys
+    print(build_job(sys.argv[1], sys.argv[2]))

@@ -435,3 +435,20 @@ def fill_ecdsa_targets(targets, msg, sig, pk):
     w.update(zip(targets["sig"], sha512.array_to_bits(sig)))
     w.update(zip(targets["pk"], sha512.array_to_bits(pk)))
     return w
+
+
+def build_cached(msg_len_bytes):
+    """The reference's per-signature circuit for one message length (get_ed25519_circuit_targets, prove_crypto/ed25519.rs:18-42)
+    with its witness program compiled, through the circuit cache: -> (CircuitData, targets, from_cache).  One definition for the
+    sequential driver (signatures.ApprovalProver), the pipeline and the out-of-process prewarm (circuit_cache.prewarm)."""
+    from .builder import CircuitBuilder, wide_ecc_config
+    from .circuit_cache import load_or_build
+
+    def build():
+        b = CircuitBuilder(wide_ecc_config())
+        targets = ed25519_circuit(b, 8 * msg_len_bytes)
+        data = b.build()
+        # the inputs in the order fill_ecdsa_targets names them: the program is the one an example witness would fix
+        data.witness_program(list(targets["msg"]) + list(targets["sig"]) + list(targets["pk"]))
+        return data, targets
+    return load_or_build("ed25519", (msg_len_bytes, sorted(wide_ecc_config().items(), key=str)), build)

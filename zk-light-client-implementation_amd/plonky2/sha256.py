@@ -103,6 +103,22 @@ def sha256_witness(words_t, msg):
     return dict(zip(words_t, padded_words(msg)))
 
 
+def block_num_of(msg_len):
+    return (8 * msg_len + 64 + 512) // 512
+
+
+def build_cached(msg_len):
+    """the SHA-256 circuit for messages of `msg_len` bytes (one circuit per number of 512-bit blocks) with its witness program,
+    through the circuit cache: -> (CircuitData, word targets, from_cache)"""
+    from .circuit_cache import load_or_build
+
+    def build():
+        data, words = sha256_circuit(msg_len)
+        data.witness_program(list(words))
+        return data, words
+    return load_or_build("sha256", (block_num_of(msg_len), sorted(standard_recursion_config().items(), key=str)), build)
+
+
 class Sha256Prover:
     """`sha256_proof_u32` (near_bft_finality/src/prove_crypto/sha256.rs:62-83) on one GPU context: one circuit per number of
     512-bit blocks, built and uploaded once (the reference rebuilds it per call), native witness generation, GPU proof."""
@@ -115,12 +131,7 @@ class Sha256Prover:
         block_num = (8 * msg_len + 64 + 512) // 512
         ent = self._circuits.get(block_num)
         if ent is None:
-            def build():
-                data, words = sha256_circuit(msg_len)
-                data.witness_program(list(words))
-                return data, words
-            from .circuit_cache import load_or_build
-            data, words, _ = load_or_build("sha256", (block_num, sorted(standard_recursion_config().items(), key=str)), build)
+            data, words, _ = build_cached(msg_len)
             prover = data.prover(self.ctx, self.hasher)
             ent = self._circuits[block_num] = (data, words, prover, data.common_data(), prover.verifier_data())
         return ent

@@ -105,19 +105,11 @@ class ApprovalProver:
 
     def ed25519_circuit(self, msg_len_bytes, example=None):
         """get_ed25519_circuit_targets (ed25519.rs:18-42): build once per message length"""
-        from .plonky2 import CircuitBuilder, HASH_GL, wide_ecc_config
+        from .plonky2 import HASH_GL
         from .plonky2 import ed25519_circuit as E
         ent = self._ed.get(msg_len_bytes)
         if ent is None:
-            def build():
-                b = CircuitBuilder(wide_ecc_config())
-                targets = E.ed25519_circuit(b, 8 * msg_len_bytes)
-                data = b.build()
-                # the inputs in the order fill_ecdsa_targets names them: the program is the one an example witness would fix
-                data.witness_program(list(targets["msg"]) + list(targets["sig"]) + list(targets["pk"]))
-                return data, targets
-            from .plonky2.circuit_cache import load_or_build
-            data, targets, _ = load_or_build("ed25519", (msg_len_bytes, sorted(wide_ecc_config().items(), key=str)), build)
+            data, targets, _ = E.build_cached(msg_len_bytes)
             prover = data.prover(self.ctx, HASH_GL)
             ent = self._ed[msg_len_bytes] = (data, targets, prover, prover.verifier_data())
         if example is not None and ent[0]._program is None:
