@@ -165,8 +165,15 @@ def pmc_traffic(n):
         return None
 
 
-VALU_INT_PEAK_TLOPS = 37.7    # measured issue ceiling of the multi-pass integer class (v_mad_u64_u32, carry adds): profiles/r02_valu_ubench.txt
-VALU_FAST_PEAK_TLOPS = 62.0   # measured issue rate of the single-pass class (v_mov / v_add_u32 / v_xor / 32-bit shifts), same file
+# Issue limits of the SIMDs (round 5: a hardware denominator instead of the empirical one of rounds 2-4).  A wave64 instruction of the
+# multi-pass integer class (v_mad_u64_u32, v_mul_*, carry adds, v_cndmask with an SGPR mask, 64-bit shifts) occupies a SIMD for 4
+# cycles, one of the single-pass class (v_mov / v_add_u32 / v_xor / 32-bit shifts) for 2: 1024 SIMDs x 64 lanes x 2.4 GHz / 4 = 39.3 T
+# lane-instructions/s, / 2 = 78.6 T.  The micro-benchmark (tools/ubench/valu_ubench.hip, warm clock, sclk sampled:
+# profiles/r05a_valu_ubench_warm_sclk.txt) reaches 4.3-4.4 and 2.4-2.6 cycles: 36.0-36.8 T and 60-66 T -- carried as `ubench`.
+VALU_CLOCK_GHZ = 2.4
+VALU_INT_PEAK_TLOPS = 1024 * 64 * VALU_CLOCK_GHZ / 4 / 1e3
+VALU_FAST_PEAK_TLOPS = 1024 * 64 * VALU_CLOCK_GHZ / 2 / 1e3
+VALU_INT_UBENCH_TLOPS, VALU_FAST_UBENCH_TLOPS = 36.3, 61.0
 # static share of single-pass instructions in each priced kernel (tools/valu_mix.py over the shipped code objects, profiles/r04_valu_mix.txt)
 VALU_FAST_SHARE = {"poseidon": 0.001, "lde": 0.136, "msm": 0.202}
 
@@ -195,9 +202,12 @@ def valu_block(wave_instructions, ms, what, kernel="poseidon"):
     ach = wave_instructions * 64 / (ms * 1e-3) / 1e12
     f = VALU_FAST_SHARE[kernel]
     peak = 1.0 / ((1.0 - f) / VALU_INT_PEAK_TLOPS + f / VALU_FAST_PEAK_TLOPS)
-    return {"bound": "valu-int", "achieved": ach, "peak": peak, "unit": "T lane-instr/s", "frac": ach / peak,
-            "note": "SQ_INSTS_VALU (%s) x 64 lanes / the live time; peak = measured issue rates (profiles/r02_valu_ubench.txt) weighted by "
-                    "the kernel's static instruction mix (single-pass share %.3f, tools/valu_mix.py)" % (what, f)}
+    ub = 1.0 / ((1.0 - f) / VALU_INT_UBENCH_TLOPS + f / VALU_FAST_UBENCH_TLOPS)
+    return {"bound": "valu-int", "achieved": ach, "peak": peak, "unit": "T lane-instr/s", "frac": ach / peak, "ubench": ub,
+            "note": "SQ_INSTS_VALU (%s) x 64 lanes / the live time; peak = the SIMDs' issue limit at 2.4 GHz (4 cycles per multi-pass "
+                    "wave64 instruction, 2 per single-pass one) weighted by the kernel's static instruction mix (single-pass share "
+                    "%.3f, tools/valu_mix.py); ubench = what the micro-benchmark reaches with the same mix "
+                    "(profiles/r05a_valu_ubench_warm_sclk.txt)" % (what, f)}
 
 
 def cpu_baseline(pk, sg, ms, budget_s=12.0):
@@ -324,6 +334,36 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
         del d_s2
     msm["distributions"] = by_dist
     msm_step()                                                    # d_out holds the uniform instance again (parity check below)
+    # the FIXED-BASE form (round 5, include/zklc.h): the bases of a Groth16 proving key are the same for every proof, so a table of
+    # 2^(c w) P_i is built once and a multi-exponentiation needs no closing doublings and one bucket reduction; its affine result is
+    # bit-identical to the plain form's.  Reported beside the plain figure (which stays the headline's MSM number).
+    if world == 1:
+        try:
+            torch.cuda.synchronize()
+            plain_words = d_out[:8].cpu().numpy().copy()
+            t_ = time.perf_counter()
+            table = ctx.bn254_msm_fixed_table(d_pts, n, stream=stream)
+            stream.synchronize()
+            t_tab = time.perf_counter() - t_
+            fstep = lambda sc_=d_sc: ctx.bn254_msm_fixed_dev(table, sc_, n, d_out, d_inf, d_ws, wb, stream=stream)
+            ms_f, wall_f = _time_stream(fstep, stream, 3, barrier)
+            stream.synchronize()
+            same = bool(np.array_equal(d_out[:8].cpu().numpy(), plain_words))
+            msm["fixed_base"] = {"metric": "BN254 G1 MSM over a precomputed table of the bases (2^(16 w) P_i, one bucket set)", "ms": wall_f,
+                                 "value": n / (wall_f * 1e-3) / 1e6, "unit": "Melem/s", "table_mb": table.numel() / 1e6,
+                                 "table_build_s": t_tab, "equals_plain_result": same}
+            s_w = sc_h.copy()
+            kind = np.random.default_rng(5).random(n)
+            s_w[kind < 0.5] = 0
+            s_w[kind < 0.5, 0] = 1
+            s_w[(kind >= 0.5) & (kind < 0.8), 1:] = 0
+            d_sw = torch.from_numpy(s_w.view(np.int64)).to(dev)
+            _, wall_fw = _time_stream(lambda: fstep(d_sw), stream, 3, barrier)
+            msm["fixed_base"]["witness_like_ms"] = wall_fw
+            del table, d_sw
+            msm_step()
+        except Exception as e:      # an extra line of the report
+            msm["fixed_base"] = {"error": repr(e)[:200]}
     pm = pmc_json("msm_pmc_latest.json")
     if pm is not None and pm.get("log_n") == args.msm_log:
         msm["roofline"]["traffic"] = pm.get("hbm_bytes_per_msm")
@@ -389,6 +429,27 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
         res["lde"]["roofline"]["traffic"] = pl_.get("hbm_bytes_per_lde")
         res["lde"]["roofline"]["valu"] = valu_block(pl_["valu_wave_instructions_per_lde"], ms, "all passes of one extension, "
                                                                                                 "profiles/lde_pmc_latest.json", "lde")
+    # the PRODUCT shape: every commitment of the Ed25519 circuit extends 2^18 -> 2^21 (prove_crypto/ed25519.rs:60), the less efficient
+    # case of the two: PMC at this shape in profiles/r05a_lde_pmc_2p18_to_2p21.json
+    try:
+        c18 = torch.randint(0, 2**63 - 1, (batch, 1 << 18), generator=g, device=dev, dtype=torch.int64)
+        l21 = torch.empty((batch, 1 << 21), dtype=torch.int64, device=dev)
+        ms18, _ = _time_stream(lambda: ctx.gl_lde_dev(c18, 18, rate, batch, 7, l21, flags=zklc_amd._lib.NTT_OUT_BITREV, stream=stream),
+                               stream, 5, barrier)
+        ms18 = reduce_max(ms18)
+        alg18 = 8.0 * ((1 << 18) + (1 << 21)) * batch
+        res["lde_2p18"] = {"metric": "Goldilocks coset LDE 234 x (2^18 -> 2^21), the Ed25519 circuit's shape", "value": world * alg18 / (ms18 * 1e-3) / 1e9,
+                           "unit": "GB/s", "ms": ms18,
+                           "roofline": {"bound": "hbm", "achieved": alg18 / (ms18 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": alg18 / (ms18 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
+        p18 = pmc_json("r05a_lde_pmc_2p18_to_2p21.json")
+        if p18 is not None:
+            res["lde_2p18"]["roofline"]["traffic"] = p18.get("hbm_bytes_per_lde")
+            res["lde_2p18"]["roofline"]["valu"] = valu_block(p18["valu_wave_instructions_per_lde"], ms18, "all passes of one extension, "
+                                                             "profiles/r05a_lde_pmc_2p18_to_2p21.json", "lde")
+        del c18, l21
+    except Exception as e:          # an extra line of the report, never a reason to lose the bench
+        res["lde_2p18"] = {"error": repr(e)[:200]}
     words = ctx.gl_merkle_tree_words(log_n + rate, cap)
     tree = torch.empty(words, dtype=torch.int64, device=dev)
     ms, wall = _time_stream(lambda: ctx.gl_merkle_commit_dev(lde, N, log_n + rate, batch, cap, tree, stream=stream), stream, 3, barrier)
@@ -858,7 +919,7 @@ def compact_line(full):
             return None
         o = {k: r3(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms") if k in r}
         if "valu" in r:
-            o["valu"] = {k: r3(r["valu"][k]) for k in ("bound", "achieved", "peak", "unit", "frac")}
+            o["valu"] = {k: r3(r["valu"][k]) for k in ("bound", "achieved", "peak", "unit", "frac", "ubench") if k in r["valu"]}
         return o
     line["roofline"] = roof(full.get("roofline"))
     cb = full.get("cpu_baseline")
@@ -866,9 +927,9 @@ def compact_line(full):
         line["cpu_baseline"] = {k: r3(cb[k]) for k in ("value", "unit", "cores", "kind", "sample", "seconds_per_block", "gpu_speedup") if k in cb}
     st = full.get("stages") or {}
     cs = {}
-    for name in ("msm", "lde", "merkle", "ed25519_verify"):
+    for name in ("msm", "lde", "lde_2p18", "merkle", "ed25519_verify"):
         s_ = st.get(name)
-        if s_:
+        if s_ and "value" in s_:
             e = {"value": r3(s_["value"]), "unit": s_["unit"]}
             if "ms" in s_:
                 e["ms"] = r3(s_["ms"])
@@ -883,6 +944,9 @@ def compact_line(full):
                 e["cpu"] = r3(s_["cpu_baseline"]["value"])
             if "distributions" in s_:
                 e["dist_ms"] = {k: r3(v["ms"]) for k, v in s_["distributions"].items()}
+            if "fixed_base" in s_ and "value" in s_["fixed_base"]:
+                fb = s_["fixed_base"]
+                e["fixed_base"] = {"value": r3(fb["value"]), "ms": r3(fb["ms"]), "W_ms": r3(fb.get("witness_like_ms")), "equal": fb["equals_plain_result"]}
             if "strong" in s_:
                 e["strong"] = {"value": r3(s_["strong"]["value"]), "ms": r3(s_["strong"]["ms"]), "equal": s_["strong"].get("equals_single_gpu_result")}
             cs[name] = e

@@ -265,6 +265,28 @@ uint64_t zklc_bn254_g2_msm_workspace_bytes(uint64_t n);
 int32_t zklc_bn254_g2_msm_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, const uint64_t *d_scalars, uint64_t n,
                               uint64_t *d_out_affine, uint32_t *d_out_is_infinity, void *d_workspace, uint64_t workspace_bytes);
 
+/* Fixed-base form of the two multi-exponentiations (round 5).  `groth16.Prove` (gnark-plonky2-verifier/cmd/web-api.go:77) multiplies
+ * the SAME bases -- the proving key's pk.G1.A / pk.G1.B / pk.G1.K / pk.G1.Z and pk.G2.B -- by every proof's scalars: a table of
+ * 2^(c w) * P_i for every window w (windows x n packed affine records: 64 bytes per G1 record, 128 per G2; c and the number of
+ * windows are the library's choice for n and are recorded in the table's 256-byte header) is built ONCE per key, and every later
+ * multi-exponentiation adds table points into one bucket set shared by all windows: no closing doublings, one bucket reduction.
+ * Result: the same canonical affine point as zklc_bn254_g{1,2}_msm[_dev] on (points, scalars), bit for bit.
+ *   *_table_bytes(n)   bytes of device memory the table of n bases needs;
+ *   *_table_dev        builds it from n affine points in HBM (layout as for the plain form) into d_table (256-byte aligned);
+ *   *_fixed_dev        the multi-exponentiation of the table's bases by d_scalars (n x 4 u64, regular form); n must be the
+ *                      table's n; workspace as zklc_bn254_g{1,2}_msm_workspace_bytes(n).  ZKLC_ERR_INVALID_ARG if d_table is
+ *                      not a table of this group for n bases.  Enqueue only, except a 20-byte header read. */
+uint64_t zklc_bn254_g1_msm_fixed_table_bytes(uint64_t n);
+int32_t zklc_bn254_g1_msm_fixed_table_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, uint64_t n, void *d_table,
+                                          uint64_t table_bytes);
+int32_t zklc_bn254_g1_msm_fixed_dev(zklc_ctx *ctx, void *stream, const void *d_table, const uint64_t *d_scalars, uint64_t n,
+                                    uint64_t *d_out_affine, uint32_t *d_out_is_infinity, void *d_workspace, uint64_t workspace_bytes);
+uint64_t zklc_bn254_g2_msm_fixed_table_bytes(uint64_t n);
+int32_t zklc_bn254_g2_msm_fixed_table_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, uint64_t n, void *d_table,
+                                          uint64_t table_bytes);
+int32_t zklc_bn254_g2_msm_fixed_dev(zklc_ctx *ctx, void *stream, const void *d_table, const uint64_t *d_scalars, uint64_t n,
+                                    uint64_t *d_out_affine, uint32_t *d_out_is_infinity, void *d_workspace, uint64_t workspace_bytes);
+
 /* Pairing-product checks: is_one[b] = (prod_{i<k} e(P_{b,i}, Q_{b,i}) == 1) for `batch` independent checks.
  * Replaces gnark-crypto `bn254.PairingCheck` behind `groth16.Verify` (gnark-plonky2-verifier/cmd/web-api.go:84) and the EVM
  * pairing precompile the reference's Solidity verifier calls (contracts/hardhat/contracts/Verifier.sol:503-548: k = 4,

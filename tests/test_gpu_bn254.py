@@ -413,3 +413,106 @@ def test_reference_groth16_kat_on_the_gpu(zctx):
     g2 = np.array([[B.g2_to_words(q) for _, q in c] for c in checks], dtype=np.uint64)
     ok, _ = zctx.bn254_pairing_check(g1, g2, 4)
     assert ok.tolist() == [1, 0] * 128
+
+
+# ---------------------------------------------------------------- fixed-base form (zklc_bn254_g{1,2}_msm_fixed_*)
+def _fixed_msm(zctx, pts, sc, group=1):
+    """table built once on the device, then the multi-exponentiation over it: -> (affine words, is_infinity)"""
+    import torch
+    n, aff = pts.shape[0], 8 * group
+    dev = "cuda:%d" % zctx.device_id
+    d_pts = torch.from_numpy(np.ascontiguousarray(pts).view(np.int64)).to(dev)
+    d_sc = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).to(dev)
+    table = zctx.bn254_msm_fixed_table(d_pts, n, group=group)
+    wb = zctx.bn254_g1_msm_workspace_bytes(n) if group == 1 else int(zctx._lib.zklc_bn254_g2_msm_workspace_bytes(n))
+    ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+    d_out = torch.zeros(aff, dtype=torch.int64, device=dev)
+    d_inf = torch.zeros(1, dtype=torch.int32, device=dev)
+    outs = []
+    for _ in range(2):                      # the table is reusable: the second call must give the same point
+        zctx.bn254_msm_fixed_dev(table, d_sc, n, d_out, d_inf, ws, wb, group=group)
+        torch.cuda.synchronize()
+        outs.append((d_out.cpu().numpy().view(np.uint64).copy(), bool(int(d_inf[0]))))
+    assert outs[0][1] == outs[1][1] and np.array_equal(outs[0][0], outs[1][0])
+    return outs[0]
+
+
+@pytest.mark.parametrize("n", [1, 2, 65, 1000, 5000, 40000, 1 << 17])
+def test_fixed_base_g1_equals_the_plain_form_and_the_oracle(zctx, n):
+    """the fixed-base form (table of 2^(c w) P_i, one bucket set for all windows) gives the canonical affine point of the plain form
+    bit for bit: uniform scalars, points at infinity among the bases, zero scalars and scalars >= r (web-api.go:77: the proving
+    key's bases are the same for every proof)"""
+    rng = np.random.default_rng(n + 7)
+    pts = cport.bn254_gen_points(n, 3, 5)
+    sc = rand_scalars(rng, n)
+    if n >= 65:
+        pts[::17] = 0                                           # infinity among the bases
+        sc[5] = 0
+        sc[6] = np.array(scalar_words(bn.R + 12345), dtype=np.uint64)
+        sc[7] = np.array(scalar_words(2**256 - 1), dtype=np.uint64)
+    got, ginf = _fixed_msm(zctx, pts, sc)
+    plain, pinf = zctx.bn254_g1_msm(pts, sc)
+    assert ginf == pinf and np.array_equal(got, plain)
+    red = sc.copy()
+    if n >= 65:
+        red[6] = np.array(scalar_words(12345), dtype=np.uint64)
+        red[7] = np.array(scalar_words((2**256 - 1) % bn.R), dtype=np.uint64)
+    want, winf, _ = cport.bn254_msm(pts, red, nthreads=8)
+    assert ginf == winf and np.array_equal(got, want)
+
+
+def test_fixed_base_g1_distributions_at_2_pow_20(zctx):
+    """witness-like (one bucket of a quarter of a million entries per window -> with ONE bucket set, four million: the heavy-combine
+    path), all scalars equal, scalars below 2^64: fixed-base == the oracle's Pippenger at 2^20"""
+    n = 1 << 20
+    rng = np.random.default_rng(21)
+    pts = cport.bn254_gen_points(n, 11, 7)
+    cases = {"W": witness_like(rng, n),
+             "A1": np.tile(np.array(scalar_words(0x2F0E1D2C3B4A59687766554433221100FFEEDDCCBBAA99887766554433221100 % bn.R), dtype=np.uint64), (n, 1)),
+             "A2": rng.integers(0, 2**63, size=(n, 4), dtype=np.uint64) * np.array([1, 0, 0, 0], dtype=np.uint64)}
+    for name, sc in cases.items():
+        sc = np.ascontiguousarray(sc)
+        got, ginf = _fixed_msm(zctx, pts, sc)
+        want, winf, _ = cport.bn254_msm(pts, sc, nthreads=16)
+        assert ginf == winf and np.array_equal(got, want), name
+
+
+def test_fixed_base_table_is_checked(zctx):
+    """a table of another size (or no table at all) is refused with ZKLC_ERR_INVALID_ARG, not read"""
+    import torch
+    import zklc_amd
+    n = 300
+    dev = "cuda:%d" % zctx.device_id
+    pts = cport.bn254_gen_points(n, 3, 5)
+    d_pts = torch.from_numpy(pts.view(np.int64)).to(dev)
+    table = zctx.bn254_msm_fixed_table(d_pts, n)
+    d_sc = torch.zeros((2 * n, 4), dtype=torch.int64, device=dev)
+    wb = zctx.bn254_g1_msm_workspace_bytes(2 * n)
+    ws = torch.empty(wb, dtype=torch.uint8, device=dev)
+    d_out, d_inf = torch.zeros(8, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    with pytest.raises(zklc_amd.ZklcError):
+        zctx.bn254_msm_fixed_dev(table, d_sc, 2 * n, d_out, d_inf, ws, wb)          # n does not match the table
+    with pytest.raises(zklc_amd.ZklcError):
+        zctx.bn254_msm_fixed_dev(table, d_sc, n, d_out, d_inf, ws, wb, group=2)     # a G1 table handed to the G2 entry point
+    junk = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    junk = junk[(-junk.data_ptr()) % 256:]
+    with pytest.raises(zklc_amd.ZklcError):
+        zctx.bn254_msm_fixed_dev(junk, d_sc, n, d_out, d_inf, ws, wb)
+
+
+def test_fixed_base_g2_equals_the_plain_form(zctx):
+    import random
+    from oracle import bn254 as B
+    for n in (1, 9, 300):
+        pts = _g2_points(n, 100 + n)
+        rng = random.Random(n)
+        sc = [rng.randrange(B.R) for _ in range(n)]
+        if n > 4:
+            sc[2] = 0
+            pts[3] = None                                       # infinity among the bases
+        pa = np.array([B.g2_to_words(p) for p in pts], dtype=np.uint64).reshape(-1, 16)
+        sa = np.array([scalar_words(s) for s in sc], dtype=np.uint64)
+        got, ginf = _fixed_msm(zctx, pa, sa, group=2)
+        plain, pinf = zctx.bn254_g2_msm(pa, sa)
+        assert ginf == pinf and np.array_equal(got, plain), n
+        assert B.g2_from_words([int(x) for x in got], ginf) == B.g2_msm(sc, pts), n

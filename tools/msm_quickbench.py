@@ -65,6 +65,26 @@ with zklc_amd.Context(0) as c:
         ms = e0.elapsed_time(e1) / iters
         print("MSM 2^%d (%s)%s: %.2f ms  %.2f Melem/s  workspace %.0f MB" % (lg, dist, "" if variant is None else " [slice kernel, %s waves per SIMD]" % variant,
                                                                          ms, n / ms / 1e3, wb / 1e6), flush=True)
+        if "--fixed" in sys.argv:
+            # the fixed-base form (round 5): table of 2^(c w) P_i built once, one bucket set for all windows
+            plain = out.cpu().numpy().view(np.uint64).copy()
+            t0 = time.time()
+            table = c.bn254_msm_fixed_table(pts[:n], n, stream=st)
+            torch.cuda.synchronize()
+            t_tab = time.time() - t0
+            ffn = lambda: c.bn254_msm_fixed_dev(table, sc, n, out, inf, ws, wb, stream=st)
+            ffn()
+            torch.cuda.synchronize()
+            e0.record(st)
+            for _ in range(iters):
+                ffn()
+            e1.record(st)
+            torch.cuda.synchronize()
+            fms = e0.elapsed_time(e1) / iters
+            same = bool(np.array_equal(out.cpu().numpy().view(np.uint64), plain))
+            print("   fixed-base: %.2f ms  %.2f Melem/s  (table %.0f MB built in %.2f s)  equals the plain form: %s" % (
+                fms, n / fms / 1e3, table.numel() / 1e6, t_tab, same), flush=True)
+            del table
         if lg <= 20:
             t0 = time.time()
             want, winf, used = cport.bn254_msm(pts_h[:n], sc_d[:n], nthreads=16)

@@ -54,6 +54,14 @@ _SIGS = {
     "zklc_bn254_g2_msm_workspace_bytes": (ctypes.c_uint64, [ctypes.c_uint64]),
     "zklc_bn254_g2_msm_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _u8p, _u8p,
                                                ctypes.c_uint64]),
+    "zklc_bn254_g1_msm_fixed_table_bytes": (ctypes.c_uint64, [ctypes.c_uint64]),
+    "zklc_bn254_g1_msm_fixed_table_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint64, _u8p, ctypes.c_uint64]),
+    "zklc_bn254_g1_msm_fixed_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _u8p, _u8p,
+                                                     ctypes.c_uint64]),
+    "zklc_bn254_g2_msm_fixed_table_bytes": (ctypes.c_uint64, [ctypes.c_uint64]),
+    "zklc_bn254_g2_msm_fixed_table_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint64, _u8p, ctypes.c_uint64]),
+    "zklc_bn254_g2_msm_fixed_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint64, _u8p, _u8p, _u8p,
+                                                     ctypes.c_uint64]),
     "zklc_bn254_pairing_check": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint32, ctypes.c_uint32, _u8p, _u8p]),
     "zklc_bn254_pairing_check_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, _u8p, ctypes.c_uint32, ctypes.c_uint32,
                                                       _u8p, _u8p]),

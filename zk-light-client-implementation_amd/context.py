@@ -220,6 +220,26 @@ class Context:
     def bn254_g1_msm_dev(self, d_points, d_scalars, n, d_out, d_inf, d_workspace, workspace_bytes, stream=None):
         self._check(self._lib.zklc_bn254_g1_msm_dev(self._h, _stream_ptr(stream), _dev_ptr(d_points), _dev_ptr(d_scalars), n,
                                                     _dev_ptr(d_out), _dev_ptr(d_inf), _dev_ptr(d_workspace), workspace_bytes))
+    # ---- fixed-base form (a Groth16 proving key's bases: the table is built once, include/zklc.h)
+    def bn254_msm_fixed_table(self, d_points, n, group=1, stream=None):
+        """-> a torch uint8 tensor in HBM holding the table of 2^(c w) P_i for the n affine points at d_points (G1: uint64 [n, 8],
+        group=2: uint64 [n, 16]); pass it to bn254_msm_fixed_dev.  windows x n x 64 (128) bytes."""
+        import torch
+        lib = self._lib
+        size_fn, build_fn = ((lib.zklc_bn254_g1_msm_fixed_table_bytes, lib.zklc_bn254_g1_msm_fixed_table_dev) if group == 1 else
+                             (lib.zklc_bn254_g2_msm_fixed_table_bytes, lib.zklc_bn254_g2_msm_fixed_table_dev))
+        nbytes = int(size_fn(n))
+        table = torch.empty(nbytes + 256, dtype=torch.uint8, device="cuda:%d" % self.device_id)
+        off = (-table.data_ptr()) % 256
+        table = table[off:off + nbytes]
+        self._check(build_fn(self._h, _stream_ptr(stream), _dev_ptr(d_points), n, table.data_ptr(), nbytes))
+        return table
+
+    def bn254_msm_fixed_dev(self, table, d_scalars, n, d_out, d_inf, d_workspace, workspace_bytes, group=1, stream=None):
+        fn = self._lib.zklc_bn254_g1_msm_fixed_dev if group == 1 else self._lib.zklc_bn254_g2_msm_fixed_dev
+        self._check(fn(self._h, _stream_ptr(stream), table.data_ptr(), _dev_ptr(d_scalars), n, _dev_ptr(d_out), _dev_ptr(d_inf),
+                       _dev_ptr(d_workspace), workspace_bytes))
+
     def bn254_g2_msm(self, points, scalars):
         """points: uint64 [n, 16] (gnark Montgomery affine G2: X.A0, X.A1, Y.A0, Y.A1), scalars: uint64 [n, 4].
         Returns (uint64[16] affine result, is_infinity)."""

@@ -121,11 +121,14 @@ __global__ void __launch_bounds__(256) msm_totals_kernel(u32 *__restrict__ cnt, 
 // ---- 2c. scatter of tile (k, w): LDS cursors start at (bucket offset + prefix of this tile)
 __global__ void __launch_bounds__(MSM_SORT_THREADS)
 msm_scatter_kernel(const unsigned short *__restrict__ dig, msm_plan pl, const u32 *__restrict__ cnt, const u32 *__restrict__ offsets,
-                   u32 *__restrict__ entries) {
+                   u32 *__restrict__ entries, u32 fixed_n) {
+    // fixed_n != 0 (fixed-base form): ONE bucket set for all windows -- the offsets are indexed by the bucket alone -- and an entry
+    // names row (w, i) of the table of 2^(c w) P_i: index w * fixed_n + i
     extern __shared__ u32 msm_lds[];
     const u32 bpw = pl.buckets_per_window, k = blockIdx.x, w = blockIdx.y;
     const u32 *pre = cnt + ((size_t)w * pl.chunks + k) * bpw;
-    for (u32 b = threadIdx.x; b < bpw; b += MSM_SORT_THREADS) msm_lds[b] = offsets[(size_t)w * bpw + b] + pre[b];
+    const u32 row_base = w * fixed_n;
+    for (u32 b = threadIdx.x; b < bpw; b += MSM_SORT_THREADS) msm_lds[b] = offsets[(fixed_n ? 0 : (size_t)w * bpw) + b] + pre[b];
     __syncthreads();
     const unsigned short *row = dig + (size_t)w * pl.n_pad;
     u32 lo = k * pl.chunk_len, hi = lo + pl.chunk_len < pl.n_pad ? lo + pl.chunk_len : pl.n_pad;
@@ -138,7 +141,7 @@ msm_scatter_kernel(const unsigned short *__restrict__ dig, msm_plan pl, const u3
                 u32 neg;
                 u32 b = msm_code_bucket(code[j], neg);
                 u32 pos = atomicAdd(&msm_lds[b], 1u);
-                entries[pos] = ((i + j) << 1) | neg;
+                entries[pos] = ((row_base + i + j) << 1) | neg;
             }
     }
 }
@@ -339,6 +342,17 @@ __global__ void __launch_bounds__(msm_cfg<F>::BLOCK) msm_final_kernel(const i32 
     const int XY = msm_cfg<F>::XYZZ;
     __shared__ i32 lds[msm_cfg<F>::BLOCK * msm_cfg<F>::XYZZ];
     ec_xyzz<F> acc = ec_infinity<F>();
+    if (pl.windows == 1) {              // the fixed-base form: one window, nothing to double or to add -- only the affine conversion
+        if (threadIdx.x == 0) {
+            acc = msm_load_xyzz<F>(win_out);
+            const int W = 2 * msm_cfg<F>::AFF;
+            u32 o[W];
+            u32 inf = ec_to_affine_gnark(o, acc);
+            for (int k = 0; k < W / 2; k++) out_affine[k] = (u64)o[2 * k] | ((u64)o[2 * k + 1] << 32);
+            *out_inf = inf;
+        }
+        return;
+    }
     // a quad of lanes per window shares every doubling (G1 and G2); with more windows than quads (tiny inputs) one lane per window
     const bool quads = 4 * pl.windows <= (u32)msm_cfg<F>::BLOCK;
     if (quads && threadIdx.x < 4 * pl.windows) {
@@ -361,6 +375,68 @@ __global__ void __launch_bounds__(msm_cfg<F>::BLOCK) msm_final_kernel(const i32 
         u32 inf = ec_to_affine_gnark(o, acc);
         for (int k = 0; k < W / 2; k++) out_affine[k] = (u64)o[2 * k] | ((u64)o[2 * k + 1] << 32);
         *out_inf = inf;
+    }
+}
+
+// ---------------------------------------------------------------- fixed-base form (round 5)
+// A Groth16 proving key is a FIXED set of bases (gnark-plonky2-verifier/cmd/web-api.go:77 multiplies the same pk.G1.A / B / K / Z
+// by every proof's witness): row w of the table holds 2^(c w) P_i as packed affine records, so the digit of window w adds a table
+// point straight into ONE bucket set shared by all windows -- no 2^(c w) doublings at the end (the 240-doubling serial chain, 0.9 ms
+// of a 2^22 multi-exponentiation) and one bucket reduction instead of sixteen.  Same additions per point, same result (the affine
+// output is canonical: tests compare it with the plain form bit for bit); 16 x the memory of the bases, built once.
+#define MSM_TABLE_HEADER_WORDS 64          // 256 bytes: [magic, n, c, windows, words per record]
+#define MSM_TABLE_MAGIC 0x7a6b6c54u
+template <class F>
+__global__ void __launch_bounds__(64) msm_fixed_table_kernel(const u64 *__restrict__ points, u32 n, u32 c, u32 windows, i32 *__restrict__ table) {
+    typedef typename F::T T;
+    const int W = msm_rec<F, true>::WORDS;
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (msm_point_is_inf<msm_cfg<F>::AFF>(points, i)) {          // all-zero records: the recoding gives such a point no digit
+        for (u32 w = 0; w < windows; w++)
+            for (int k = 0; k < W; k++) table[((size_t)w * n + i) * W + k] = 0;
+        return;
+    }
+    T x, y;
+    msm_load_point<F>(points, i, x, y);
+    x = F::reduce(x);
+    y = F::reduce(y);
+#pragma unroll 1
+    for (u32 w = 0; w < windows; w++) {
+        u32 *dst = reinterpret_cast<u32 *>(table + ((size_t)w * n + i) * W);
+        F::pack(dst, x);
+        F::pack(dst + F::PACKW, y);
+        if (w + 1 == windows) break;
+        ec_xyzz<F> acc;
+        acc.X = x;
+        acc.Y = y;
+        acc.ZZ = acc.ZZZ = F::one();
+#pragma unroll 1
+        for (u32 k = 0; k < c; k++) acc = ec_double(acc);
+        T inv = F::inv(F::mul(acc.ZZ, acc.ZZZ));                // a point of prime order never doubles to infinity
+        x = F::reduce(F::mul(acc.X, F::mul(inv, acc.ZZZ)));
+        y = F::reduce(F::mul(acc.Y, F::mul(inv, acc.ZZ)));
+    }
+}
+// digits of the scalars; a base is skipped when its table record is all zeros (= the point at infinity)
+template <class F>
+__global__ void __launch_bounds__(256)
+msm_recode_fixed_kernel(const i32 *__restrict__ table, const u64 *__restrict__ scalars, msm_plan pl, unsigned short *__restrict__ dig) {
+    const int W = msm_rec<F, true>::WORDS;
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pl.n_pad) return;
+    bool live = i < pl.n;
+    if (live) {
+        i32 acc = 0;
+        for (int k = 0; k < W; k++) acc |= table[(size_t)i * W + k];
+        live = acc != 0;
+    }
+    u32 sw[8];
+    if (live) msm_load_scalar(scalars, i, sw);
+    u32 carry = 0;
+    for (u32 w = 0; w < pl.windows; w++) {
+        int d = live ? msm_digit(sw, w, pl.c, carry) : 0;
+        dig[(size_t)w * pl.n_pad + i] = (unsigned short)msm_digit_code(d);
     }
 }
 
@@ -410,18 +486,29 @@ static hipError_t msm_sort_lds_attr() {
 
 template <class F>
 static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, const uint64_t *d_scalars, uint64_t n,
-                           uint64_t *d_out_affine, uint32_t *d_out_inf, void *d_workspace, uint64_t workspace_bytes) {
+                           uint64_t *d_out_affine, uint32_t *d_out_inf, void *d_workspace, uint64_t workspace_bytes,
+                           const i32 *fixed_table = nullptr) {
+    // fixed_table != nullptr: the fixed-base form -- d_points is not read, the records come from the table (rows of 2^(c w) P_i)
+    const bool fixed = fixed_table != nullptr;
     const int AFF = msm_cfg<F>::AFF;
     const size_t XB = msm_cfg<F>::XYZZ * 4;
-    if (!ctx || !d_out_affine || !d_out_inf || (n && (!d_points || !d_scalars)) || n >= (1ULL << 30)) return ZKLC_ERR_INVALID_ARG;
+    if (!ctx || !d_out_affine || !d_out_inf || (n && ((!fixed && !d_points) || !d_scalars)) || n >= (1ULL << 30)) return ZKLC_ERR_INVALID_ARG;
     if (((uintptr_t)d_points | (uintptr_t)d_scalars) & 15) return ZKLC_ERR_INVALID_ARG;
     ZKLC_HIP(ctx, hipSetDevice(ctx->device));
     ZKLC_HIP(ctx, msm_sort_lds_attr());
     hipStream_t st = zklc_pick_stream(ctx, stream);
-    msm_plan pl = msm_make_plan(n, F::LIMBS == 10 && msm_glv_enabled());
+    msm_plan pl = msm_make_plan(n, !fixed && F::LIMBS == 10 && msm_glv_enabled());
+    if (fixed && (uint64_t)pl.n * pl.windows >= (1ULL << 31)) return ZKLC_ERR_INVALID_ARG;       // entry = (row index << 1) | sign
+    // the view of the kernels behind the sort: ONE window whose tiles are all (chunk, window) tiles of the sort
+    msm_plan pm = pl;
+    if (fixed) {
+        pm.windows = 1;
+        pm.chunks = pl.windows * pl.chunks;
+        pm.total_buckets = pl.buckets_per_window;
+    }
     if (workspace_bytes < msm_workspace_bytes<F>(n) || !d_workspace) return ZKLC_ERR_INVALID_ARG;
     u32 seg_per_window = (pl.buckets_per_window + MSM_SEG - 1) / MSM_SEG;
-    // carve the workspace (256-byte aligned pieces)
+    // carve the workspace (256-byte aligned pieces; sized for the plain form, which needs more)
     char *p = (char *)d_workspace;
     auto take = [&](size_t bytes) {
         char *r = p;
@@ -448,8 +535,12 @@ static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points
 
     ZKLC_HIP(ctx, hipMemsetAsync(heavy_count, 0, 16, st));
     const char *pkv = getenv("ZKLC_MSM_PACKED");          // A/B: 0 = point records of ten 32-bit limbs per coordinate (default packed)
-    const bool packed = !(pkv && pkv[0] == '0');
-    if (pl.n) {
+    const bool packed = fixed || !(pkv && pkv[0] == '0');          // a table holds packed records
+    if (pl.n && fixed) {
+        hipLaunchKernelGGL((msm_recode_fixed_kernel<F>), dim3((pl.n_pad + 255) / 256), dim3(256), 0, st, fixed_table, d_scalars, pl, dig);
+        hipLaunchKernelGGL(msm_hist_kernel, dim3(pl.chunks, pl.windows), dim3(MSM_SORT_THREADS), lds, st, (const unsigned short *)dig, pl,
+                           tile_cnt);
+    } else if (pl.n) {
         if constexpr (F::LIMBS == 10) {
             if (pl.glv) {
                 const unsigned grid = (pl.n_pts + 255) / 256;
@@ -466,21 +557,23 @@ static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points
     } else {
         ZKLC_HIP(ctx, hipMemsetAsync(tile_cnt, 0, (size_t)pl.total_buckets * pl.chunks * 4, st));
     }
-    hipLaunchKernelGGL(msm_totals_kernel, dim3((pl.total_buckets + 255) / 256), dim3(256), 0, st, tile_cnt, pl, totals);
-    hipLaunchKernelGGL(msm_scan_block_kernel, dim3(nblocks), dim3(256), 0, st, (const u32 *)totals, offsets, block_sums, pl.total_buckets);
-    hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(1), dim3(256), 0, st, block_sums, nblocks);
-    hipLaunchKernelGGL(msm_scan_add_kernel, dim3((pl.total_buckets + 255) / 256), dim3(256), 0, st, offsets, (const u32 *)block_sums,
-                       pl.total_buckets);
+    const u32 nblocks_m = (pm.total_buckets + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    hipLaunchKernelGGL(msm_totals_kernel, dim3((pm.total_buckets + 255) / 256), dim3(256), 0, st, tile_cnt, pm, totals);
+    hipLaunchKernelGGL(msm_scan_block_kernel, dim3(nblocks_m), dim3(256), 0, st, (const u32 *)totals, offsets, block_sums, pm.total_buckets);
+    hipLaunchKernelGGL(msm_scan_sums_kernel, dim3(1), dim3(256), 0, st, block_sums, nblocks_m);
+    hipLaunchKernelGGL(msm_scan_add_kernel, dim3((pm.total_buckets + 255) / 256), dim3(256), 0, st, offsets, (const u32 *)block_sums,
+                       pm.total_buckets);
     if (pl.n) {
         hipLaunchKernelGGL(msm_scatter_kernel, dim3(pl.chunks, pl.windows), dim3(MSM_SORT_THREADS), lds, st, (const unsigned short *)dig, pl,
-                           (const u32 *)tile_cnt, (const u32 *)offsets, entries);
+                           (const u32 *)tile_cnt, (const u32 *)offsets, entries, fixed ? pl.n : 0u);
     }
     // the bucket array starts as infinity (all-zero limbs): empty buckets are never written
-    ZKLC_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)pl.total_buckets * XB, st));
+    ZKLC_HIP(ctx, hipMemsetAsync(buckets, 0, (size_t)pm.total_buckets * XB, st));
+    const i32 *recs = fixed ? fixed_table : (const i32 *)cpoints;
     if (pl.n) {
         // A/B switches: ZKLC_MSM_PACKED = 0 / 1 (point records of 10 x 32-bit limbs per coordinate / packed 8 x 32 bits, default packed),
         // ZKLC_MSM_WAVES = 1..3: waves per SIMD the G1 slice kernel's register allocation keeps
-        if (!pl.glv) {
+        if (!pl.glv && !fixed) {
             if (packed)
                 hipLaunchKernelGGL((msm_convert_kernel<F, true>), dim3((pl.n + 255) / 256), dim3(256), 0, st, d_points, pl.n, cpoints);
             else
@@ -493,11 +586,11 @@ static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points
 #define MSM_SLICE_LAUNCH(W)                                                                                                          \
     do {                                                                                                                             \
         if (packed)                                                                                                                  \
-            hipLaunchKernelGGL((msm_slice_kernel<F, W, true>), g, b, 0, st, (const i32 *)cpoints, (const u32 *)entries,              \
-                               (const u32 *)offsets, (const u32 *)totals, pl, buckets, partials);                                   \
+            hipLaunchKernelGGL((msm_slice_kernel<F, W, true>), g, b, 0, st, recs, (const u32 *)entries,                              \
+                               (const u32 *)offsets, (const u32 *)totals, pm, buckets, partials);                                   \
         else                                                                                                                         \
-            hipLaunchKernelGGL((msm_slice_kernel<F, W, false>), g, b, 0, st, (const i32 *)cpoints, (const u32 *)entries,             \
-                               (const u32 *)offsets, (const u32 *)totals, pl, buckets, partials);                                   \
+            hipLaunchKernelGGL((msm_slice_kernel<F, W, false>), g, b, 0, st, recs, (const u32 *)entries,                             \
+                               (const u32 *)offsets, (const u32 *)totals, pm, buckets, partials);                                   \
     } while (0)
         if constexpr (F::LIMBS != 10) {
             MSM_SLICE_LAUNCH(1);
@@ -510,14 +603,14 @@ static int32_t msm_run_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points
         }
 #undef MSM_SLICE_LAUNCH
     }
-    hipLaunchKernelGGL(msm_combine_kernel<F>, dim3((pl.total_buckets + 63) / 64), dim3(64), 0, st, (const u32 *)offsets, (const u32 *)totals,
-                       pl, (const i32 *)partials, buckets, heavy_list, heavy_count);
+    hipLaunchKernelGGL(msm_combine_kernel<F>, dim3((pm.total_buckets + 63) / 64), dim3(64), 0, st, (const u32 *)offsets, (const u32 *)totals,
+                       pm, (const i32 *)partials, buckets, heavy_list, heavy_count);
     hipLaunchKernelGGL(msm_heavy_combine_kernel<F>, dim3(MSM_MAX_HEAVY), dim3(BLK), 0, st, (const u32 *)offsets, (const u32 *)totals,
                        (const i32 *)partials, buckets, (const u32 *)heavy_list, (const u32 *)heavy_count);
-    hipLaunchKernelGGL(msm_segment_kernel<F>, dim3((seg_per_window * pl.windows + 63) / 64), dim3(64), 0, st, (const i32 *)buckets, pl,
+    hipLaunchKernelGGL(msm_segment_kernel<F>, dim3((seg_per_window * pm.windows + 63) / 64), dim3(64), 0, st, (const i32 *)buckets, pm,
                        seg_out);
-    hipLaunchKernelGGL(msm_window_kernel<F>, dim3(pl.windows), dim3(BLK), 0, st, (const i32 *)seg_out, pl, win_out);
-    hipLaunchKernelGGL(msm_final_kernel<F>, dim3(1), dim3(BLK), 0, st, (const i32 *)win_out, pl, d_out_affine, d_out_inf);
+    hipLaunchKernelGGL(msm_window_kernel<F>, dim3(pm.windows), dim3(BLK), 0, st, (const i32 *)seg_out, pm, win_out);
+    hipLaunchKernelGGL(msm_final_kernel<F>, dim3(1), dim3(BLK), 0, st, (const i32 *)win_out, pm, d_out_affine, d_out_inf);
     ZKLC_HIP(ctx, hipGetLastError());
     return ZKLC_OK;
 }
@@ -557,6 +650,60 @@ extern "C" int32_t zklc_bn254_g1_msm(zklc_ctx *ctx, const uint64_t *points, cons
                                      uint32_t *out_is_infinity) {
     return msm_run_host<FpField>(ctx, points, scalars, n, out_affine, out_is_infinity);
 }
+// ---- fixed-base form: table construction and the multi-exponentiation over a table
+template <class F>
+static uint64_t msm_fixed_table_bytes(uint64_t n) {
+    msm_plan pl = msm_make_plan(n, false);
+    return (uint64_t)MSM_TABLE_HEADER_WORDS * 4 + (uint64_t)pl.windows * pl.n * msm_rec<F, true>::WORDS * 4;
+}
+template <class F>
+static int32_t msm_fixed_table_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, uint64_t n, void *d_table, uint64_t table_bytes) {
+    if (!ctx || !d_table || (n && !d_points) || n >= (1ULL << 30) || ((uintptr_t)d_table & 255)) return ZKLC_ERR_INVALID_ARG;
+    if (table_bytes < msm_fixed_table_bytes<F>(n)) return ZKLC_ERR_INVALID_ARG;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = zklc_pick_stream(ctx, stream);
+    msm_plan pl = msm_make_plan(n, false);
+    u32 hdr[MSM_TABLE_HEADER_WORDS] = {MSM_TABLE_MAGIC, pl.n, pl.c, pl.windows, (u32)msm_rec<F, true>::WORDS};
+    ZKLC_HIP(ctx, hipMemcpyAsync(d_table, hdr, sizeof(hdr), hipMemcpyHostToDevice, st));
+    ZKLC_HIP(ctx, zklc_stream_wait(st));                 // hdr lives on this stack frame
+    if (pl.n)
+        hipLaunchKernelGGL((msm_fixed_table_kernel<F>), dim3((pl.n + 63) / 64), dim3(64), 0, st, d_points, pl.n, pl.c, pl.windows,
+                           (i32 *)d_table + MSM_TABLE_HEADER_WORDS);
+    ZKLC_HIP(ctx, hipGetLastError());
+    return ZKLC_OK;
+}
+template <class F>
+static int32_t msm_fixed_run_dev(zklc_ctx *ctx, void *stream, const void *d_table, const uint64_t *d_scalars, uint64_t n,
+                                 uint64_t *d_out_affine, uint32_t *d_out_inf, void *d_workspace, uint64_t workspace_bytes) {
+    if (!ctx || !d_table || ((uintptr_t)d_table & 255)) return ZKLC_ERR_INVALID_ARG;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    u32 hdr[5];
+    ZKLC_HIP(ctx, hipMemcpy(hdr, d_table, sizeof(hdr), hipMemcpyDeviceToHost));     // 20 bytes: is this a table for n bases of this group?
+    msm_plan pl = msm_make_plan(n, false);
+    if (hdr[0] != MSM_TABLE_MAGIC || hdr[1] != pl.n || hdr[2] != pl.c || hdr[3] != pl.windows || hdr[4] != (u32)msm_rec<F, true>::WORDS)
+        return ZKLC_ERR_INVALID_ARG;
+    return msm_run_dev<F>(ctx, stream, nullptr, d_scalars, n, d_out_affine, d_out_inf, d_workspace, workspace_bytes,
+                          (const i32 *)d_table + MSM_TABLE_HEADER_WORDS);
+}
+extern "C" uint64_t zklc_bn254_g1_msm_fixed_table_bytes(uint64_t n) { return msm_fixed_table_bytes<FpField>(n); }
+extern "C" int32_t zklc_bn254_g1_msm_fixed_table_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, uint64_t n, void *d_table,
+                                                     uint64_t table_bytes) {
+    return msm_fixed_table_dev<FpField>(ctx, stream, d_points, n, d_table, table_bytes);
+}
+extern "C" int32_t zklc_bn254_g1_msm_fixed_dev(zklc_ctx *ctx, void *stream, const void *d_table, const uint64_t *d_scalars, uint64_t n,
+                                               uint64_t *d_out_affine, uint32_t *d_out_inf, void *d_workspace, uint64_t workspace_bytes) {
+    return msm_fixed_run_dev<FpField>(ctx, stream, d_table, d_scalars, n, d_out_affine, d_out_inf, d_workspace, workspace_bytes);
+}
+extern "C" uint64_t zklc_bn254_g2_msm_fixed_table_bytes(uint64_t n) { return msm_fixed_table_bytes<Fp2Field>(n); }
+extern "C" int32_t zklc_bn254_g2_msm_fixed_table_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, uint64_t n, void *d_table,
+                                                     uint64_t table_bytes) {
+    return msm_fixed_table_dev<Fp2Field>(ctx, stream, d_points, n, d_table, table_bytes);
+}
+extern "C" int32_t zklc_bn254_g2_msm_fixed_dev(zklc_ctx *ctx, void *stream, const void *d_table, const uint64_t *d_scalars, uint64_t n,
+                                               uint64_t *d_out_affine, uint32_t *d_out_inf, void *d_workspace, uint64_t workspace_bytes) {
+    return msm_fixed_run_dev<Fp2Field>(ctx, stream, d_table, d_scalars, n, d_out_affine, d_out_inf, d_workspace, workspace_bytes);
+}
+
 extern "C" uint64_t zklc_bn254_g2_msm_workspace_bytes(uint64_t n) { return msm_workspace_bytes<Fp2Field>(n); }
 extern "C" int32_t zklc_bn254_g2_msm_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_points, const uint64_t *d_scalars, uint64_t n,
                                          uint64_t *d_out_affine, uint32_t *d_out_inf, void *d_workspace, uint64_t workspace_bytes) {
