@@ -382,11 +382,18 @@ __global__ void gl_group_twiddle_kernel(u64 *out, u64 w, u32 g, u32 s_first, u64
 }
 
 // out[i] = in[bitrev(i)] (per polynomial)
-__global__ void __launch_bounds__(256) gl_bitrev_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t stride, int logn) {
+// in place: element i and element bitrev(i) change places (the lower index of every pair does the swap).  Round 5: replaces a
+// device-to-device copy into scratch followed by the out-of-place kernel -- half the traffic, no scratch buffer.
+__global__ void __launch_bounds__(256) gl_bitrev_inplace_kernel(u64 *__restrict__ data, size_t stride, int logn) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (1ULL << logn)) return;
     u64 r = __brevll(i) >> (64 - logn);
-    out[(size_t)blockIdx.y * stride + i] = in[(size_t)blockIdx.y * stride + r];
+    if (i < r) {
+        u64 *p = data + (size_t)blockIdx.y * stride;
+        u64 a = p[i], b = p[r];
+        p[i] = b;
+        p[r] = a;
+    }
 }
 
 // ---------------------------------------------------------------- Poseidon / Merkle
@@ -798,12 +805,20 @@ extern "C" int32_t zklc_gl_ntt_dev(zklc_ctx *ctx, void *stream, uint64_t *d_data
     if (in_br) return gl_ntt_run(ctx, st, d_data, n, d_data, n, log_n, log_n, batch, inverse, true, 0);
     int32_t rc = gl_ntt_run(ctx, st, d_data, n, d_data, n, log_n, log_n, batch, inverse, false, coset_shift);
     if (rc || out_br) return rc;
-    // natural order requested: permute through the context scratch buffer
-    void *tmp;
-    if ((rc = zklc_stage(ctx, 7, n * batch * 8, &tmp))) return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(tmp, d_data, n * batch * 8, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(gl_bitrev_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, st, (const u64 *)tmp, d_data, n,
-                       (int)log_n);
+    // natural order requested: swap i <-> bitrev(i) in place
+    hipLaunchKernelGGL(gl_bitrev_inplace_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, st, d_data, n, (int)log_n);
+    ZKLC_HIP(ctx, hipGetLastError());
+    return ZKLC_OK;
+}
+
+int32_t zklc_gl_intt_copy_dev(zklc_ctx *ctx, hipStream_t st, const uint64_t *d_src, uint64_t *d_dst, uint32_t log_n, uint32_t batch) {
+    if (!ctx || !d_src || !d_dst || log_n > ZKLC_GL_MAX_LOG) return ZKLC_ERR_INVALID_ARG;
+    if (batch == 0) return ZKLC_OK;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    size_t n = 1ULL << log_n;
+    int32_t rc = gl_ntt_run(ctx, st, d_src, n, d_dst, n, log_n, log_n, batch, true, false, 0);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gl_bitrev_inplace_kernel, dim3((unsigned)((n + 255) / 256), batch), dim3(256), 0, st, d_dst, n, (int)log_n);
     ZKLC_HIP(ctx, hipGetLastError());
     return ZKLC_OK;
 }
@@ -818,11 +833,7 @@ extern "C" int32_t zklc_gl_lde_dev(zklc_ctx *ctx, void *stream, const uint64_t *
     size_t n = 1ULL << log_n, N = 1ULL << logN;
     int32_t rc = gl_ntt_run(ctx, st, d_coeffs, n, d_out, N, logN, log_n, batch, false, false, coset_shift);
     if (rc || (flags & ZKLC_NTT_OUT_BITREV)) return rc;
-    void *tmp;
-    if ((rc = zklc_stage(ctx, 7, N * batch * 8, &tmp))) return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(tmp, d_out, N * batch * 8, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(gl_bitrev_kernel, dim3((unsigned)((N + 255) / 256), batch), dim3(256), 0, st, (const u64 *)tmp, d_out, N,
-                       logN);
+    hipLaunchKernelGGL(gl_bitrev_inplace_kernel, dim3((unsigned)((N + 255) / 256), batch), dim3(256), 0, st, d_out, N, logN);
     ZKLC_HIP(ctx, hipGetLastError());
     return ZKLC_OK;
 }

@@ -1475,8 +1475,9 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
 
     // ---- wires commitment
     std::vector<uint8_t> wires_cap, zs_cap, quot_cap;
-    ZKLC_HIP(ctx, hipMemcpyAsync(c->wires.coeffs, d_wires, (size_t)P.num_wires * n * 8, hipMemcpyDeviceToDevice, st));
-    P2_RC(p2_commit_values(c, st, c->wires, wires_cap));
+    // values -> coefficients out of place (the wire values stay where the caller put them: Z and the partial products read them)
+    P2_RC(zklc_gl_intt_copy_dev(ctx, st, d_wires, c->wires.coeffs, P.degree_bits, P.num_wires));
+    P2_RC(p2_commit_coeffs(c, st, c->wires, wires_cap));
     p2_observe_cap(ch, wires_cap, hasher);
     p2_challenges chal = {};
     for (u32 k = 0; k < nch; k++) chal.beta[k] = ch.challenge();

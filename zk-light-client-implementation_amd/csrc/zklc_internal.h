@@ -103,6 +103,10 @@ void zklc_bn254_fr_ntt_fini(zklc_ctx *ctx);
 
 // Merkle commit with an explicit leaf layout: element q of leaf i at d_mat[q * stride + i * leaf_stride]
 // (poly-major LDE matrices: leaf_stride 1; row-major FRI leaves: stride 1, leaf_stride = width)
+// values -> coefficients (natural order) from `d_src` into `d_dst` (d_src is not modified; the first pass reads it, the rest runs in
+// place on d_dst): the prover keeps the wire values and needs the coefficients -- no device-to-device copy in front of an in-place
+// transform
+int32_t zklc_gl_intt_copy_dev(zklc_ctx *ctx, hipStream_t st, const uint64_t *d_src, uint64_t *d_dst, uint32_t log_n, uint32_t batch);
 int32_t zklc_gl_merkle_commit_strided(zklc_ctx *ctx, hipStream_t st, const uint64_t *d_mat, uint64_t stride, uint64_t leaf_stride,
                                       uint32_t log_leaves, uint32_t width, uint32_t cap_height, uint64_t *d_tree);
 int32_t zklc_bn254_merkle_commit_strided(zklc_ctx *ctx, hipStream_t st, const uint64_t *d_mat, uint64_t stride, uint64_t leaf_stride,
