@@ -191,3 +191,51 @@ def test_wire_format_roundtrip_and_rejects_garbage():
             D.decode_obj(bad)
     with pytest.raises(TypeError):
         D.encode_obj({"f": lambda: 0})
+
+
+def _ok_worker(rank, world, port, failing, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib
+    PL = importlib.import_module("zk-light-client-implementation_amd.pipeline")
+    D = importlib.import_module("zk-light-client-implementation_amd.distributed")
+    # the strong form's checkpoint on a stand-in pipeline: the rank in `failing` has an error, every rank must raise -- the failing one
+    # its own exception, the others RemoteRankFailed -- after setting the exception on the futures its threads wait on
+    p = object.__new__(PL.BlockPipeline)
+    p.rank, p.world, p.comm_device, p.nthreads, p._sig_failed = rank, world, None, 2, False
+    st = p._new_state([(b"msg", [], [])], True)
+    if rank in failing:
+        p._fail(st, ValueError("rank %d broke" % rank))
+    try:
+        p._strong_checkpoint(st, [])
+        out = "passed"
+    except D.RemoteRankFailed:
+        out = "remote"
+    except ValueError:
+        out = "own"
+    fut = st["sets"][0].future
+    q.put((rank, out, fut.done() and fut.exception() is not None, D.all_ok(True), D.all_ok(rank != 0)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,failing", [(2, [1]), (3, [0]), (2, [])])
+def test_a_failed_rank_fails_the_block_on_every_rank(world, failing):
+    """in the strong form a rank's failure must reach the others BEFORE any exchange (pipeline._strong_checkpoint over
+    distributed.all_ok, a MIN all-reduce): nobody folds a partial aggregate, nobody waits for a proof that will not come"""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_ok_worker, args=(r, world, port, failing, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, fut_failed, ok_all, ok_some in res:
+        if not failing:
+            assert out == "passed" and not fut_failed
+        else:
+            assert out == ("own" if rank in failing else "remote") and fut_failed
+        assert ok_all is True and ok_some is False

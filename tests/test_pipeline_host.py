@@ -69,3 +69,66 @@ def test_prewarm_jobs_of_the_mainnet_window():
     assert len({block_num_of(n) for n in sha}) <= len(sha)
     epoch = BlockWindow.from_fixture(load_golden("block_window_epoch_CRTZ.json"))
     assert len([j for j in prewarm_jobs(epoch) if j[0] == "sha256"]) >= 6
+
+
+# ---- the signature stage's thread protocol on stand-ins (no GPU): ADVICE r04 -- a failing prover must not leak its wire-matrix slot
+# or leave the witness producer blocked, and the first witness chunk must fit the buffers
+def _fake_signature_stage(n_sig, nthreads, wchunk, fail_on=None):
+    import queue
+    import threading
+    import numpy as np
+    from zklc_amd import pipeline as PL
+    p = object.__new__(PL.BlockPipeline)
+    p.nthreads, p.wchunk, p.nbuf, p.dev_wit = nthreads, wchunk, 2, False
+    p._lock, p._sig_failed = threading.Lock(), False
+    p.ed_ctxs = [None] * (nthreads - 1)
+    chunks, proved = [], []
+
+    class Data:
+        def generate_witness_native(self, fills, out, threads):
+            assert len(fills) <= len(out) <= wchunk, "a witness chunk larger than the buffer"
+            chunks.append(len(fills))
+            return None, [[7]] * len(fills)
+
+    class Prover:
+        def prove_host_ptr(self, ptr, pis):
+            proved.append(ptr)
+            if fail_on is not None and len(proved) > fail_on:
+                raise RuntimeError("stand-in prover failure")
+            return b"proof"
+    ent = PL._EdCircuit()
+    ent.data, ent.provers = Data(), [Prover() for _ in p.ed_ctxs]
+    ent.views = [np.zeros((wchunk, 1, 1), dtype=np.uint64) for _ in range(p.nbuf)]
+    ent.free_slots, ent.slot_left = queue.Queue(), [0] * p.nbuf
+    for sl in range(p.nbuf):
+        ent.free_slots.put(sl)
+    p._ed = {41: ent}
+    st = p._new_state([(b"m" * 41, [], [])], False)
+    s = st["sets"][0]
+    s.ed, s.n_sig, s.my_sigs = ent, n_sig, list(range(n_sig))
+    s.fills = {i: {} for i in range(n_sig)}
+    s.ed_done = [threading.Event() for _ in range(n_sig)]
+    s.ed_proofs = [None] * n_sig
+    ths = p._start([(p._witness_producer, (st,))] + [(p._ed_worker, (st, w)) for w in range(len(p.ed_ctxs))])
+    for th in ths:
+        th.join(30)
+    assert not any(th.is_alive() for th in ths), "the signature stage did not terminate"
+    return p, ent, st, s, chunks
+
+
+def test_signature_stage_first_chunk_fits_the_buffer_and_all_proofs_are_made():
+    p, ent, st, s, chunks = _fake_signature_stage(n_sig=11, nthreads=8, wchunk=2)          # prove_streams - 1 = 7 > witness_batch = 2
+    assert not st["errors"] and max(chunks) <= 2 and sum(chunks) == 11
+    assert all(x == b"proof" for x in s.ed_proofs) and all(ev.is_set() for ev in s.ed_done)
+    assert ent.slot_left == [0, 0] and ent.free_slots.qsize() == 2
+
+
+def test_signature_stage_with_failing_provers_terminates_and_frees_its_slots():
+    p, ent, st, s, chunks = _fake_signature_stage(n_sig=9, nthreads=3, wchunk=2, fail_on=1)   # every prover fails after the first proof
+    assert st["errors"] and "stand-in prover failure" in str(st["errors"][0])
+    assert p._sig_failed
+    p._reset_slots(ent)                      # what the next signature stage does first
+    assert ent.slot_left == [0, 0] and sorted(ent.free_slots.get_nowait() for _ in range(2)) == [0, 1]
+    import pytest as _pytest
+    with _pytest.raises(RuntimeError):
+        p._raise(st)
