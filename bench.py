@@ -337,7 +337,7 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
     # the FIXED-BASE form (round 5, include/zklc.h): the bases of a Groth16 proving key are the same for every proof, so a table of
     # 2^(c w) P_i is built once and a multi-exponentiation needs no closing doublings and one bucket reduction; its affine result is
     # bit-identical to the plain form's.  Reported beside the plain figure (which stays the headline's MSM number).
-    if world == 1:
+    if world == 1 and args.extra_stages:
         try:
             torch.cuda.synchronize()
             plain_words = d_out[:8].cpu().numpy().copy()
@@ -432,6 +432,8 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
     # the PRODUCT shape: every commitment of the Ed25519 circuit extends 2^18 -> 2^21 (prove_crypto/ed25519.rs:60), the less efficient
     # case of the two: PMC at this shape in profiles/r05a_lde_pmc_2p18_to_2p21.json
     try:
+        if not args.extra_stages:
+            raise KeyError("skipped")
         c18 = torch.randint(0, 2**63 - 1, (batch, 1 << 18), generator=g, device=dev, dtype=torch.int64)
         l21 = torch.empty((batch, 1 << 21), dtype=torch.int64, device=dev)
         ms18, _ = _time_stream(lambda: ctx.gl_lde_dev(c18, 18, rate, batch, 7, l21, flags=zklc_amd._lib.NTT_OUT_BITREV, stream=stream),
@@ -448,6 +450,8 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
             res["lde_2p18"]["roofline"]["valu"] = valu_block(p18["valu_wave_instructions_per_lde"], ms18, "all passes of one extension, "
                                                              "profiles/r05a_lde_pmc_2p18_to_2p21.json", "lde")
         del c18, l21
+    except KeyError:
+        pass
     except Exception as e:          # an extra line of the report, never a reason to lose the bench
         res["lde_2p18"] = {"error": repr(e)[:200]}
     words = ctx.gl_merkle_tree_words(log_n + rate, cap)
@@ -637,7 +641,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     # circuit cache yet are built by worker processes side by side, not one after the other under this process's GIL
     win_ = BlockWindow.from_fixture(json.load(open(os.path.join(ROOT, "tests", "golden", "block_window_HPi5.json"))))
     c1_msg_len = len(bytes.fromhex(json.load(open(os.path.join(ROOT, "tests", "golden", "ed25519_near_c1_small.json")))["msg"]))
-    out["circuit_prewarm"] = pipe.prewarm(win_, extra_msg_lens=[c1_msg_len])
+    out["circuit_prewarm"] = pipe.prewarm(win_, extra_msg_lens=[c1_msg_len], timeout_s=300)
     if world > 1:
         barrier()
 
@@ -1021,6 +1025,9 @@ def main():
     ap.add_argument("--c5-validators", type=int, default=200, help="the C5 stage: a synthetic epoch of this many validators through "
                     "BlockPipeline.prove_approvals (default 200: ~13 s on one MI355X; 1000 = BASELINE configs[4], ~63 s; 0 skips it), "
                     "reported under stages.prove.c5_synthetic_epoch")
+    ap.add_argument("--extra-stages", action="store_true", help="also time the fixed-base form of the 2^22 G1 multi-exponentiation (table of "
+                    "the bases built once; 4.3 GB) and the coset LDE at the Ed25519 circuit's shape 234 x (2^18 -> 2^21); both have "
+                    "their own profiles under profiles/ (r05g_msm_fixed_base_*, r05a_lde_*)")
     ap.add_argument("--host-witness", action="store_true", help="Ed25519-circuit witnesses from the host interpreter (threads + PCIe) instead of the GPU")
     ap.add_argument("--witness-batch", type=int, default=32, help="signatures per device witness batch (<= 64; 0.5 GB of HBM each)")
     ap.add_argument("--detail", default=os.environ.get("ZKLC_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json")),
@@ -1029,6 +1036,9 @@ def main():
                     "(CPU tests): no kernels are launched and the line says so; never a measurement")
     args = ap.parse_args()
 
+    # a bench that does not finish says WHERE it is: every 20 minutes the stacks of all threads go to stderr (diagnosis only)
+    import faulthandler
+    faulthandler.dump_traceback_later(1200, repeat=True, file=sys.stderr)
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
         self_launch(args)                 # does not return

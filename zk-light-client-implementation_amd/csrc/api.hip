@@ -54,11 +54,13 @@ extern "C" int32_t zklc_init_priority(zklc_ctx **out, int32_t device_id, int32_t
     if (hipSetDevice(device_id) != hipSuccess) return fail(ZKLC_ERR_NO_DEVICE);
     {
         // Round 5: a proving thread that waits for its stream (~10 waits per proof) was measured at 1.00 host cores busy -- the
-        // runtime's default wait spins (profiles/r05d_host_cpu_probe.txt), six cores per rank with the pipeline's six threads.
-        // Ask the device for blocking waits (the thread sleeps on the completion interrupt); ZKLC_SPIN_WAIT=1 keeps the default.
-        // Best effort: a runtime that refuses the flag on an active device leaves the waits as they were.
-        static const bool spin = getenv("ZKLC_SPIN_WAIT") && getenv("ZKLC_SPIN_WAIT")[0] == '1';
-        if (!spin) {
+        // runtime's default wait spins (profiles/r05d_host_cpu_probe.txt): six cores per rank with the pipeline's six threads.
+        // ZKLC_BLOCKING_WAIT=1 asks the device for blocking waits (the thread sleeps on the completion interrupt: 0.14 cores busy at
+        // +1 % wall time, profiles/r05e_host_cpu_probe_blocking.txt).  OPT-IN: the flag is device-wide -- it also changes how the
+        // caller's own runtime calls wait (torch's allocator, hipFree) -- and the one full bench run made with it as the default did
+        // not get past torch.cuda.empty_cache() (profiles/r05h_*); the GPU suite, smoke() and whole block proofs passed with it.
+        static const bool blocking = getenv("ZKLC_BLOCKING_WAIT") && getenv("ZKLC_BLOCKING_WAIT")[0] == '1';
+        if (blocking) {
             (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
             (void)hipGetLastError();
         }
