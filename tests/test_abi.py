@@ -51,3 +51,20 @@ def test_strerror_and_version(lib_path):
     assert lib.zklc_abi_version() >= 1
     assert lib.zklc_strerror(0) == b"ok"
     assert b"invalid" in lib.zklc_strerror(-1)
+
+
+def test_import_alias_keeps_the_real_module_specs():
+    """`zklc_amd.x` is the module object of `zk-light-client-implementation_amd.x` WITH its own spec -- relative imports
+    inside lazily importing functions raise no ImportWarning (__package__ == __spec__.parent), importlib.reload and inspect work"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import importlib, inspect; import zklc_amd; import zklc_amd.pipeline as pl; "
+            "import zklc_amd.plonky2.builder as b; "
+            "assert pl.__spec__.name == 'zk-light-client-implementation_amd.pipeline' and pl.__package__ == pl.__spec__.parent; "
+            "assert sys.modules['zklc_amd.pipeline'] is sys.modules['zk-light-client-implementation_amd.pipeline']; "
+            "from zklc_amd.plonky2.recursion import RecursionProver; importlib.reload(pl); "
+            "assert inspect.getsourcefile(b).endswith('builder.py'); print('ok')" % root)
+    r = subprocess.run([sys.executable, "-W", "error::ImportWarning", "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stderr[-1500:]

@@ -185,3 +185,17 @@ def test_dag_wiring_epoch_blocks():
     assert bn_1[2]["public_inputs"] == [1] + list(hx(w["blocks"][5]["hash"])) + list(hx(w["ep3_last_block"]["hash"])) + \
         list(hx(w["ep2_last_block"]["hash"]))
     assert len(ap.msgs) == 2 and bp.counts["prove_header_hash"] == 9 and bp.counts["prove_valid_keys_stakes"] == 2
+
+
+def test_pipelined_form_refuses_what_it_would_silently_ignore():
+    """`prove_block_bft(pipelined=True)` proves its own header proofs on its own contexts -- a caller that passes
+    `header_proofs`, or a BlockProver built over stand-ins (no zklc Context), gets an error instead of a proof that ignored them"""
+    w, blocks, validators = _window()
+    hx = bytes.fromhex
+    args = (hx(w["ep2_last_block"]["bytes"]), hx(w["ep2_last_block"]["hash"]), hx(w["ep1_first_block"]["bytes"]),
+            hx(w["ep1_first_block"]["hash"]), blocks, validators)
+    bp = BlockProver(None, parts=(FakeApprovals(), FakeHashes(), FakeKeys(), FakePrims()))
+    with pytest.raises(ValueError, match="header_proofs"):
+        bp.prove_block_bft(*args, header_proofs={"b1": None}, pipelined=True)
+    with pytest.raises(ValueError, match="Context"):
+        bp.prove_block_bft(*args, pipelined=True)
