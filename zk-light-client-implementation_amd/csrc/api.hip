@@ -59,6 +59,9 @@ extern "C" int32_t zklc_init_priority(zklc_ctx **out, int32_t device_id, int32_t
         // +1 % wall time, profiles/r05e_host_cpu_probe_blocking.txt).  OPT-IN: the flag is device-wide -- it also changes how the
         // caller's own runtime calls wait (torch's allocator, hipFree) -- and the one full bench run made with it as the default did
         // not get past torch.cuda.empty_cache() (profiles/r05h_*); the GPU suite, smoke() and whole block proofs passed with it.
+        // What separates the two: bench.py had run torch kernels on the device BEFORE its first zklc_init flipped the wait mode,
+        // the passing programs created their context first.  Like cudaSetDeviceFlags, the mode belongs at process start: use
+        // ZKLC_BLOCKING_WAIT=1 only in a process whose first GPU call is zklc_init (a Rust / Go host; the pipeline's own ranks).
         static const bool blocking = getenv("ZKLC_BLOCKING_WAIT") && getenv("ZKLC_BLOCKING_WAIT")[0] == '1';
         if (blocking) {
             (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
