@@ -308,7 +308,108 @@ static u32 hostsim_msm(const u64 *points, const u64 *scalars, u32 n, u32 mode, u
     }
     return ec_to_affine_gnark(out, total);
 }
+// The FIXED-BASE form of the multi-exponentiation (csrc/bn254_msm.hip, round 5) walked on the CPU with the same lane functions: the
+// table of 2^(c w) P_i as packed affine records (what msm_fixed_table_kernel writes: c doublings + one inversion per row), the digits
+// of all windows sorted into ONE bucket set (the (chunk, window) tiles of the sort become the tiles of a single window; an entry
+// names table row w * n + i), slices, combine, ONE bucket reduction and no closing doublings.
+template <class F>
+static u32 hostsim_msm_fixed(const u64 *points, const u64 *scalars, u32 n, u32 *out) {
+    typedef typename F::T T;
+    const int AFF = msm_cfg<F>::AFF, XY = msm_cfg<F>::XYZZ, W = msm_rec<F, true>::WORDS;
+    msm_plan pl = msm_make_plan(n, false);
+    const u32 bpw = pl.buckets_per_window;
+    std::vector<i32> table((size_t)pl.windows * n * W, 0);
+    for (u32 i = 0; i < n; i++) {
+        if (msm_point_is_inf<AFF>(points, i)) continue;              // all-zero records
+        T x, y;
+        msm_load_point<F>(points, i, x, y);
+        x = F::reduce(x);
+        y = F::reduce(y);
+        for (u32 w = 0; w < pl.windows; w++) {
+            u32 *dst = reinterpret_cast<u32 *>(table.data() + ((size_t)w * n + i) * W);
+            F::pack(dst, x);
+            F::pack(dst + F::PACKW, y);
+            if (w + 1 == pl.windows) break;
+            ec_xyzz<F> acc;
+            acc.X = x;
+            acc.Y = y;
+            acc.ZZ = acc.ZZZ = F::one();
+            for (u32 k = 0; k < pl.c; k++) acc = ec_double(acc);
+            T inv = F::inv(F::mul(acc.ZZ, acc.ZZZ));
+            x = F::reduce(F::mul(acc.X, F::mul(inv, acc.ZZZ)));
+            y = F::reduce(F::mul(acc.Y, F::mul(inv, acc.ZZ)));
+        }
+    }
+    std::vector<unsigned short> dig((size_t)pl.windows * pl.n_pad, 0);
+    for (u32 i = 0; i < pl.n_pad; i++) {
+        bool live = i < pl.n;
+        if (live) {
+            i32 acc = 0;
+            for (int k = 0; k < W; k++) acc |= table[(size_t)i * W + k];
+            live = acc != 0;
+        }
+        u32 sw[8], carry = 0;
+        if (live) msm_load_scalar(scalars, i, sw);
+        for (u32 w = 0; w < pl.windows; w++) {
+            int d = live ? msm_digit(sw, w, pl.c, carry) : 0;
+            dig[(size_t)w * pl.n_pad + i] = (unsigned short)msm_digit_code(d);
+        }
+    }
+    msm_plan pm = pl;                                                // the view behind the sort: one window, windows x chunks tiles
+    pm.windows = 1;
+    pm.chunks = pl.windows * pl.chunks;
+    pm.total_buckets = bpw;
+    std::vector<u32> cnt((size_t)bpw * pm.chunks, 0), totals(bpw), offsets(bpw);
+    for (u32 w = 0; w < pl.windows; w++)
+        for (u32 k = 0; k < pl.chunks; k++) {
+            u32 lo = k * pl.chunk_len, hi = lo + pl.chunk_len < pl.n_pad ? lo + pl.chunk_len : pl.n_pad;
+            for (u32 i = lo; i < hi; i++) {
+                u32 code = dig[(size_t)w * pl.n_pad + i], neg;
+                if (code) cnt[((size_t)w * pl.chunks + k) * bpw + msm_code_bucket(code, neg)]++;
+            }
+        }
+    for (u32 b = 0; b < bpw; b++) {                                  // msm_totals_kernel with the merged plan
+        u32 run = 0;
+        for (u32 t = 0; t < pm.chunks; t++) {
+            u32 &c = cnt[(size_t)t * bpw + b];
+            u32 v = c;
+            c = run;
+            run += v;
+        }
+        totals[b] = run;
+    }
+    u32 run = 0;
+    for (u32 b = 0; b < bpw; b++) {
+        offsets[b] = run;
+        run += totals[b];
+    }
+    std::vector<u32> entries((size_t)run + 1, 0);
+    for (u32 w = 0; w < pl.windows; w++)
+        for (u32 k = 0; k < pl.chunks; k++) {
+            std::vector<u32> cur(bpw);
+            for (u32 b = 0; b < bpw; b++) cur[b] = offsets[b] + cnt[((size_t)w * pl.chunks + k) * bpw + b];
+            u32 lo = k * pl.chunk_len, hi = lo + pl.chunk_len < pl.n_pad ? lo + pl.chunk_len : pl.n_pad;
+            for (u32 i = lo; i < hi; i++) {
+                u32 code = dig[(size_t)w * pl.n_pad + i], neg;
+                if (!code) continue;
+                u32 b = msm_code_bucket(code, neg);
+                entries[cur[b]++] = ((w * n + i) << 1) | neg;
+            }
+        }
+    std::vector<i32> buckets((size_t)bpw * XY, 0);
+    const u32 E = run, slices = (u32)(((u64)pl.n * pl.windows + MSM_SLICE - 1) / MSM_SLICE);
+    std::vector<i32> partials(((size_t)slices + 1) * 2 * XY, 0x5a5a5a5a);
+    for (u32 lane = 0; lane < slices; lane++)
+        msm_slice_lane<F, true>(table.data(), entries.data(), offsets.data(), bpw, E, lane, buckets.data(), partials.data());
+    for (u32 key = 0; key < bpw; key++) msm_combine_lane<F>(offsets.data(), totals.data(), key, partials.data(), buckets.data());
+    u32 seg_per_window = (bpw + MSM_SEG - 1) / MSM_SEG;
+    ec_xyzz<F> total = ec_infinity<F>();
+    for (u32 si = 0; si < seg_per_window; si++) total = ec_add(total, msm_segment_lane<F>(buckets.data(), pm, 0, si));
+    return ec_to_affine_gnark(out, total);
+}
 extern "C" {
+u32 hostsim_msm_fixed_g1(const u64 *points, const u64 *scalars, u32 n, u32 *out16) { return hostsim_msm_fixed<FpField>(points, scalars, n, out16); }
+u32 hostsim_msm_fixed_g2(const u64 *points, const u64 *scalars, u32 n, u32 *out32) { return hostsim_msm_fixed<Fp2Field>(points, scalars, n, out32); }
 u32 hostsim_msm_g1(const u64 *points, const u64 *scalars, u32 n, u32 mode, u32 heavy_min, u32 heavy_threads, u32 *out16) {
     return hostsim_msm<FpField>(points, scalars, n, mode, heavy_min, heavy_threads, out16);
 }

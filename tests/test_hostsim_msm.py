@@ -188,3 +188,24 @@ def test_glv_split_and_the_split_msm(hostsim):
     assert inf == winf and np.array_equal(got, want)
     got2, inf2 = _run(hostsim, pts, sc, mode=2)          # no split, unpacked records: the same point
     assert inf2 == inf and np.array_equal(got2, got)
+
+
+@pytest.mark.parametrize("kind,n", [("uniform", 300), ("witness", 500), ("equal", 200), ("top", 70), ("uniform", 1), ("uniform", 2500)])
+def test_fixed_base_walk_matches_the_plain_walk_and_the_oracle(hostsim, kind, n):
+    """the fixed-base form of round 5 (table of 2^(c w) P_i, ONE bucket set for all windows, no closing doublings:
+    csrc/bn254_msm.hip) walked with the same lane functions: the same canonical affine point as the plain walk and as the oracle's
+    naive multi-exponentiation (gnark-crypto MultiExp under groth16.Prove, gnark-plonky2-verifier/cmd/web-api.go:77)"""
+    rng = np.random.default_rng(50 + n)
+    pts = cport.bn254_gen_points(n, 5, 3)
+    if kind == "witness":
+        pts[3] = 0
+        pts[n - 1] = 0
+    sc = _scalars(kind, n, rng)
+    out = (ctypes.c_uint32 * 16)()
+    inf = hostsim.hostsim_msm_fixed_g1(pts.ctypes.data_as(ctypes.c_void_p), sc.ctypes.data_as(ctypes.c_void_p), n, out)
+    got = np.array([out[2 * i] | (out[2 * i + 1] << 32) for i in range(8)], dtype=np.uint64)
+    plain, pinf = _run(hostsim, pts, sc)
+    assert bool(inf) == pinf and (pinf or np.array_equal(got, plain))
+    live = [i for i in range(n) if pts[i].any()]
+    want, winf, _ = cport.bn254_msm(pts[live], _reduced(sc[live]), naive=True)
+    assert bool(inf) == winf and (winf or np.array_equal(got, want))

@@ -381,7 +381,7 @@ __global__ void gl_group_twiddle_kernel(u64 *out, u64 w, u32 g, u32 s_first, u64
     out[i] = gl_pow(w, ((u64)gl_bitrev_small(m, (int)g) * J) << s_first);
 }
 
-// out[i] = in[bitrev(i)] (per polynomial)
+// bit reversal of every polynomial of a batch
 // in place: element i and element bitrev(i) change places (the lower index of every pair does the swap).  Round 5: replaces a
 // device-to-device copy into scratch followed by the out-of-place kernel -- half the traffic, no scratch buffer.
 __global__ void __launch_bounds__(256) gl_bitrev_inplace_kernel(u64 *__restrict__ data, size_t stride, int logn) {
