@@ -809,6 +809,12 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     def block_done(r):
         tele_steps.append(dict(tele.mark(), rss_mb=rss_mb()))
     import resource
+
+    def clocks_ns():
+        # the timed region in every clock a profiler may stamp kernels with: tools/block_accounting.py picks the one the trace uses
+        return {n: time.clock_gettime_ns(getattr(time, c)) for n, c in (("monotonic", "CLOCK_MONOTONIC"), ("boottime", "CLOCK_BOOTTIME"),
+                                                                       ("realtime", "CLOCK_REALTIME"), ("monotonic_raw", "CLOCK_MONOTONIC_RAW"))}
+    clk0 = clocks_ns()
     cpu_all = time.process_time()
     t_all = time.perf_counter()
     if overlap:
@@ -823,6 +829,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                 block_done(r)
     barrier()
     total_s = reduce_max(time.perf_counter() - t_all)
+    clk1 = clocks_ns()
     cpu_all = time.process_time() - cpu_all        # user + system seconds of THIS rank's process (all threads) over the timed blocks
     block_s = total_s / steps
     tele.close()
@@ -864,7 +871,8 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                       "final_proof_verified": True, "final_proof_verify_s_untimed": t_v,
                       "first_block_s_incl_circuit_construction": t_setup,
                       "host_cpu_s_per_block": cpu_all / steps, "host_cores_busy": cpu_all / max(total_s, 1e-9),
-                      "peak_rss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0}
+                      "peak_rss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0,
+                      "timed_region_clock_ns": {k: [clk0[k], clk1[k]] for k in clk0}}
     if world > 1 and not strong_only and not args.no_strong_section:
         # the STRONG form of the block measured in the same run, so that one SCALE run holds both: all ranks prove
         # ONE block per step (signature shards, local folds, a binary-tree fold over the ranks, the header proofs on the other ranks,
