@@ -88,13 +88,21 @@ class GpuTelemetry:
     KEYS = (("sclk_mhz", ("freq1_input",), 1e-6), ("power_w", ("power1_average", "power1_input"), 1e-6),
             ("temp_c", ("temp2_input", "temp1_input"), 1e-3), ("mclk_mhz", ("freq2_input",), 1e-6))
 
-    def __init__(self, period=0.2):
+    def __init__(self, period=0.2, pci=None):
+        """pci: "dddd:bb:dd.f" of the device this process computes on (own_pci()): only that card is sampled.  Round 6 found the
+        round-5 line's 2155 MHz / 1.23 kW next to an unchanged block time to be ANOTHER tenant's card: the boxes expose every GPU of
+        the node in sysfs and "the busiest card" is not necessarily ours (profiles/r06a_*: a 324 W, 100 % busy neighbour)."""
         import glob
         import threading
         self.cards = []
+        self.own = None
         for d in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
             if not os.path.exists(os.path.join(d, "gpu_busy_percent")):
                 continue
+            if pci is not None:
+                if os.path.basename(os.path.realpath(d)).lower() != pci.lower():
+                    continue
+                self.own = pci
             files = {"busy_pct": (os.path.join(d, "gpu_busy_percent"), 1.0)}
             for h in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
                 for key, names, scale in self.KEYS:
@@ -127,6 +135,7 @@ class GpuTelemetry:
             for c in self.cards:
                 m = {k: round(v / max(1, c["n"]), 1) for k, v in c["acc"].items()}
                 m["samples"], m["card"] = c["n"], c["name"]
+                m["card_selected_by"] = "pci address" if self.own else "busiest card (own PCI address unknown)"
                 if best is None or (m.get("busy_pct", 0), m.get("power_w", 0)) > (best.get("busy_pct", 0), best.get("power_w", 0)):
                     best = m
                 c["acc"], c["n"] = {}, 0
@@ -134,6 +143,16 @@ class GpuTelemetry:
 
     def close(self):
         self.stop_ev.set()
+
+    @staticmethod
+    def own_pci(device=None):
+        """PCI address of the HIP device this process uses, as sysfs spells it; None when torch cannot say"""
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device() if device is None else device)
+            return "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            return None
 
     @staticmethod
     def smi_snapshot():
@@ -795,7 +814,10 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     for _ in range(max(0, args.warmup - 1)):
         pipe.prove_block_bft(window)
     barrier()
-    tele = GpuTelemetry()
+    tele = GpuTelemetry(pci=GpuTelemetry.own_pci())
+    if not tele.cards:                       # sysfs does not know the address torch reports: fall back to the busiest card
+        tele.close()
+        tele = GpuTelemetry()
     tele.mark()
     rss0 = rss_mb()
     steps = max(1, args.steps)
@@ -942,6 +964,9 @@ def compact_line(full):
         o = {k: r3(r.get(k)) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms") if k in r}
         if "valu" in r:
             o["valu"] = {k: r3(r["valu"][k]) for k in ("bound", "achieved", "peak", "unit", "frac", "ubench") if k in r["valu"]}
+        if "block" in r:
+            o["block"] = {k: r3(r["block"][k]) for k in ("valu_lane_instr_per_block", "frac_of_issue_limit", "sum_exclusive_kernel_s",
+                                                         "wall_s", "sclk_mhz", "gpu_idle_s", "floor_s_at_issue_limit") if r["block"].get(k) is not None}
         return o
     line["roofline"] = roof(full.get("roofline"))
     cb = full.get("cpu_baseline")
@@ -1201,6 +1226,23 @@ def main():
                     out["roofline"]["valu"] = valu_block(pm["SQ_INSTS_VALU_per_launch"], mk["ms"], "gl_hash_leaves_kernel, "
                                                          "profiles/poseidon_pmc_latest.json")
                     out["roofline"]["valu"]["instructions_per_permutation"] = pm["SQ_INSTS_VALU_per_launch"] * 64 / ((1 << 20) * 30)
+            # the HEADLINE's own fraction: VALU lane-instructions ONE block executes -- SQ_INSTS_VALU summed over
+            # the ~28.7 k dispatches of a timed block, a rocprofv3 PMC pass of this very command (tools/gpu_block_accounting.sh ->
+            # profiles/block_pmc_latest.json; the prover is deterministic, the count does not depend on the run) -- over the LIVE block
+            # time x the SIMDs' multi-pass issue limit.  Valid for the window the count was taken on (73 approvals) and one rank's block.
+            bp = pmc_json("block_pmc_latest.json")
+            if bp is not None and blk["approvals"] == 73 and blk["scaling"] == "weak":
+                lanes = float(bp["valu_lane_instr_per_block"])
+                tr = bp.get("trace", {})
+                out["roofline"]["block"] = {
+                    "valu_lane_instr_per_block": lanes, "wall_s": blk["seconds_per_block"],
+                    "frac_of_issue_limit": lanes / (blk["seconds_per_block"] * VALU_INT_PEAK_TLOPS * 1e12),
+                    "floor_s_at_issue_limit": lanes / (VALU_INT_PEAK_TLOPS * 1e12),
+                    "sum_exclusive_kernel_s": bp.get("sum_serialised_kernel_s"), "gpu_idle_s": tr.get("idle_s"),
+                    "sclk_mhz": (blk.get("telemetry_mean") or {}).get("sclk_mhz"),
+                    "note": "frac = lane-instructions / (live wall x 39.3 T/s); sum_exclusive_kernel_s = the block's kernels run one at a time "
+                            "(their own durations under counter collection); gpu_idle_s = time with no kernel resident in the kernel trace of "
+                            "the overlapped run (profiles/r06a_block_accounting.json)"}
             try:
                 if "cpu_baseline" in edp:
                     cb = edp["cpu_baseline"]

@@ -30,6 +30,9 @@ typedef struct zklc_ctx zklc_ctx;
 #define ZKLC_ERR_OOM (-2)
 #define ZKLC_ERR_HIP (-3)
 #define ZKLC_ERR_NO_DEVICE (-4)
+#define ZKLC_ERR_IO (-5)        /* a container file could not be opened / written (errno is the caller's to read) */
+#define ZKLC_ERR_FORMAT (-6)    /* not a container, another version, truncated, a failed checksum or sections that contradict each other */
+#define ZKLC_ERR_NOT_FOUND (-7) /* the container has no section with that tag */
 
 /* One context per process-per-GPU rank.  Owns a stream, staging buffers and
  * the constant tables (Ed25519 base-point table, NTT twiddles, ...). */
@@ -239,6 +242,77 @@ int32_t zklc_plonky2_witness_program_info(zklc_witness_program *p, uint32_t n_wi
                                           uint32_t *n_launches);
 int32_t zklc_plonky2_witness_run_dev(zklc_ctx *ctx, void *stream, zklc_witness_program *p, const uint64_t *input_values,
                                      uint32_t n_witnesses, uint64_t *d_wires, uint64_t *pi_out, int32_t *status, char *err_out);
+
+/* ---- (b'') circuit container: the hand-off between `builder.build()` and `data.prove(pw)` ------------------------
+ * The reference builds a circuit once and proves with it many times: `get_ed25519_circuit_targets` /
+ * `ed25519_proof_reuse_circuit` (near_bft_finality/src/prove_crypto/ed25519.rs:18-42 build, :44-66 prove; the call at :60),
+ * `recursive_proof` (recursion.rs:36-94 build, :95 prove).  The container is that seam as a FILE: a flat little-endian list of
+ * tagged sections holding exactly the arguments of zklc_plonky2_circuit_create and zklc_plonky2_witness_program_create, written
+ * by whoever ran the circuit builder (a Rust shim beside plonky2's CircuitBuilder: INTEGRATION.md; this repo's Python mirror:
+ * zklc_amd/plonky2/container.py) and loaded by any caller of this ABI (tests/c_abi/prove_from_file.c proves from two files and
+ * nothing else).  Layout (csrc/container.cpp): 64-byte header (magic "ZKLCCIRC", version, section count, file size, table
+ * checksum), one 32-byte table entry per section (tag, element size, offset, bytes, checksum), payload sections on 64-byte
+ * boundaries.  The file functions are host code: they work without a GPU. */
+#define ZKLC_CONTAINER_VERSION 1u
+#define ZKLC_CONTAINER_VERIFY 1u      /* zklc_container_open flag: also check every section's checksum (reads the whole file) */
+enum zklc_container_tag {
+    ZKLC_SEC_PARAMS = 1,           /* one zklc_plonky2_params (hasher = the builder's default; create_from_container can override it) */
+    ZKLC_SEC_GATES = 2,            /* zklc_plonky2_gate[num_gates] */
+    ZKLC_SEC_GATE_EXTRA = 3,       /* u64[]: gate_extra (absent when no gate has a table) */
+    ZKLC_SEC_K_IS = 4,             /* u64[num_routed_wires] */
+    ZKLC_SEC_CONSTANTS = 5,        /* u64[num_constants x 2^degree_bits], selectors first */
+    ZKLC_SEC_SIGMAS = 6,           /* u64[num_routed_wires x 2^degree_bits] */
+    ZKLC_SEC_WP_DIMS = 16,         /* one zklc_witness_dims: the scalar arguments of zklc_plonky2_witness_program_create */
+    ZKLC_SEC_WP_CODE = 17,         /* u32[code_len] */
+    ZKLC_SEC_WP_PARAMS = 18,       /* i64[n_params] */
+    ZKLC_SEC_WP_INPUT_SLOTS = 19,  /* u32[n_inputs] */
+    ZKLC_SEC_WP_WIRE_SLOT = 20,    /* u32[n_wire_entries] */
+    ZKLC_SEC_WP_WIRE_INDEX = 21,   /* u32[n_wire_entries] */
+    ZKLC_SEC_WP_PI_SLOTS = 22,     /* u32[n_pi] */
+    ZKLC_SEC_INPUT_VALUES = 32,    /* u64[n_witnesses x n_inputs]: a witness-input file (the PartialWitness of ed25519.rs:54-59 /
+                                      recursion.rs:44-92 in the order of the program's inputs) */
+    ZKLC_SEC_HOST_FIRST = 0x1000   /* tags from here on belong to the writer (target names, JSON notes); the library ignores them */
+};
+typedef struct {
+    uint64_t code_len, n_params, n_wire_entries;
+    uint32_t n_slots, n_inputs, num_wires, n_rows, n_pi, reserved;
+} zklc_witness_dims;
+typedef struct {
+    uint32_t tag;         /* zklc_container_tag or a writer's own tag >= ZKLC_SEC_HOST_FIRST; one section per tag */
+    uint32_t elem_bytes;  /* size of one element (the section is an array of them): 1, 4, 8 or a struct size */
+    const void *data;
+    uint64_t bytes;
+} zklc_container_entry;
+typedef struct zklc_container zklc_container;
+/* writes `path` atomically (temporary file beside it + rename).  ZKLC_ERR_IO when the directory cannot be written. */
+int32_t zklc_container_write(const char *path, const zklc_container_entry *entries, uint32_t n_entries);
+/* the circuit of zklc_plonky2_circuit_create and -- when `dims` is not NULL -- the witness program of
+ * zklc_plonky2_witness_program_create as one container; extra_entries: the writer's own sections (tags >= ZKLC_SEC_HOST_FIRST) */
+int32_t zklc_plonky2_container_write(const char *path, const zklc_plonky2_params *params, const zklc_plonky2_gate *gates,
+                                     const uint64_t *gate_extra, uint32_t gate_extra_words, const uint64_t *k_is,
+                                     const uint64_t *constants, const uint64_t *sigmas, const zklc_witness_dims *dims,
+                                     const uint32_t *code, const int64_t *wparams, const uint32_t *input_slots,
+                                     const uint32_t *wire_slot, const uint32_t *wire_index, const uint32_t *pi_slots,
+                                     const zklc_container_entry *extra_entries, uint32_t n_extra_entries);
+/* maps the file read-only and checks header, size and section table (with ZKLC_CONTAINER_VERIFY: every section's checksum).
+ * The data pointers of the entries stay valid until zklc_container_close. */
+int32_t zklc_container_open(const char *path, uint32_t flags, zklc_container **out);
+void zklc_container_close(zklc_container *c);
+uint32_t zklc_container_count(const zklc_container *c);
+int32_t zklc_container_entry_at(const zklc_container *c, uint32_t i, zklc_container_entry *out);
+int32_t zklc_container_find(const zklc_container *c, uint32_t tag, zklc_container_entry *out);
+/* after the circuit is on the GPU the mapped pages are dead weight: hand them back (the mapping stays valid) */
+void zklc_container_release_pages(const zklc_container *c);
+/* the parameter blocks of a circuit container after the consistency checks the create functions below run (either may be NULL) */
+int32_t zklc_plonky2_container_params(const zklc_container *c, zklc_plonky2_params *params_out, zklc_witness_dims *dims_out);
+/* zklc_plonky2_circuit_create / zklc_plonky2_witness_program_create with the arguments taken from the container's sections,
+ * after checking that every section has the size the parameters imply and every index is in range (ZKLC_ERR_FORMAT otherwise).
+ * hasher: ZKLC_HASHER_* or -1 = the one stored in the file.  The container may be closed as soon as the call returns. */
+int32_t zklc_plonky2_circuit_create_from_container(zklc_ctx *ctx, const zklc_container *c, int32_t hasher, zklc_plonky2_circuit **out);
+int32_t zklc_plonky2_witness_program_create_from_container(zklc_ctx *ctx, const zklc_container *c, zklc_witness_program **out);
+/* zklc_plonky2_witness_run (host interpreter, no GPU) over the container's program */
+int32_t zklc_plonky2_witness_run_from_container(const zklc_container *c, const uint64_t *input_values, uint32_t n_witnesses,
+                                                uint64_t *wires_out, uint64_t *pi_out, int32_t *status, char *err_out, uint32_t threads);
 
 /* ---- (c) BN254 ---------------------------------------------------------------
  * G1 multi-scalar multiplication sum_i scalars[i] * points[i].

@@ -97,6 +97,24 @@ _SIGS = {
     "zklc_plonky2_witness_run": (ctypes.c_int32, [_u8p, ctypes.c_uint64, _u8p, ctypes.c_uint32, _u8p, ctypes.c_uint32, _u8p,
                                                   ctypes.c_uint32, _u8p, _u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, _u8p,
                                                   _u8p, ctypes.c_uint32, _u8p, _u8p, ctypes.c_char_p, ctypes.c_uint32]),
+    # ---- circuit container (csrc/container.cpp): host functions, no GPU
+    "zklc_container_write": (ctypes.c_int32, [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint32]),
+    "zklc_plonky2_container_write": (ctypes.c_int32, [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, _u8p, ctypes.c_uint32, _u8p, _u8p,
+                                                      _u8p, ctypes.c_void_p, _u8p, _u8p, _u8p, _u8p, _u8p, _u8p, ctypes.c_void_p,
+                                                      ctypes.c_uint32]),
+    "zklc_container_open": (ctypes.c_int32, [ctypes.c_char_p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]),
+    "zklc_container_close": (None, [ctypes.c_void_p]),
+    "zklc_container_count": (ctypes.c_uint32, [ctypes.c_void_p]),
+    "zklc_container_entry_at": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "zklc_container_find": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "zklc_container_release_pages": (None, [ctypes.c_void_p]),
+    "zklc_plonky2_container_params": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "zklc_plonky2_circuit_create_from_container": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                                                    ctypes.POINTER(ctypes.c_void_p)]),
+    "zklc_plonky2_witness_program_create_from_container": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p,
+                                                                            ctypes.POINTER(ctypes.c_void_p)]),
+    "zklc_plonky2_witness_run_from_container": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint32, _u8p, _u8p, _u8p, ctypes.c_char_p,
+                                                                 ctypes.c_uint32]),
 }
 
 NTT_INVERSE, NTT_IN_BITREV, NTT_OUT_BITREV = 1, 2, 4

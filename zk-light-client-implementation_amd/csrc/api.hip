@@ -20,7 +20,7 @@ int32_t zklc_stage(zklc_ctx *ctx, int slot, size_t bytes, void **out) {
     return ZKLC_OK;
 }
 
-extern "C" uint32_t zklc_abi_version(void) { return 1; }
+extern "C" uint32_t zklc_abi_version(void) { return 2; }   // 2: circuit container (round 6)
 
 extern "C" const char *zklc_strerror(int32_t code) {
     switch (code) {
@@ -29,6 +29,9 @@ extern "C" const char *zklc_strerror(int32_t code) {
         case ZKLC_ERR_OOM: return "out of device memory";
         case ZKLC_ERR_HIP: return "HIP runtime error (see zklc_last_hip_error)";
         case ZKLC_ERR_NO_DEVICE: return "no usable gfx950 device";
+        case ZKLC_ERR_IO: return "container file could not be opened or written";
+        case ZKLC_ERR_FORMAT: return "not a valid circuit container (magic, version, size, checksum or inconsistent sections)";
+        case ZKLC_ERR_NOT_FOUND: return "no such section in the container";
         default: return "unknown zklc status";
     }
 }
