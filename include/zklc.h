@@ -49,6 +49,13 @@ int32_t zklc_synchronize(zklc_ctx *ctx);
  * points to keep several contexts' work concurrent on one GPU */
 void *zklc_stream(zklc_ctx *ctx);
 uint32_t zklc_abi_version(void);
+/* Device memory for hosts that bind nothing but this ABI (a C / Rust / Go caller need not link the HIP runtime to hold the
+ * buffers the *_dev entry points take): alloc returns a ZERO-FILLED buffer on the context's GPU (what
+ * zklc_plonky2_witness_run_dev expects of d_wires); copy moves bytes between host and device on the context's stream and returns
+ * when they have arrived (to_host != 0: device -> host). */
+int32_t zklc_device_alloc(zklc_ctx *ctx, uint64_t bytes, void **d_out);
+int32_t zklc_device_free(zklc_ctx *ctx, void *d_ptr);
+int32_t zklc_device_copy(zklc_ctx *ctx, void *dst, const void *src, uint64_t bytes, int32_t to_host);
 
 /* ---- (a) batched Ed25519 -------------------------------------------------
  * Replaces the per-approval native pre-check loop

@@ -1,5 +1,5 @@
 """zklc_amd/plonky2/circuit_cache.py: a circuit loaded from the on-disk cache is the circuit that was built -- same matrices, same
-witness program, and its input targets are still the objects the witness program names (one pickle per entry)."""
+witness program, and its input targets are still the objects the witness program names (one circuit container per entry: plonky2/container.py)."""
 import hashlib
 
 import numpy as np
@@ -43,7 +43,7 @@ def test_cache_round_trip(tmp_path, monkeypatch):
     _, _, hit = CC.load_or_build("sha256", 1, _build(10))
     assert not hit and len(list(tmp_path.glob("sha256-*.circuit"))) == 2
     path = sorted(tmp_path.glob("sha256-*.circuit"))[0]
-    path.write_bytes(b"not a pickle")
+    path.write_bytes(b"not a container")
     for key, n in ((2, 64), (1, 10)):
         d, w, _ = CC.load_or_build("sha256", key, _build(n))
         assert d._program is not None

@@ -19,6 +19,9 @@ _SIGS = {
     "zklc_synchronize": (ctypes.c_int32, [ctypes.c_void_p]),
     "zklc_abi_version": (ctypes.c_uint32, []),
     "zklc_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "zklc_device_alloc": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]),
+    "zklc_device_free": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p]),
+    "zklc_device_copy": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int32]),
     "zklc_ed25519_verify_batch": (ctypes.c_int32, [ctypes.c_void_p, _u8p, _u8p, _u8p, ctypes.c_uint32, ctypes.c_uint32,
                                                    ctypes.c_uint32, _u8p]),
     "zklc_ed25519_verify_batch_dev": (ctypes.c_int32, [ctypes.c_void_p, ctypes.c_void_p, _u8p, _u8p, _u8p, ctypes.c_uint32,

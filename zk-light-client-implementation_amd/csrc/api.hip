@@ -55,22 +55,12 @@ extern "C" int32_t zklc_init_priority(zklc_ctx **out, int32_t device_id, int32_t
         return code;
     };
     if (hipSetDevice(device_id) != hipSuccess) return fail(ZKLC_ERR_NO_DEVICE);
-    {
-        // Round 5: a proving thread that waits for its stream (~10 waits per proof) was measured at 1.00 host cores busy -- the
-        // runtime's default wait spins (profiles/r05d_host_cpu_probe.txt): six cores per rank with the pipeline's six threads.
-        // ZKLC_BLOCKING_WAIT=1 asks the device for blocking waits (the thread sleeps on the completion interrupt: 0.14 cores busy at
-        // +1 % wall time, profiles/r05e_host_cpu_probe_blocking.txt).  OPT-IN: the flag is device-wide -- it also changes how the
-        // caller's own runtime calls wait (torch's allocator, hipFree) -- and the one full bench run made with it as the default did
-        // not get past torch.cuda.empty_cache() (profiles/r05h_*); the GPU suite, smoke() and whole block proofs passed with it.
-        // What separates the two: bench.py had run torch kernels on the device BEFORE its first zklc_init flipped the wait mode,
-        // the passing programs created their context first.  Like cudaSetDeviceFlags, the mode belongs at process start: use
-        // ZKLC_BLOCKING_WAIT=1 only in a process whose first GPU call is zklc_init (a Rust / Go host; the pipeline's own ranks).
-        static const bool blocking = getenv("ZKLC_BLOCKING_WAIT") && getenv("ZKLC_BLOCKING_WAIT")[0] == '1';
-        if (blocking) {
-            (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
-            (void)hipGetLastError();
-        }
-    }
+    // Waiting.  Rounds 1-5 left a proving thread at 1.00 host cores busy; round 5 offered hipDeviceScheduleBlockingSync behind
+    // ZKLC_BLOCKING_WAIT=1, a DEVICE-WIDE mode that also changed how the caller's own runtime calls wait (and the one bench run with it
+    // as the default hung in torch's allocator).  Round 6 found the spinning itself: hipMemcpyAsync to / from pageable host memory
+    // waits for the stream inside the call.  Every transfer of the per-proof paths now goes through page-locked staging
+    // (plonky2_prover.hip `p2_pin`, plonky2_witness_dev.hip `h_pin`) and every wait through zklc_stream_wait (an event created with
+    // hipEventBlockingSync): the library never touches the device's scheduling flags.
     int prio_low = 0, prio_high = 0;   // numerically lower = higher priority
     if (high_priority && hipDeviceGetStreamPriorityRange(&prio_low, &prio_high) != hipSuccess) prio_high = 0;
     if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, high_priority ? prio_high : 0) != hipSuccess)
@@ -94,6 +84,40 @@ extern "C" void zklc_destroy(zklc_ctx *ctx) {
 }
 
 extern "C" void *zklc_stream(zklc_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+// Device memory for hosts that bind nothing but this ABI (tests/c_abi/prove_from_file.c; a Rust / Go shim need not link HIP)
+extern "C" int32_t zklc_device_alloc(zklc_ctx *ctx, uint64_t bytes, void **d_out) {
+    if (!ctx || !d_out) return ZKLC_ERR_INVALID_ARG;
+    *d_out = nullptr;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    void *p = nullptr;
+    ZKLC_HIP(ctx, hipMalloc(&p, bytes ? bytes : 8));
+    hipError_t e = hipMemsetAsync(p, 0, bytes ? bytes : 8, ctx->stream);
+    if (e == hipSuccess) e = zklc_stream_wait(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(p);
+        ctx->last_err = std::string("zklc_device_alloc: ") + hipGetErrorString(e);
+        return ZKLC_ERR_HIP;
+    }
+    *d_out = p;
+    return ZKLC_OK;
+}
+
+extern "C" int32_t zklc_device_free(zklc_ctx *ctx, void *d_ptr) {
+    if (!ctx) return ZKLC_ERR_INVALID_ARG;
+    if (!d_ptr) return ZKLC_OK;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    ZKLC_HIP(ctx, hipFree(d_ptr));
+    return ZKLC_OK;
+}
+
+extern "C" int32_t zklc_device_copy(zklc_ctx *ctx, void *dst, const void *src, uint64_t bytes, int32_t to_host) {
+    if (!ctx || (bytes && (!dst || !src))) return ZKLC_ERR_INVALID_ARG;
+    ZKLC_HIP(ctx, hipSetDevice(ctx->device));
+    ZKLC_HIP(ctx, hipMemcpyAsync(dst, src, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, ctx->stream));
+    ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
+    return ZKLC_OK;
+}
 
 extern "C" int32_t zklc_synchronize(zklc_ctx *ctx) {
     if (!ctx) return ZKLC_ERR_INVALID_ARG;

@@ -1038,7 +1038,55 @@ struct zklc_plonky2_circuit {
     double timings[8] = {};
     u64 tree_words = 0;
     std::vector<void *> allocs;
+    // page-locked staging for every host <-> device transfer of a proof (p2_pin): blocks, bytes used of the last one
+    std::vector<std::pair<uint8_t *, size_t>> pin_blocks;
+    size_t pin_used = 0;
 };
+
+// Pinned staging.  hipMemcpyAsync to or from PAGEABLE host memory is not an enqueue: the runtime stages the bytes itself and the
+// call returns only when the stream has reached the copy -- waiting ACTIVELY.  With the transcript on the host a proof has ~10 such
+// points, so a proving thread sat at 1.00 host cores for the whole proof (profiles/r05d_host_cpu_probe.txt) although every explicit
+// wait already went through an event created with hipEventBlockingSync (zklc_stream_wait).  Round 6: every transfer of a proof goes
+// through this per-circuit page-locked arena, hipMemcpyAsync returns at once, and the thread sleeps in zklc_stream_wait -- blocking
+// waits by construction, no device-wide flag (the hipSetDeviceFlags option of round 5 is gone).  The arena is reset at the start of
+// a proof (a circuit proves one witness at a time) and grows by whole blocks, so pointers handed out stay valid until the next proof.
+static void *p2_pin(zklc_plonky2_circuit *c, size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (c->pin_blocks.empty() || c->pin_used + bytes > c->pin_blocks.back().second) {
+        size_t cap = bytes > (1u << 20) ? bytes : (1u << 20);
+        void *q = nullptr;
+        if (hipHostMalloc(&q, cap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        c->pin_blocks.push_back({(uint8_t *)q, cap});
+        c->pin_used = 0;
+    }
+    void *r = c->pin_blocks.back().first + c->pin_used;
+    c->pin_used += bytes;
+    return r;
+}
+// start of a proof: one block of the size the last proof needed (no transfer of this circuit is in flight here)
+static void p2_pin_reset(zklc_plonky2_circuit *c) {
+    if (c->pin_blocks.size() > 1) {
+        size_t total = 0;
+        for (auto &b : c->pin_blocks) {
+            total += b.second;
+            (void)hipHostFree(b.first);
+        }
+        c->pin_blocks.clear();
+        void *q = nullptr;
+        if (hipHostMalloc(&q, total, hipHostMallocDefault) == hipSuccess) c->pin_blocks.push_back({(uint8_t *)q, total});
+        else (void)hipGetLastError();
+    }
+    c->pin_used = 0;
+}
+#define P2_PIN(c, ptr, type, count)                                          \
+    type *ptr = (type *)p2_pin((c), sizeof(type) * (size_t)(count));          \
+    if (!ptr) {                                                               \
+        (c)->ctx->last_err = "hipHostMalloc: pinned staging";                 \
+        return ZKLC_ERR_OOM;                                                  \
+    }
 
 static int32_t p2_alloc(zklc_plonky2_circuit *c, void **p, size_t bytes) {
     zklc_ctx *ctx = c->ctx;
@@ -1078,9 +1126,10 @@ static int32_t p2_commit_coeffs(zklc_plonky2_circuit *c, hipStream_t st, p2_batc
     P2_RC(p2_merkle(c, st, b.lde, c->N, 1, c->lde_bits, b.width, b.tree));
     u32 cap_h = c->P.cap_height < c->lde_bits ? c->P.cap_height : c->lde_bits;
     cap.resize((size_t)32 << cap_h);
-    ZKLC_HIP(ctx, hipMemcpyAsync(cap.data(), p2_tree_level(b.tree, c->lde_bits, c->lde_bits - cap_h), cap.size(),
-                                 hipMemcpyDeviceToHost, st));
+    P2_PIN(c, h_cap, uint8_t, cap.size());
+    ZKLC_HIP(ctx, hipMemcpyAsync(h_cap, p2_tree_level(b.tree, c->lde_bits, c->lde_bits - cap_h), cap.size(), hipMemcpyDeviceToHost, st));
     ZKLC_HIP(ctx, zklc_stream_wait(st));
+    memcpy(cap.data(), h_cap, cap.size());
     return ZKLC_OK;
 }
 // values on the subgroup (natural order, in b.coeffs) -> coefficients in place, then commit
@@ -1103,10 +1152,13 @@ static int32_t p2_hash_no_pad(zklc_plonky2_circuit *c, hipStream_t st, const std
     void *d;
     P2_RC(zklc_stage(ctx, 6, v.size() * 8 + 64, &d));
     u64 *dv = (u64 *)d;
-    ZKLC_HIP(ctx, hipMemcpyAsync(dv + 8, v.data(), v.size() * 8, hipMemcpyHostToDevice, st));
+    P2_PIN(c, h_v, u64, v.size() + 4);
+    memcpy(h_v + 4, v.data(), v.size() * 8);
+    ZKLC_HIP(ctx, hipMemcpyAsync(dv + 8, h_v + 4, v.size() * 8, hipMemcpyHostToDevice, st));
     P2_RC(zklc_bn254_merkle_commit_strided(ctx, st, dv + 8, 1, 0, 0, (u32)v.size(), 0, dv));
-    ZKLC_HIP(ctx, hipMemcpyAsync(out32, dv, 32, hipMemcpyDeviceToHost, st));
+    ZKLC_HIP(ctx, hipMemcpyAsync(h_v, dv, 32, hipMemcpyDeviceToHost, st));
     ZKLC_HIP(ctx, zklc_stream_wait(st));
+    memcpy(out32, h_v, 32);
     return ZKLC_OK;
 }
 
@@ -1222,6 +1274,7 @@ extern "C" void zklc_plonky2_circuit_destroy(zklc_plonky2_circuit *c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (void *p : c->allocs) (void)hipFree(p);
+    for (auto &b : c->pin_blocks) (void)hipHostFree(b.first);
     delete c;
 }
 
@@ -1465,6 +1518,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
         t_prev = t;
     };
     c->last_challenges.clear();
+    p2_pin_reset(c);
 
     // ---- transcript start
     u64 pih[4];
@@ -1486,7 +1540,8 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
 
     // ---- Z and partial products (values written into zs.coeffs, then interpolated in place)
     u32 nblocks = (n + P2_SCAN_BLOCK - 1) / P2_SCAN_BLOCK;
-    u64 grand[P2_MAX_CH] = {1, 1};
+    P2_PIN(c, grand, u64, P2_MAX_CH);
+    for (u32 k = 0; k < P2_MAX_CH; k++) grand[k] = 1;
     for (u32 k = 0; k < nch; k++) {
         hipLaunchKernelGGL(p2_chunk_products_kernel, dim3((n + P2_THREADS - 1) / P2_THREADS), dim3(P2_THREADS), 0, st, d_wires,
                            (const u64 *)c->d_sigma_vals, (const u64 *)c->d_subgroup, (const u64 *)c->d_kis, n, P.num_routed_wires,
@@ -1518,7 +1573,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
         a.ch = chal;
         {
             u32 n_pow = nch + nch * (npp + 1) + P.num_gate_constraints + 1;
-            std::vector<u32> tab((size_t)nch * n_pow * 6);
+            P2_PIN(c, tab, u32, (size_t)nch * n_pow * 6);        // pinned and alive until the next proof: the upload needs no wait
             for (u32 k = 0; k < nch; k++) {
                 u64 v = 1;
                 for (u32 i = 0; i < n_pow; i++) {
@@ -1529,8 +1584,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
                     v = h_mul(v, chal.alpha[k]);
                 }
             }
-            ZKLC_HIP(ctx, hipMemcpyAsync(c->d_apow, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, st));
-            ZKLC_HIP(ctx, zklc_stream_wait(st));   // `tab` is a stack-lifetime source
+            ZKLC_HIP(ctx, hipMemcpyAsync(c->d_apow, tab, (size_t)nch * n_pow * 6 * 4, hipMemcpyHostToDevice, st));
             for (u32 k = 0; k < nch; k++) a.apow[k] = c->d_apow + (size_t)k * n_pow * 6;
             for (u32 k = nch; k < P2_MAX_CH; k++) a.apow[k] = c->d_apow;
         }
@@ -1611,7 +1665,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
     // ---- openings at zeta (all polynomials) and g*zeta (Zs)
     const u32 w0 = c->cs.width, w1 = c->wires.width, w2 = c->zs.width, w3 = c->quot.width;
     const u32 n_open = w0 + w1 + w2 + w3 + nch;
-    std::vector<gl2> open(n_open);
+    P2_PIN(c, open, gl2, n_open);
     {
         hipLaunchKernelGGL(p2_ext_powers_kernel, dim3((n + 255) / 256), dim3(256), 0, st, c->d_zpow, zeta, (u64)n);
         const p2_batch *bs[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
@@ -1627,7 +1681,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
         hipLaunchKernelGGL(p2_eval_finish_kernel, dim3((n_open + 255) / 256), dim3(256), 0, st, (const gl2 *)c->d_open_partial, n_open,
                            c->d_open);
         ZKLC_HIP(ctx, hipGetLastError());
-        ZKLC_HIP(ctx, hipMemcpyAsync(open.data(), c->d_open, (size_t)n_open * sizeof(gl2), hipMemcpyDeviceToHost, st));
+        ZKLC_HIP(ctx, hipMemcpyAsync(open, c->d_open, (size_t)n_open * sizeof(gl2), hipMemcpyDeviceToHost, st));
         ZKLC_HIP(ctx, zklc_stream_wait(st));
     }
     // transcript order = FriOpenings: batch at zeta (constants, sigmas, wires, zs, partial products, quotient), then zs_next
@@ -1680,9 +1734,11 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
             P2_RC(p2_merkle(c, st, (const u64 *)c->d_fri[r], 1, 2 * A, leaves_bits, 2 * A, c->d_fri_tree[r]));
             u32 cap_h = P.cap_height < leaves_bits ? P.cap_height : leaves_bits;
             fri_caps[r].resize((size_t)32 << cap_h);
-            ZKLC_HIP(ctx, hipMemcpyAsync(fri_caps[r].data(), p2_tree_level(c->d_fri_tree[r], leaves_bits, leaves_bits - cap_h),
-                                         fri_caps[r].size(), hipMemcpyDeviceToHost, st));
+            P2_PIN(c, h_fcap, uint8_t, fri_caps[r].size());
+            ZKLC_HIP(ctx, hipMemcpyAsync(h_fcap, p2_tree_level(c->d_fri_tree[r], leaves_bits, leaves_bits - cap_h), fri_caps[r].size(),
+                                         hipMemcpyDeviceToHost, st));
             ZKLC_HIP(ctx, zklc_stream_wait(st));
+            memcpy(fri_caps[r].data(), h_fcap, fri_caps[r].size());
             p2_observe_cap(ch, fri_caps[r], hasher);
             fri_betas[r].a = ch.challenge();
             fri_betas[r].b = ch.challenge();
@@ -1700,11 +1756,12 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
                            (const gl2 *)c->d_fri[P.num_arities], c->d_final, bits, h_inv(shift), h_inv(h_root(bits)), h_inv(M));
         ZKLC_HIP(ctx, hipGetLastError());
     }
-    std::vector<gl2> final_poly((size_t)1 << final_bits);
-    ZKLC_HIP(ctx, hipMemcpyAsync(final_poly.data(), c->d_final, final_poly.size() * sizeof(gl2), hipMemcpyDeviceToHost, st));
+    const size_t final_n = (size_t)1 << final_bits;
+    P2_PIN(c, final_poly, gl2, final_n);
+    ZKLC_HIP(ctx, hipMemcpyAsync(final_poly, c->d_final, final_n * sizeof(gl2), hipMemcpyDeviceToHost, st));
     ZKLC_HIP(ctx, zklc_stream_wait(st));
     const u32 final_len = 1u << (final_bits - P.rate_bits);
-    for (size_t i = final_len; i < final_poly.size(); i++)
+    for (size_t i = final_len; i < final_n; i++)
         if (final_poly[i].a || final_poly[i].b) {
             ctx->last_err = "plonky2: FRI final polynomial has a non-zero high coefficient (witness does not satisfy the circuit)";
             return ZKLC_ERR_INVALID_ARG;
@@ -1725,14 +1782,16 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
         a.pow_bits = P.proof_of_work_bits;
         a.found = c->d_found;
         const u64 batch = 1ULL << (P.proof_of_work_bits + 2 < 24 ? P.proof_of_work_bits + 2 : 24);  // ~98 % hit rate per launch
+        P2_PIN(c, h_found, unsigned long long, 1);
         unsigned long long found = ~0ULL;
         for (u64 base = 0;; base += batch) {
             ZKLC_HIP(ctx, hipMemsetAsync(c->d_found, 0xFF, 8, st));
             a.base = base;
             hipLaunchKernelGGL(p2_pow_kernel, dim3((unsigned)(batch / P2_THREADS)), dim3(P2_THREADS), 0, st, a);
             ZKLC_HIP(ctx, hipGetLastError());
-            ZKLC_HIP(ctx, hipMemcpyAsync(&found, c->d_found, 8, hipMemcpyDeviceToHost, st));
+            ZKLC_HIP(ctx, hipMemcpyAsync(h_found, c->d_found, 8, hipMemcpyDeviceToHost, st));
             ZKLC_HIP(ctx, zklc_stream_wait(st));
+            found = *h_found;
             if (found != ~0ULL) break;
             if (base > (1ULL << 50)) return ZKLC_ERR_INVALID_ARG;
         }
@@ -1747,7 +1806,8 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
     lap(5);
 
     // ---- query rounds: gather leaves, Merkle paths and FRI cosets
-    std::vector<u64> qwords(L.per_round_words * P.num_query_rounds);
+    const size_t n_qwords = L.per_round_words * P.num_query_rounds;
+    P2_PIN(c, qwords, u64, n_qwords);
     {
         std::vector<p2_gather> gs;
         const p2_batch *bs[4] = {&c->cs, &c->wires, &c->zs, &c->quot};
@@ -1777,20 +1837,22 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
                 }
             }
         }
-        if (dst != qwords.size()) return ZKLC_ERR_INVALID_ARG;
+        if (dst != n_qwords) return ZKLC_ERR_INVALID_ARG;
         if (c->gather_cap < gs.size()) {
             P2_ALLOC(c, c->d_gather, gs.size() * sizeof(p2_gather));
             c->gather_cap = gs.size();
         }
-        if (c->gather_out_words < qwords.size()) {
-            P2_ALLOC(c, c->d_gather_out, qwords.size() * 8);
-            c->gather_out_words = qwords.size();
+        if (c->gather_out_words < n_qwords) {
+            P2_ALLOC(c, c->d_gather_out, n_qwords * 8);
+            c->gather_out_words = n_qwords;
         }
-        ZKLC_HIP(ctx, hipMemcpyAsync(c->d_gather, gs.data(), gs.size() * sizeof(p2_gather), hipMemcpyHostToDevice, st));
+        P2_PIN(c, h_gs, p2_gather, gs.size());
+        memcpy(h_gs, gs.data(), gs.size() * sizeof(p2_gather));
+        ZKLC_HIP(ctx, hipMemcpyAsync(c->d_gather, h_gs, gs.size() * sizeof(p2_gather), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(p2_gather_kernel, dim3((unsigned)gs.size()), dim3(64), 0, st, (const p2_gather *)c->d_gather, (u32)gs.size(),
                            c->d_gather_out);
         ZKLC_HIP(ctx, hipGetLastError());
-        ZKLC_HIP(ctx, hipMemcpyAsync(qwords.data(), c->d_gather_out, qwords.size() * 8, hipMemcpyDeviceToHost, st));
+        ZKLC_HIP(ctx, hipMemcpyAsync(qwords, c->d_gather_out, n_qwords * 8, hipMemcpyDeviceToHost, st));
         ZKLC_HIP(ctx, zklc_stream_wait(st));
     }
 
@@ -1804,12 +1866,12 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
     put(zs_cap.data(), zs_cap.size());
     put(quot_cap.data(), quot_cap.size());
     // openings: constants, sigmas, wires, zs, zs_next, partial products, quotient
-    put(open.data(), (size_t)(w0 + w1 + nch) * 16);
-    put(open.data() + (w0 + w1 + w2 + w3), (size_t)nch * 16);
-    put(open.data() + (w0 + w1 + nch), (size_t)(w2 - nch + w3) * 16);
+    put(open, (size_t)(w0 + w1 + nch) * 16);
+    put(open + (w0 + w1 + w2 + w3), (size_t)nch * 16);
+    put(open + (w0 + w1 + nch), (size_t)(w2 - nch + w3) * 16);
     for (u32 r = 0; r < P.num_arities; r++) put(fri_caps[r].data(), fri_caps[r].size());
     {
-        const u64 *w = qwords.data();
+        const u64 *w = qwords;
         u32 widths[4] = {w0, w1, w2, w3};
         for (u32 q = 0; q < P.num_query_rounds; q++) {
             for (int k = 0; k < 4; k++) {
@@ -1832,7 +1894,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
             }
         }
     }
-    put(final_poly.data(), (size_t)final_len * 16);
+    put(final_poly, (size_t)final_len * 16);
     put(&pow_witness, 8);
     u64 npi = P.num_public_inputs;
     put(&npi, 8);

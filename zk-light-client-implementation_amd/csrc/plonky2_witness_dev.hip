@@ -56,6 +56,10 @@ struct zklc_witness_program {
     u64 *d_val = nullptr, *d_inputs = nullptr, *d_pis = nullptr;
     unsigned long long *d_err = nullptr;
     u32 cap_w = 0;
+    // page-locked staging of a batch's inputs, public inputs and error words: hipMemcpyAsync to / from pageable memory waits for
+    // the stream inside the call, actively (csrc/plonky2_prover.hip `p2_pin`); from here the thread sleeps in zklc_stream_wait
+    uint8_t *h_pin = nullptr;
+    size_t h_pin_bytes = 0;
     std::vector<void *> allocs;
 };
 
@@ -203,6 +207,7 @@ extern "C" void zklc_plonky2_witness_program_destroy(zklc_witness_program *p) {
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
     for (void *q : p->allocs) (void)hipFree(q);
+    if (p->h_pin) (void)hipHostFree(p->h_pin);
     delete p;
 }
 
@@ -438,10 +443,20 @@ extern "C" int32_t zklc_plonky2_witness_run_dev(zklc_ctx *ctx, void *stream, zkl
         WIT_ALLOC(p, p->d_err, (size_t)64 * 8);
         p->cap_w = W;
     }
+    const size_t in_bytes = (size_t)p->n_inputs * W * 8, pi_bytes = (size_t)p->n_pi * W * 8;
+    const size_t in_off = 0, pi_off = (in_bytes + 63) & ~(size_t)63, err_off = pi_off + ((pi_bytes + 63) & ~(size_t)63);
+    if (p->h_pin_bytes < err_off + 64 * 8) {
+        if (p->h_pin) (void)hipHostFree(p->h_pin);      // no transfer of this program is in flight between two runs
+        p->h_pin = nullptr;
+        p->h_pin_bytes = 0;
+        ZKLC_HIP(ctx, hipHostMalloc((void **)&p->h_pin, err_off + 64 * 8, hipHostMallocDefault));
+        p->h_pin_bytes = err_off + 64 * 8;
+    }
     ZKLC_HIP(ctx, hipMemsetAsync(p->d_val, 0xFF, (size_t)p->n_slots * W * 8, st));
     ZKLC_HIP(ctx, hipMemsetAsync(p->d_err, 0, 64 * 8, st));
     if (p->n_inputs) {
-        ZKLC_HIP(ctx, hipMemcpyAsync(p->d_inputs, input_values, (size_t)p->n_inputs * W * 8, hipMemcpyHostToDevice, st));
+        memcpy(p->h_pin + in_off, input_values, in_bytes);
+        ZKLC_HIP(ctx, hipMemcpyAsync(p->d_inputs, p->h_pin + in_off, in_bytes, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(wit_set_inputs_kernel, dim3((p->n_inputs * W + 255) / 256), dim3(256), 0, st, p->d_val,
                            (const u32 *)p->d_input_slots, (const u64 *)p->d_inputs, p->n_inputs, W, p->d_err);
     }
@@ -476,9 +491,11 @@ extern "C" int32_t zklc_plonky2_witness_run_dev(zklc_ctx *ctx, void *stream, zkl
                            (const u32 *)p->d_pi_slots, p->n_pi, W, p->d_pis, p->d_err);
     ZKLC_HIP(ctx, hipGetLastError());
     unsigned long long errs[64];
-    if (p->n_pi) ZKLC_HIP(ctx, hipMemcpyAsync(pi_out, p->d_pis, (size_t)p->n_pi * W * 8, hipMemcpyDeviceToHost, st));
-    ZKLC_HIP(ctx, hipMemcpyAsync(errs, p->d_err, 64 * 8, hipMemcpyDeviceToHost, st));
+    if (p->n_pi) ZKLC_HIP(ctx, hipMemcpyAsync(p->h_pin + pi_off, p->d_pis, pi_bytes, hipMemcpyDeviceToHost, st));
+    ZKLC_HIP(ctx, hipMemcpyAsync(p->h_pin + err_off, p->d_err, 64 * 8, hipMemcpyDeviceToHost, st));
     ZKLC_HIP(ctx, zklc_stream_wait(st));
+    if (p->n_pi) memcpy(pi_out, p->h_pin + pi_off, pi_bytes);
+    memcpy(errs, p->h_pin + err_off, 64 * 8);
     if (d_trace) {
         // debugging aid: the slowest levels of the stepping kernel with their opcode mix (ticks of the 100 MHz wall clock)
         std::vector<unsigned long long> tr(p->n_levels + 1);

@@ -770,11 +770,28 @@ class CircuitData:
         self._program = None
         self._init_arrays(b.config, uniq, row_gate, row_consts, sig_col, sig_row, len(b.public_inputs))
 
-    def __getstate__(self):
-        """what a prover needs after the build (circuit_cache.py): everything but the builder and its scratch"""
-        st = dict(self.__dict__)
-        st["builder"] = st["_plan"] = st["_trace"] = None
-        return st
+    _container = None         # set by plonky2/container.py `read_circuit`: the mapped file this circuit's arrays are views of
+
+    @property
+    def subgroup(self):
+        """[w^i] for the circuit's 2^degree_bits subgroup as Python integers (tests and tools only; computed on first use)"""
+        if getattr(self, "_subgroup", None) is None:
+            w, sub = root_of_unity(self.degree_bits), [1] * self.n
+            for i in range(1, self.n):
+                sub[i] = sub[i - 1] * w % P
+            self._subgroup = sub
+        return self._subgroup
+
+    def save(self, path, aux=None, note=None):
+        """write this circuit (and its compiled witness program) as a circuit container (plonky2/container.py, include/zklc.h b'')"""
+        from .container import write_circuit
+        write_circuit(path, self, aux, note)
+
+    @classmethod
+    def load(cls, path, verify=True):
+        """-> (CircuitData, aux) from a circuit container; the arrays are views of the mapped file"""
+        from .container import read_circuit
+        return read_circuit(path, verify)
 
     @classmethod
     def from_arrays(cls, config, gates, row_gate, row_consts, sig_col, sig_row, num_public_inputs):
@@ -826,11 +843,7 @@ class CircuitData:
         routed = cfg["num_routed_wires"]
         self.num_partial_products = -(-routed // qdf) - 1
         self.k_is = [pow(GENERATOR, i, P) for i in range(routed)]
-        w = root_of_unity(self.degree_bits)
-        sub = [1] * n
-        for i in range(1, n):
-            sub[i] = sub[i - 1] * w % P
-        self.subgroup = sub
+        sub = self.subgroup
         # sigma_j(w^i) = k_is[col'] * w^(row'): one field multiplication per cell
         sub_arr = np.array(sub, dtype=np.uint64)
         k_arr = np.array(self.k_is, dtype=np.uint64)
@@ -1133,10 +1146,13 @@ class DeviceWitness:
         self.n_inputs, self.n_pi = len(pr["input_slots"]), len(pr["pi_slots"])
         self.num_wires, self.n_rows = data.config["num_wires"], data.n
         h = ctypes.c_void_p()
-        rc = self._lib.zklc_plonky2_witness_program_create(
-            ctx._h, pr["code"].ctypes.data, len(pr["code"]), pr["params"].ctypes.data, len(pr["params"]), pr["n_slots"],
-            pr["input_slots"].ctypes.data, self.n_inputs, pr["wire_slot"].ctypes.data, pr["wire_index"].ctypes.data, len(pr["wire_slot"]),
-            self.num_wires, self.n_rows, pr["pi_slots"].ctypes.data, self.n_pi, ctypes.byref(h))
+        if data._container is not None:      # loaded from a circuit container: the library reads the program's sections itself
+            rc = self._lib.zklc_plonky2_witness_program_create_from_container(ctx._h, data._container._h, ctypes.byref(h))
+        else:
+            rc = self._lib.zklc_plonky2_witness_program_create(
+                ctx._h, pr["code"].ctypes.data, len(pr["code"]), pr["params"].ctypes.data, len(pr["params"]), pr["n_slots"],
+                pr["input_slots"].ctypes.data, self.n_inputs, pr["wire_slot"].ctypes.data, pr["wire_index"].ctypes.data, len(pr["wire_slot"]),
+                self.num_wires, self.n_rows, pr["pi_slots"].ctypes.data, self.n_pi, ctypes.byref(h))
         ctx._check(rc)
         self._h = h
 

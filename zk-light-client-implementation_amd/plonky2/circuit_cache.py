@@ -10,16 +10,15 @@ the gate list, the constants and sigma matrices, the witness program (instructio
 Processes that miss the same entry at the same time (the ranks of a multi-GPU job on a cold cache) build it ONCE: the first takes an
 advisory lock beside the entry, the others wait for it and load the result.
 
-A cache entry is ONE pickle (protocol 5, numpy buffers inline) of (CircuitData without its builder, aux) so that the Target objects
-shared between `aux` and the witness program's input list stay the same objects.  The file name carries the caller's key and a
-digest of this package's circuit-building sources: any change to them invalidates every entry.  The directory is a LOCAL cache and
-must be trusted like the code itself (pickle executes what it loads); nothing received from a peer or the network ever goes
-through it (the multi-GPU wire format is distributed.encode_obj).
+A cache entry is ONE circuit container (plonky2/container.py; include/zklc.h section b''; csrc/container.cpp): the flat, versioned,
+language-neutral file whose sections are the arguments of `zklc_plonky2_circuit_create` / `zklc_plonky2_witness_program_create`,
+plus the host mirror's own sections (configuration, gate ids, the caller's target tree as JSON with table indices).  Loading maps the
+file and parses JSON: nothing in an entry is executed, the matrices are never copied into the Python heap, and the prover creates the
+GPU circuit straight from the mapped sections.  The file name carries the caller's key and a digest of this package's
+circuit-building sources: any change to them invalidates every entry.
 """
 import hashlib
 import os
-import pickle
-import tempfile
 
 _SOURCES_DIGEST = None
 
@@ -33,7 +32,8 @@ def _sources_digest():
         files = sorted(os.path.join(here, f) for f in os.listdir(here) if f.endswith(".py"))
         files += sorted(os.path.join(pkg, f) for f in os.listdir(pkg) if f.endswith(".py"))
         # the cached witness programs are interpreted by native code: a change of the opcode encoding must invalidate them too
-        files += [os.path.join(pkg, "csrc", f) for f in ("plonky2_witness_ops.h", "plonky2_witness.cpp", "plonky2_witness_dev.hip")]
+        files += [os.path.join(pkg, "csrc", f) for f in ("plonky2_witness_ops.h", "plonky2_witness.cpp", "plonky2_witness_dev.hip",
+                                                         "container.cpp")]
         for f in files:
             h.update(os.path.basename(f).encode())
             with open(f, "rb") as fh:
@@ -76,8 +76,8 @@ def _load(path):
     if not os.path.exists(path):
         return None
     try:
-        with open(path, "rb") as f:
-            return pickle.load(f)
+        from .container import read_circuit
+        return read_circuit(path, verify=os.environ.get("ZKLC_CIRCUIT_CACHE_VERIFY", "1") != "0")
     except Exception as e:          # a truncated or foreign file: rebuild and replace it -- and say so, once per entry
         import sys
         print("zklc circuit cache: entry %s discarded (%s: %s), rebuilding" % (os.path.basename(path), type(e).__name__, e),
@@ -100,22 +100,20 @@ def _lock(path):
 def _build_and_store(d, path, build):
     data, aux = build()
     assert data._program is not None, "compile the witness program before caching a circuit"
-    tmp = None
     try:                                       # the cache is an optimisation: a read-only or full directory must not stop a proof
         os.makedirs(d, exist_ok=True)
-        fd, tmp = tempfile.mkstemp(dir=d, suffix=".tmp")
-        with os.fdopen(fd, "wb") as f:
-            pickle.dump((data, aux), f, protocol=5)
-        os.replace(tmp, path)              # atomic: concurrent processes never see a partial entry
-    except OSError as e:
+        data.save(path, aux, note="circuit cache entry %s" % os.path.basename(path))      # atomic inside the library (temp + rename)
+    except (OSError, ValueError) as e:
         import sys
         print("zklc circuit cache: entry %s not written (%s: %s)" % (os.path.basename(path), type(e).__name__, e), file=sys.stderr)
-        if tmp and os.path.exists(tmp):
-            try:
-                os.unlink(tmp)
-            except OSError:
-                pass
-    return data, aux, False
+        return data, aux, False
+    # continue with the entry just written, not with the builder's object graph (millions of Python objects per circuit): the
+    # process that built a circuit then holds what every later process holds -- views of the mapped file
+    got = _load(path)
+    if got is None:
+        return data, aux, False
+    del data, aux
+    return got[0], got[1], False
 
 
 # ------------------------------------------------------------------------------------------------ out-of-process builds
@@ -179,29 +177,44 @@ def prewarm(jobs, processes=None, timeout_s=900):
         code = ("import sys; sys.path.insert(0, %r); import zklc_amd; from zklc_amd.plonky2 import circuit_cache as C; "
                 "C.build_job(sys.argv[1], sys.argv[2])" % root)
         env = dict(os.environ, OMP_NUM_THREADS="2", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+        import tempfile
         running, pending = [], list(todo)
         deadline = time.perf_counter() + timeout_s
+
+        def tail(f):
+            # a child's stderr goes to a file, not a pipe: a pipe nobody reads blocks the child after 64 KB of warnings
+            try:
+                f.seek(0)
+                return f.read()[-300:]
+            except (OSError, ValueError):
+                return ""
+            finally:
+                f.close()
         while pending or running:
+            if time.perf_counter() > deadline and pending:        # out of time: what has not started is not started any more
+                rep["failed"] += [(job[0], job[1], "timeout (not started)") for job in pending]
+                pending = []
             while pending and len(running) < procs_max:
                 job = pending.pop(0)
+                errf = tempfile.TemporaryFile(mode="w+")
                 running.append((job, subprocess.Popen([sys.executable, "-c", code, job[0], str(job[1])], env=env,
-                                                      stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)))
+                                                      stdout=subprocess.DEVNULL, stderr=errf, text=True), errf))
             time.sleep(0.2)
             still = []
-            for job, p in running:
+            for job, p, errf in running:
                 if p.poll() is None:
                     if time.perf_counter() > deadline:
                         p.kill()
-                        p.communicate()
-                        rep["failed"].append((job[0], job[1], "timeout"))
+                        p.wait()
+                        rep["failed"].append((job[0], job[1], "timeout: " + tail(errf)))
                     else:
-                        still.append((job, p))
+                        still.append((job, p, errf))
                     continue
-                err = p.communicate()[1]
+                err = tail(errf)
                 if p.returncode == 0 and os.path.exists(job[2]):
                     rep["built"] += 1
                 else:
-                    rep["failed"].append((job[0], job[1], (err or "")[-300:]))
+                    rep["failed"].append((job[0], job[1], err))
             running = still
     except Exception as e:          # an optimisation: the in-process build on first use remains
         rep["failed"].append(("prewarm", 0, repr(e)[:300]))

@@ -10,7 +10,6 @@ import numpy as np
 
 from .. import _lib
 from . import serialization as S
-from .builder import P, root_of_unity
 
 HASH_GL, HASH_BN128 = S.HASH_GL, S.HASH_BN128
 
@@ -45,37 +44,17 @@ class Prover:
     def __init__(self, ctx, data, hasher=HASH_GL):
         self.ctx, self.data, self.hasher = ctx, data, hasher
         self._lib = _lib.load()
-        cfg = data.config
-        fri = cfg["fri_config"]
-        p = ParamsC()
-        p.degree_bits, p.num_wires, p.num_routed_wires = data.degree_bits, cfg["num_wires"], cfg["num_routed_wires"]
-        p.num_constants, p.num_selectors, p.num_challenges = data.num_constants, len(data.groups), cfg["num_challenges"]
-        p.rate_bits, p.cap_height, p.proof_of_work_bits = fri["rate_bits"], fri["cap_height"], fri["proof_of_work_bits"]
-        p.num_query_rounds = fri["num_query_rounds"]
-        p.quotient_degree_factor, p.num_partial_products = data.quotient_degree_factor, data.num_partial_products
-        p.num_gate_constraints, p.num_public_inputs = data.num_gate_constraints, data.num_public_inputs
-        p.hasher, p.num_gates, p.num_arities = hasher, len(data.gates), len(data.fri_arity_bits)
-        for i, a in enumerate(data.fri_arity_bits):
-            p.arity_bits[i] = a
-        gates = (GateC * len(data.gates))()
-        extra = []
-        for i, g in enumerate(data.gates):
-            gates[i].type = g.code
-            for k in range(4):
-                gates[i].p[k] = g.params[k]
-            s, e = data.groups[data.selector_indices[i]]
-            gates[i].selector_index, gates[i].group_start, gates[i].group_end = data.selector_indices[i], s, e
-            gates[i].extra_off = len(extra)
-            if g.code == 13:   # CosetInterpolationGate: barycentric weights, then the subgroup points
-                w = root_of_unity(g.subgroup_bits)
-                extra += list(g.weights) + [pow(w, j, P) for j in range(1 << g.subgroup_bits)]
-        ex = np.array(extra, dtype=np.uint64)
-        kis = np.array(data.k_is, dtype=np.uint64)
-        consts = np.ascontiguousarray(data.constants, dtype=np.uint64)
-        sig = np.ascontiguousarray(data.sigmas, dtype=np.uint64)
         h = ctypes.c_void_p()
-        rc = self._lib.zklc_plonky2_circuit_create(ctx._h, ctypes.byref(p), gates, ex.ctypes.data if len(extra) else None, len(extra),
-                                                   kis.ctypes.data, consts.ctypes.data, sig.ctypes.data, ctypes.byref(h))
+        if data._container is not None:
+            # a circuit loaded from a container file: the library takes parameters, gates and matrices from the file's sections
+            rc = self._lib.zklc_plonky2_circuit_create_from_container(ctx._h, data._container._h, int(hasher), ctypes.byref(h))
+        else:
+            from .container import native_arguments
+            p, gates, ex, kis = native_arguments(data, hasher)
+            consts = np.ascontiguousarray(data.constants, dtype=np.uint64)
+            sig = np.ascontiguousarray(data.sigmas, dtype=np.uint64)
+            rc = self._lib.zklc_plonky2_circuit_create(ctx._h, ctypes.byref(p), gates, ex.ctypes.data if ex.size else None, ex.size,
+                                                       kis.ctypes.data, consts.ctypes.data, sig.ctypes.data, ctypes.byref(h))
         ctx._check(rc)
         self._h = h
         self.common = data.common_data()
