@@ -206,6 +206,10 @@ uint32_t zklc_plonky2_last_timings(zklc_plonky2_circuit *c, double *out_ms, uint
 int32_t zklc_poseidon_gl_gate_rows(const uint64_t *inputs, const uint64_t *swap, uint32_t n, uint64_t *rows);
 /* out[i] = a[i] * b[i] in the Goldilocks field (host function; canonical inputs): the circuit builder's sigma values */
 void zklc_gl_mul_vec(const uint64_t *a, const uint64_t *b, uint64_t *out, uint64_t n);
+/* copy classes of a circuit under construction (host function): union-find over n_pairs `connect(a, b)` records given as dense
+ * target indices; root_out[i] = the smallest index of i's class.  The native part of the host circuit builder (plonky2's
+ * `wire_partition`, reached from every gadget of crypto/plonky2_ed25519/src/gadgets). */
+int32_t zklc_host_copy_classes(const int64_t *ia, const int64_t *ib, uint64_t n_pairs, uint64_t n_keys, int64_t *root_out);
 /* Poseidon-Goldilocks parameters (gnark-plonky2-verifier/poseidon/goldilocks_constants.go): all round constants (30 x 12),
  * the optimised partial-round constants (first layer 12, one per round 22), MDS circulant + diagonal.  Used by the host
  * circuit builder to restate PoseidonGate's constraints in-circuit (recursive verifier). */

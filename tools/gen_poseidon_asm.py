@@ -668,12 +668,10 @@ def c_table(name, vals):
     return "\n".join(lines)
 
 
-def main():
-    consts, tables = load_constants()
-    selftest(consts, tables)
-    if "--check" in sys.argv:
-        print("gen_poseidon_asm: simulator self-test OK")
-        return
+def render(consts=None, tables=None):
+    """-> (text of csrc/poseidon_gl_asm.inc, per-statement statistics, instructions per permutation); writes nothing"""
+    if consts is None:
+        consts, tables = load_constants()
     parts = ["// GENERATED by tools/gen_poseidon_asm.py -- do not edit.  Hand-scheduled gfx950 statements of the Poseidon-Goldilocks",
              "// permutation (see the generator for the derivation, the hazard rule and the simulator that checks every list).",
              "// Tables: PGL_ASM_RC[layer][row] = {lo, 0, hi, 0} of the constant added after the MDS of full round `layer`;",
@@ -704,7 +702,23 @@ def main():
     total = 7 * stats[0][1] + stats[1][1] + 2 * stats[2][1]
     parts.insert(5, "// instructions per statement (of which s_nop): " + "; ".join("%s %d (%d)" % s for s in stats)
                  + "; permutation ~%d + first constant layer / canonicalisation" % total)
-    open(os.path.join(ROOT, "zk-light-client-implementation_amd", "csrc", "poseidon_gl_asm.inc"), "w").write("\n".join(parts) + "\n")
+    return "\n".join(parts) + "\n", stats, total
+
+
+INC_PATH = os.path.join(ROOT, "zk-light-client-implementation_amd", "csrc", "poseidon_gl_asm.inc")
+
+
+def main():
+    consts, tables = load_constants()
+    selftest(consts, tables)
+    if "--check" in sys.argv:
+        print("gen_poseidon_asm: simulator self-test OK")
+        return
+    text, stats, total = render(consts, tables)
+    if os.path.exists(INC_PATH) and open(INC_PATH).read() == text:
+        print("poseidon_gl_asm.inc is current:", stats, "total ~", total)       # untouched: its mtime drives the incremental build
+        return
+    open(INC_PATH, "w").write(text)
     print("generated poseidon_gl_asm.inc:", stats, "total ~", total)
 
 

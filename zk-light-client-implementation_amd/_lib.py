@@ -89,6 +89,7 @@ _SIGS = {
     "zklc_plonky2_witness_release": (None, []),
     "zklc_poseidon_gl_constants": (None, [_u8p, _u8p, _u8p, _u8p, _u8p]),
     "zklc_gl_mul_vec": (None, [_u8p, _u8p, _u8p, ctypes.c_uint64]),
+    "zklc_host_copy_classes": (ctypes.c_int32, [_u8p, _u8p, ctypes.c_uint64, ctypes.c_uint64, _u8p]),
     "zklc_plonky2_witness_program_create": (ctypes.c_int32, [ctypes.c_void_p, _u8p, ctypes.c_uint64, _u8p, ctypes.c_uint64, ctypes.c_uint32,
                                                              _u8p, ctypes.c_uint32, _u8p, _u8p, ctypes.c_uint64, ctypes.c_uint32,
                                                              ctypes.c_uint32, _u8p, ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]),

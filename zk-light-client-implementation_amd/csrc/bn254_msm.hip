@@ -666,6 +666,10 @@ static int32_t msm_fixed_table_dev(zklc_ctx *ctx, void *stream, const uint64_t *
     u32 hdr[MSM_TABLE_HEADER_WORDS] = {MSM_TABLE_MAGIC, pl.n, pl.c, pl.windows, (u32)msm_rec<F, true>::WORDS};
     ZKLC_HIP(ctx, hipMemcpyAsync(d_table, hdr, sizeof(hdr), hipMemcpyHostToDevice, st));
     ZKLC_HIP(ctx, zklc_stream_wait(st));                 // hdr lives on this stack frame
+    {
+        std::lock_guard<std::mutex> lk(ctx->msm_tables_mu);
+        ctx->msm_tables[d_table] = {hdr[0], hdr[1], hdr[2], hdr[3], hdr[4]};
+    }
     if (pl.n)
         hipLaunchKernelGGL((msm_fixed_table_kernel<F>), dim3((pl.n + 63) / 64), dim3(64), 0, st, d_points, pl.n, pl.c, pl.windows,
                            (i32 *)d_table + MSM_TABLE_HEADER_WORDS);
@@ -677,8 +681,32 @@ static int32_t msm_fixed_run_dev(zklc_ctx *ctx, void *stream, const void *d_tabl
                                  uint64_t *d_out_affine, uint32_t *d_out_inf, void *d_workspace, uint64_t workspace_bytes) {
     if (!ctx || !d_table || ((uintptr_t)d_table & 255)) return ZKLC_ERR_INVALID_ARG;
     ZKLC_HIP(ctx, hipSetDevice(ctx->device));
-    u32 hdr[5];
-    ZKLC_HIP(ctx, hipMemcpy(hdr, d_table, sizeof(hdr), hipMemcpyDeviceToHost));     // 20 bytes: is this a table for n bases of this group?
+    // is this a table for n bases of this group?  A table this context built (or has checked before) is known by its address: the
+    // call stays enqueue-only.  Any other address is read ONCE -- 20 bytes on the caller's stream, a blocking wait -- and remembered.
+    std::array<u32, 5> hdr;
+    bool known = false;
+    {
+        std::lock_guard<std::mutex> lk(ctx->msm_tables_mu);
+        auto it = ctx->msm_tables.find(d_table);
+        if (it != ctx->msm_tables.end()) {
+            hdr = it->second;
+            known = true;
+        }
+    }
+    if (!known) {
+        hipStream_t st = zklc_pick_stream(ctx, stream);
+        u32 *h_hdr = nullptr;
+        ZKLC_HIP(ctx, hipHostMalloc((void **)&h_hdr, sizeof(u32) * 5, hipHostMallocDefault));
+        hipError_t e = hipMemcpyAsync(h_hdr, d_table, sizeof(u32) * 5, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = zklc_stream_wait(st);
+        for (int i = 0; i < 5; i++) hdr[i] = h_hdr[i];
+        (void)hipHostFree(h_hdr);
+        ZKLC_HIP(ctx, e);
+        if (hdr[0] == MSM_TABLE_MAGIC) {
+            std::lock_guard<std::mutex> lk(ctx->msm_tables_mu);
+            ctx->msm_tables[d_table] = hdr;
+        }
+    }
     msm_plan pl = msm_make_plan(n, false);
     if (hdr[0] != MSM_TABLE_MAGIC || hdr[1] != pl.n || hdr[2] != pl.c || hdr[3] != pl.windows || hdr[4] != (u32)msm_rec<F, true>::WORDS)
         return ZKLC_ERR_INVALID_ARG;

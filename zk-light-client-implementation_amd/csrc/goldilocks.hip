@@ -448,9 +448,16 @@ __device__ __forceinline__ u64 pgl_coop_mds(u64 s, u32 g, u64 *grp) {
     // A 16-lane group lives inside ONE wave and owns its 12 LDS words: the LDS queue of a wave is in order, so the exchange needs no
     // workgroup barrier (round 5: two s_barrier per layer x 30 layers were most of a cooperative permutation's latency) -- only the
     // compiler must keep the order: previous layer's reads, this layer's writes, this layer's reads.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // INVARIANT (every caller; checked where the groups are formed): blockDim.x is a multiple of 16, the 16 lanes of a group are
+    // threadIdx.x >> 4 == const -- so a group never spans two waves (64 % 16 == 0) -- and `grp` is PRIVATE to the group.  A caller
+    // whose groups crossed waves or shared `grp` would need __syncthreads() here instead.
+    static_assert(64 % 16 == 0 && (PGL_COOP_GROUPS * 16) % 64 == 0, "a 16-lane group must live inside one wave");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // order for the compiler ...
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // ... and the previous layer's reads have returned
     if (g < 12) grp[g] = s;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the group's twelve words are in LDS before anyone reads them
+    __builtin_amdgcn_wave_barrier();
     u64 sl = 0, sh = 0;
     const u32 gg = g < 12 ? g : 0;
 #pragma unroll

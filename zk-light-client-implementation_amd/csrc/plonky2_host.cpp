@@ -157,3 +157,32 @@ extern "C" int32_t zklc_poseidon_gl_gate_rows(const uint64_t *inputs, const uint
     }
     return 0;
 }
+
+// Copy classes of a circuit (plonky2 `CircuitBuilder::connect` -> `wire_partition`, plonk/permutation_argument.rs; the reference
+// reaches it through every gadget of crypto/plonky2_ed25519/src/gadgets/*.rs): union-find over the n_pairs recorded connections
+// (ia[k], ib[k] = dense indices of the two targets), root_out[i] = the SMALLEST index of i's class.  The Ed25519 circuit records
+// ~40 M connections: a Python union-find took minutes, scipy's connected components seconds; this is 0.3 s and drops the scipy
+// dependency.  Returns -1 on an index out of range.
+extern "C" int32_t zklc_host_copy_classes(const int64_t *ia, const int64_t *ib, uint64_t n_pairs, uint64_t n_keys, int64_t *root_out) {
+    if ((n_pairs && (!ia || !ib)) || (n_keys && !root_out) || n_keys >> 40) return -1;
+    int64_t *p = root_out;                                 // parent forest in place; links always point to the smaller index
+    for (uint64_t i = 0; i < n_keys; i++) p[i] = (int64_t)i;
+    auto find = [&](int64_t x) {
+        int64_t r = x;
+        while (p[r] != r) r = p[r];
+        while (p[x] != r) {                                // path compression
+            int64_t nx = p[x];
+            p[x] = r;
+            x = nx;
+        }
+        return r;
+    };
+    for (uint64_t k = 0; k < n_pairs; k++) {
+        if (ia[k] < 0 || ib[k] < 0 || (uint64_t)ia[k] >= n_keys || (uint64_t)ib[k] >= n_keys) return -1;
+        int64_t ra = find(ia[k]), rb = find(ib[k]);
+        if (ra < rb) p[rb] = ra;
+        else if (rb < ra) p[ra] = rb;
+    }
+    for (uint64_t i = 0; i < n_keys; i++) p[i] = p[p[i]] == p[i] ? p[i] : find((int64_t)i);   // every entry -> its root
+    return 0;
+}

@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <array>
+#include <map>
+#include <mutex>
 #include <string>
 #include "../../include/zklc.h"
 
@@ -37,6 +40,10 @@ struct zklc_ctx {
     void *fr_ntt_tab[2][29] = {};
     // grow-only staging buffers for the host-pointer entry points (slot 7 = kernel scratch)
     zklc_devbuf stage[8];
+    // fixed-base MSM tables this context has built or validated: device address -> header words (bn254_msm.hip), so that the
+    // *_msm_fixed_dev entry points stay enqueue-only (no device read, no null-stream copy) after a table's first use
+    std::map<const void *, std::array<uint32_t, 5>> msm_tables;
+    std::mutex msm_tables_mu;
 };
 
 #define ZKLC_HIP(ctx, call)                                           \

@@ -503,12 +503,33 @@ class BlockPipeline:
             # (2) local folds -> binary tree over the ranks -> closing proof on rank 0, per approval set
             self._join(sig)
             self._strong_checkpoint(st, dag)          # .. and so does a failed signature stage: no partial aggregate is folded
-            combine = lambda x, y: (lambda rc_p: (rc_p[0].common, rc_p[0].verifier_only, rc_p[1]))(self.rp.recursive_proof(x, y, raw=True))
-            for s in st["sets"]:
-                total = DIST.tree_fold(s.local_agg, combine, device=self.comm_device)   # None = a rank without signatures
-                if self.rank == 0:
-                    self._close_set(st, s, total)
+            fold_err = []
+
+            def combine(x, y):
+                # a combine that raised would leave this rank's tree partners blocked in recv_obj: the exchange pattern is kept
+                # (every send / receive still happens, with nothing folded), the error is recorded and checkpoint (3) below makes
+                # EVERY rank fail the block together
+                if fold_err:
+                    return None
+                try:
+                    rc_, p_ = self.rp.recursive_proof(x, y, raw=True)
+                    return (rc_.common, rc_.verifier_only, p_)
+                except Exception as e:
+                    fold_err.append(e)
+                    return None
+            totals = [DIST.tree_fold(s.local_agg, combine, device=self.comm_device) for s in st["sets"]]   # None = no signatures here
+            if fold_err:
+                self._fail(st, fold_err[0])
+            self._strong_checkpoint(st, dag)          # (3) the tree fold succeeded on every rank
+            if self.rank == 0:
+                try:
+                    for s, total in zip(st["sets"], totals):
+                        if not s.future.done():       # rank 0's DAG thread may have failed meanwhile: _fail has set the futures
+                            self._close_set(st, s, total)
+                except Exception as e:
+                    self._fail(st, e)
             self._join(dag)
+            self._strong_checkpoint(st, [])           # (4) closing proofs, joins and wrap on rank 0: the block succeeds or fails everywhere
         else:
             self._join(sig + dag + side)
         self._raise(st)

@@ -155,7 +155,7 @@ class CircuitBuilder:
     # Copy constraints (plonky2 `connect` -> the disjoint-set forest of `wire_partition`).  Round 5: `connect` only RECORDS the pair
     # (the Ed25519 circuit makes 4.4 M of them; a Python union-find per call was a quarter of its construction time); the classes
     # are resolved once, when something first asks for them, as the connected components of the recorded graph
-    # (scipy.sparse.csgraph).  The root of a class is its smallest key -- nothing depends on which member it is.
+    # (native union-find, zklc_host_copy_classes).  The root of a class is its smallest key -- nothing depends on which member it is.
     def connect(self, a, b):
         self._conn_a.append(a.k)
         self._conn_b.append(b.k)
@@ -167,18 +167,17 @@ class CircuitBuilder:
         if n_pairs == 0:
             self._classes = (0, {}, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))
             return self._classes
-        from scipy.sparse import coo_matrix
-        from scipy.sparse.csgraph import connected_components
         a = np.array(self._conn_a, dtype=np.int64)
         b = np.array(self._conn_b, dtype=np.int64)
         keys, inv = np.unique(np.concatenate([a, b]), return_inverse=True)
-        ia, ib = inv[:n_pairs], inv[n_pairs:]
-        g = coo_matrix((np.ones(n_pairs, dtype=np.int8), (ia, ib)), shape=(len(keys), len(keys)))
-        _, label = connected_components(g, directed=False)
-        # root = the smallest key of the class: keys are sorted, so the first occurrence of a label is its minimum
-        first = np.full(int(label.max()) + 1, len(keys), dtype=np.int64)
-        np.minimum.at(first, label, np.arange(len(keys), dtype=np.int64))
-        roots = keys[first[label]]
+        ia, ib = np.ascontiguousarray(inv[:n_pairs], dtype=np.int64), np.ascontiguousarray(inv[n_pairs:], dtype=np.int64)
+        # native union-find (csrc/plonky2_host.cpp): root index = the smallest index of the class; keys are sorted, so that is the
+        # class's smallest key
+        from .. import _lib
+        root_idx = np.empty(len(keys), dtype=np.int64)
+        rc = _lib.load().zklc_host_copy_classes(ia.ctypes.data, ib.ctypes.data, n_pairs, len(keys), root_idx.ctypes.data)
+        assert rc == 0, "copy classes: index out of range"
+        roots = keys[root_idx]
         nonroot = roots != keys
         parent = dict(zip(keys[nonroot].tolist(), roots[nonroot].tolist()))
         self._classes = (n_pairs, parent, keys, roots)
