@@ -451,8 +451,6 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
     # the PRODUCT shape: every commitment of the Ed25519 circuit extends 2^18 -> 2^21 (prove_crypto/ed25519.rs:60), the less efficient
     # case of the two: PMC at this shape in profiles/r05a_lde_pmc_2p18_to_2p21.json
     try:
-        if not args.extra_stages:
-            raise KeyError("skipped")
         c18 = torch.randint(0, 2**63 - 1, (batch, 1 << 18), generator=g, device=dev, dtype=torch.int64)
         l21 = torch.empty((batch, 1 << 21), dtype=torch.int64, device=dev)
         ms18, _ = _time_stream(lambda: ctx.gl_lde_dev(c18, 18, rate, batch, 7, l21, flags=zklc_amd._lib.NTT_OUT_BITREV, stream=stream),
@@ -974,8 +972,15 @@ def compact_line(full):
         line["cpu_baseline"] = {k: r3(cb[k]) for k in ("value", "unit", "cores", "kind", "sample", "seconds_per_block", "gpu_speedup") if k in cb}
     st = full.get("stages") or {}
     cs = {}
+    # `lde` of the line = the PRODUCT shape 234 x (2^18 -> 2^21) every commitment of the Ed25519 circuit extends; C3's own shape
+    # (2^17 -> 2^20, BASELINE configs[2]) rides beside it as `lde_c3` (round 6; the detail file keeps them as lde_2p18 / lde)
+    have18 = bool(st.get("lde_2p18") and "value" in st["lde_2p18"])
     for name in ("msm", "lde", "lde_2p18", "merkle", "ed25519_verify"):
         s_ = st.get(name)
+        if name == "lde" and have18:
+            name = "lde_c3"
+        elif name == "lde_2p18" and have18:
+            name = "lde"
         if s_ and "value" in s_:
             e = {"value": r3(s_["value"]), "unit": s_["unit"]}
             if "ms" in s_:

@@ -104,3 +104,26 @@ def test_strong_scaling_block_over_rccl():
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["final_proof_verified"] and j["block_i"]["strong"]["final_proof_verified"]
     assert j["stages"]["msm"]["strong"]["equal"] is True          # compact line: sharded MSM == the single-GPU point
+
+
+def test_two_ranks_share_the_one_gpu_over_gloo():
+    """The multi-rank bench path kept alive on a ONE-GPU box (test hygiene): `python bench.py --gpus 2 --backend gloo`
+    starts its own two ranks (no torchrun), both on cuda:0 -- RCCL cannot put two ranks on one device, gloo can: collectives on host
+    tensors, kernels on the shared GPU -- and runs the weak step (each rank its own block) AND the strong section (ONE block over
+    both ranks: signature shards, local folds, the tree fold's point-to-point exchange, header proofs on rank 1, joins and the wrap
+    on rank 0) with the final proofs verified by the oracle's verifier inside bench.py.  Several minutes (two ranks build or load
+    every circuit); ZKLC_FAST_TESTS=1 skips."""
+    import json
+    if os.environ.get("ZKLC_FAST_TESTS"):
+        pytest.skip("ZKLC_FAST_TESTS: a multi-minute two-rank bench run")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", ZKLC_BENCH_DETAIL=os.path.join(ROOT, "gpurun_out", "test_two_ranks_detail.json"))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-bn254-extras", "--c5-validators", "0"], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["final_proof_verified"] is True
+    blk = line["block_i"]
+    assert blk["blocks_checked"] == 1 and blk["strong"]["final_proof_verified"] is True
+    assert line["stages"]["msm"]["strong"]["equal"] is True          # the index-sharded MSM == the single-GPU point
+    print("two ranks on one GPU: weak %.2f s per step, strong %.2f s per block" % (line["ms_per_step"] / 1e3, blk["strong"]["seconds_per_block"]))

@@ -69,7 +69,14 @@ class KeysStakesProver:
         shape = (tuple(valid_keys[0::PK_HASH_BYTES + 1]), tuple(len(v) for v in validators))
         ent = next((e for e in self._cache if e[0] == shape), None)
         if ent is None:
-            data, vt, kt = keys_stakes_circuit(valid_keys, [len(v) for v in validators])
+            from .plonky2.circuit_cache import load_or_build
+
+            def build():
+                data, vt, kt = keys_stakes_circuit(valid_keys, [len(v) for v in validators])
+                data.witness_program([t for ts in vt for t in ts] + list(kt))
+                return data, {"vt": vt, "kt": kt}
+            data, aux, _ = load_or_build("keys_stakes", shape, build)
+            vt, kt = aux["vt"], aux["kt"]
             ent = (shape, data, vt, kt, data.prover(self.ctx, HASH_GL))
             self._cache.append(ent)
             if len(self._cache) > self.cache_size:

@@ -836,6 +836,19 @@ def recursive_circuit(inners, num_public_inputs=0, builder=None):
     return b.build(), {"proofs": pts, "verifier_data": vts, "public_inputs": pis}
 
 
+def target_leaves(tree):
+    """every Target of a nested dict / list / tuple, in traversal order"""
+    from .builder import Target
+    if isinstance(tree, Target):
+        yield tree
+    elif isinstance(tree, dict):
+        for v in tree.values():
+            yield from target_leaves(v)
+    elif isinstance(tree, (list, tuple)):
+        for v in tree:
+            yield from target_leaves(v)
+
+
 def recursive_witness(targets, inner_proofs, public_inputs=()):
     """the PartialWitness of recursion.rs:44-92: inner_proofs = [(proof_json, verifier_only_json), ...]"""
     pw = {}
@@ -952,7 +965,17 @@ class RecursionProver:
         key = json.dumps([commons, num_public_inputs], sort_keys=True)
         rc = self._cache.get(key)
         if rc is None:
-            data, targets = recursive_circuit(commons, num_public_inputs)
+            # through the circuit cache (round 6): a verifier circuit is ~1-2.5 s of host Python to build and compile, a block's DAG
+            # has ~20 distinct shapes, and a container entry loads in 0.1 s.  The program's inputs are every target of the tree
+            # (what `recursive_witness` assigns), in tree order.
+            import hashlib
+            from .circuit_cache import load_or_build
+
+            def build():
+                data, targets = recursive_circuit(commons, num_public_inputs)
+                data.witness_program(list(target_leaves(targets)))
+                return data, targets
+            data, targets, _ = load_or_build("recursion", hashlib.sha256(key.encode()).hexdigest(), build)
             rc = self._cache[key] = RecursiveCircuit(data, targets, data.prover(self.ctx, self.hasher), list(commons), self.inner_hasher)
         return rc
 

@@ -120,10 +120,15 @@ class PrimitiveProver:
         from .plonky2 import HASH_GL
         ent = self._cache.get(key)
         if ent is None:
-            data, t1, t2 = build()
-            data.witness_program(t1 + t2)
+            from .plonky2.circuit_cache import load_or_build
+
+            def build_():
+                data, t1, t2 = build()
+                data.witness_program(t1 + t2)
+                return data, {"t": t1 + t2}
+            data, aux, _ = load_or_build("primitive", key, build_)
             prover = data.prover(self.ctx, HASH_GL)
-            ent = self._cache[key] = (data, t1 + t2, prover, data.common_data(), prover.verifier_data())
+            ent = self._cache[key] = (data, aux["t"], prover, data.common_data(), prover.verifier_data())
         data, targets, prover, common, vd = ent
         wires, pis = data.generate_witness_native([dict(zip(targets, values))])
         return common, vd, prover.prove(wires[0], [int(x) for x in pis[0]])
