@@ -93,6 +93,8 @@ def simulate(prog, regs):
             R[ins[1]] = val(ins[3]) if FL[ins[4]] else val(ins[2])
         elif op == "sor":
             FL[ins[1]] = FL[ins[2]] | FL[ins[3]]
+        elif op == "sandn2":
+            FL[ins[1]] = FL[ins[2]] & (1 - FL[ins[3]])
         elif op == "nop":
             pass
         else:
@@ -169,12 +171,12 @@ def build_range4(n):
     outs = [("r%dl" % k, "r%dh" % k) for k in range(n)]
     x = [("x%dl" % k, "x%dh" % k) for k in range(n)]
     streams = [range4_stream(x[k], outs[k], TMP_PER_RANGE_STREAM * k, F(k), fd) for k in range(n)]
-    prog, nops = G.schedule(streams)
+    prog, nops = G.schedule(streams, pool=[F(k) for k in range(n, NF - 1)])      # temporaries of the reductions (G.reduce128)
     return prog, [r for o in outs for r in o], [r for v in x for r in v], nops
 
 
 def check_constant_bus(prog):
-    G.check_constant_bus([i for i in prog if i[0] != "sor"])
+    G.check_constant_bus([i for i in prog if i[0] not in ("sor", "sandn2")])
 
 
 def statement(name, prog, outs, ins, n_tmp, comment):
@@ -185,7 +187,7 @@ def statement(name, prog, outs, ins, n_tmp, comment):
     def tr(i):
         return tuple(idx.get(x, x) if isinstance(x, str) else x for x in i)
     lines = [emit(tr(i)) for i in prog]
-    clob = ["v%d" % (VB + i) for i in range(n_tmp)] + ["s%d" % i for i in range(FB, FB + 2 * NF)] + ["vcc"]
+    clob = ["v%d" % (VB + i) for i in range(n_tmp)] + ["s%d" % i for i in range(FB, FB + 2 * NF)] + ["vcc", "scc"]
     c = ["// %s" % comment, "ZKLC_D void %s(%s) {" % (name, ", ".join(["u32 &%s" % x for x in outs] + ["u32 %s" % x for x in ins])),
          "    asm volatile("]
     c += ['        "%s\\n\\t"' % ln for ln in lines]

@@ -74,18 +74,33 @@ def mulmod(a, b, out, sc, f, fl, fd):
     ] + reduce128(P0, P3, hi(P3), None, S, out, f, fl, fd)
 
 
+_XUID = [0]
+
+
+def xflag():
+    """a fresh TEMPORARY flag: written once, read once by an s_andn2; the scheduler binds it to a free flag pair of its pool at the
+    writer and releases the pair at the reader"""
+    _XUID[0] += 1
+    return "X%d" % _XUID[0]
+
+
 def reduce128(LO, w2, w3, w4, TP, out, f, fl, fd):
-    """out = {LO} + w2 * eps - {w4, w3}  (eps = 2^32 - 1; 2^64 = eps, 2^96 = -1, 2^128 = -2^32 mod p); TP: scratch pair"""
+    """out = {LO} + w2 * eps - {w4, w3}  (eps = 2^32 - 1; 2^64 = eps, 2^96 = -1, 2^128 = -2^32 mod p); TP: scratch pair.
+    Round 6: the two conditional corrections (a borrow means the wrapped value is eps too large, a carry that it is eps too small)
+    no longer build a 0 / -1 mask with v_cndmask: x - eps b = (x.lo + b, x.hi - (b & ~c)) with c the carry of the low add, and the
+    AND-NOT of the two flags is ONE s_andn2_b64 on the SCALAR unit -- seven VALU instructions instead of nine (the kernel is VALU
+    issue-bound; the scalar unit idles)."""
+    x1, x2 = xflag(), xflag()
     return [
         ("sub_co", LO, fl, LO, w3),
-        ("subb", hi(LO), fl, hi(LO), w4 if w4 is not None else 0, fl),
-        ("cnd", f, 0, -1, fl),                         # borrow: the wrapped value is 2^64 = eps too large
-        ("sub_co", LO, fl, LO, f),
-        ("subb", hi(LO), fd, hi(LO), 0, fl),
-        ("mad", TP, fl, w2, -1, LO),
-        ("cnd", f, 0, -1, fl),                         # carry: add eps back
-        ("add_co", out[0], fl, TP, f),
-        ("addc", out[1], fd, hi(TP), 0, fl),
+        ("subb", hi(LO), fl, hi(LO), w4 if w4 is not None else 0, fl),      # borrow b: wrapped by 2^64 = eps too large
+        ("addc", LO, x1, LO, 0, fl),                   # low word + b, carry c
+        ("sandn2", fl, fl, x1),                        # b & ~c
+        ("subb", hi(LO), fd, hi(LO), 0, fl),           # high word - (b & ~c): together - eps b
+        ("mad", TP, fl, w2, -1, LO),                   # carry c1: wrapped, eps too small
+        ("subb", out[0], x2, TP, 0, fl),               # low word - c1, borrow b2
+        ("sandn2", fl, fl, x2),                        # c1 & ~b2
+        ("addc", out[1], fd, hi(TP), 0, fl),           # high word + (c1 & ~b2): together + eps c1
     ]
 
 
@@ -108,6 +123,7 @@ def mds_row_stream(r, lo, hi_, out, base, rc, fl, fd):
     if r == 0:
         a_terms = a_terms + [(0, 8)]
     ins = []
+    x1 = xflag()
     for k, (j, c) in enumerate(a_terms):
         ins.append(("mad", Al, fd, lo[j], c, Al if k else None))
         ins.append(("mad", Ah, fd, hi_[j], c, Ah if k else None))
@@ -119,9 +135,9 @@ def mds_row_stream(r, lo, hi_, out, base, rc, fl, fd):
         ("add64", Al, Al, Bl),                         # sl < 2^42
         ("add64", Ah, Ah, Bh),                         # sh < 2^42; value = sl + sh 2^32
         ("mad", Al, fd, hi(Ah), -1, Al),               # sh.hi 2^64 = sh.hi eps: no carry (both < 2^42)
-        ("add_co", hi(Al), fl, hi(Al), Ah),            # + sh.lo 2^32
-        ("cnd", f, 0, -1, fl),
-        ("add_co", out[0], fl, Al, f),
+        ("add_co", hi(Al), fl, hi(Al), Ah),            # + sh.lo 2^32, carry c: + eps (as in reduce128)
+        ("subb", out[0], x1, Al, 0, fl),
+        ("sandn2", fl, fl, x1),
         ("addc", out[1], fd, hi(Al), 0, fl),
     ]
     return ins
@@ -199,19 +215,31 @@ def flags_read(ins):
         return [ins[5]]
     if op == "cnd":
         return [ins[4]]
+    if op == "sandn2":
+        return [ins[2], ins[3]]
     return []
 
 
 def flag_written(ins):
+    if ins[0] == "sandn2":
+        return ins[1]
     return ins[2] if ins[0] in ("mad", "add_co", "addc", "sub_co", "subb") else None
 
 
-def schedule(streams, prologue=(), priority=False):
+def bind_flags(ins, binding):
+    """the instruction with its temporary flags (xflag) replaced by the flag pairs they are bound to"""
+    return tuple(binding.get(x, x) if isinstance(x, str) and x[0] == "X" else x for x in ins)
+
+
+def schedule(streams, prologue=(), priority=False, pool=()):
     """greedy merge (round-robin, or always the first stream that can issue when priority=True: later streams are filler);
-    a flag reader is placed >= 3 slots after the flag's writer"""
+    a flag reader is placed >= 3 slots after the flag's writer.  `pool`: the flag pairs no stream owns; a temporary flag (xflag)
+    takes one of them when its writer is placed and gives it back when its reader (the s_andn2) is -- a writer that finds the pool
+    empty waits like a hazard."""
     out = list(prologue)
     pos = len(out)
     lastw, events = {}, set()
+    free, binding = list(pool), {}
     heads = [0] * len(streams)
     waited = False
     rr = nops = 0
@@ -240,7 +268,11 @@ def schedule(streams, prologue=(), priority=False):
             ins = streams[i][heads[i]]
             if ins[0] == "wait":
                 continue
-            if all(pos - lastw.get(f, -9) >= 3 for f in flags_read(ins)):
+            w_ = flag_written(ins)
+            if w_ is not None and w_[0] == "X" and w_ not in binding and not free:
+                assert binding, "schedule(): a temporary flag is needed and the pool is empty (pass pool=[...])"
+                continue                        # no flag pair free for its temporary: another stream goes first
+            if all(pos - lastw.get(binding.get(f, f), -9) >= 3 for f in flags_read(ins)):
                 chosen = i
                 break
         if chosen is None:
@@ -252,6 +284,13 @@ def schedule(streams, prologue=(), priority=False):
             pos += 1
             continue
         ins = streams[chosen][heads[chosen]]
+        w = flag_written(ins)
+        if w is not None and w[0] == "X" and w not in binding:
+            binding[w] = free.pop(0)
+        released = [f for f in flags_read(ins) if f[0] == "X"] if ins[0] == "sandn2" else []
+        ins = bind_flags(ins, binding)
+        for f in released:
+            free.append(binding.pop(f))
         out.append(ins)
         w = flag_written(ins)
         if w is not None:
@@ -267,6 +306,7 @@ def check_hazards(prog):
     for pos, ins in enumerate(prog):
         for f in flags_read(ins):
             assert pos - lastw.get(f, -9) >= 3, ("flag hazard", pos, ins)
+        assert not any(isinstance(x, str) and x[0] == "X" for x in ins), ("unbound temporary flag", ins)
         w = flag_written(ins) if ins[0] not in ("nop", "waitcnt", "sload", "smov") else None
         if w is not None:
             lastw[w] = pos
@@ -303,6 +343,8 @@ def simulate(prog, regs, consts=None):
             R[ins[1]] = v & M32
         elif op == "cnd":
             R[ins[1]] = val(ins[3]) if FL[ins[4]] else val(ins[2])
+        elif op == "sandn2":
+            FL[ins[1]] = FL[ins[2]] & (1 - FL[ins[3]])
         elif op == "add64":
             v = (val64(ins[2]) + val64(ins[3])) & (2**64 - 1)
             R[ins[1]], R[hi(ins[1])] = v & M32, v >> 32
@@ -348,6 +390,8 @@ def emit(ins, ptr_operand):
         return "v_subb_co_u32_e64 %s, %s, %s, %s, %s" % (ins[1], fmt_flag(ins[2]), fmt_src(ins[3]), fmt_src(ins[4]), fmt_flag(ins[5]))
     if op == "cnd":
         return "v_cndmask_b32_e64 %s, %s, %s, %s" % (ins[1], fmt_src(ins[2]), fmt_src(ins[3]), fmt_flag(ins[4]))
+    if op == "sandn2":
+        return "s_andn2_b64 %s, %s, %s" % (fmt_flag(ins[1]), fmt_flag(ins[2]), fmt_flag(ins[3]))
     if op == "add64":
         return "v_lshl_add_u64 %s, %s, 0, %s" % (fmt_pair(ins[1]), fmt_pair(ins[2]), fmt_pair(ins[3]))
     if op == "mov":
@@ -368,7 +412,7 @@ def emit(ins, ptr_operand):
 def check_constant_bus(prog):
     """a gfx9 VOP3 instruction may read ONE SGPR (pair) through the constant bus; a carry-in counts"""
     for ins in prog:
-        if ins[0] in ("nop", "waitcnt", "sload", "smov"):
+        if ins[0] in ("nop", "waitcnt", "sload", "smov", "sandn2"):
             continue
         srcs = [x for x in ins[3:] if isinstance(x, str)] if ins[0] != "cnd" else [x for x in ins[2:] if isinstance(x, str)]
         if ins[0] == "add64":
@@ -438,7 +482,7 @@ def build_fullround():
             st += mds_row_stream(r, lo, hi_, xs[r], 24 + 12 * m, (K(4 * r), K(4 * r + 2)), F(1 + m), fd)
         streams.append(st)
     prologue = [("sload", K(0), 16, 0), ("sload", K(16), 16, 64), ("sload", K(32), 16, 128)]
-    prog, nops = schedule(streams, prologue)
+    prog, nops = schedule(streams, prologue, pool=[F(4), F(5), F(6), F(7)])
     return prog, [r for x in xs for r in x], nops
 
 
@@ -476,7 +520,7 @@ def build_fullround_init(cs):
         for t, r in enumerate(rows):
             folds[t] += [("wait", "m%d" % g)] + fold3(accs[t], T(48 + 4 * t), T(50 + 4 * t), xs[r], F(1 + t), fd) + [("signal", "f%d_%d" % (g, t))]
     D.finish(even_groups=False)
-    prog, nops = schedule(streams + [D.ins] + folds, STMT_PRE + prefetch0())
+    prog, nops = schedule(streams + [D.ins] + folds, STMT_PRE + prefetch0(), pool=[F(5), F(6), F(7)])
     return prog, [r for x in xs for r in x], nops, D.table + [0] * 24
 
 
@@ -524,7 +568,7 @@ def build_partial_block(cs, b):
         for t, j in enumerate(js):
             folds[t] += [("wait", "mat%d" % g)] + fold3(accs[t], T(46 + 4 * t), T(48 + 4 * t), u[j], F(2 + t), fd) + [("signal", "mf%d_%d" % (g, t))]
     n_groups = D.finish(even_groups=True)
-    prog, nops = schedule([chain, D.ins] + folds, priority=True)
+    prog, nops = schedule([chain, D.ins] + folds, priority=True, pool=[F(6), F(7)])
     return prog, list(s0) + [r for x in u for r in x], nops, D.table, n_groups
 
 
@@ -708,11 +752,87 @@ def render(consts=None, tables=None):
 INC_PATH = os.path.join(ROOT, "zk-light-client-implementation_amd", "csrc", "poseidon_gl_asm.inc")
 
 
+def budget(consts):
+    """Lane-instructions of ONE permutation by component, against a stated floor.  Counted on the very
+    instruction lists the statements are emitted from.  Issue classes from profiles/r05a_valu_ubench_warm_sclk.txt: every
+    instruction of these lists except v_mov is of the 4-cycle class (v_mad_u64_u32, carry adds / subtracts, v_cndmask with an SGPR
+    mask, v_lshl_add_u64), so the count IS the issue time."""
+    fd = F(0)
+    x, y = ("xl", "xh"), (T(0), T(1))
+    valu = lambda lst: sum(1 for i in lst if i[0] not in ("sandn2", "needconst"))
+    n_mul = valu(mulmod(x, x, y, (T(4), T(6), T(8)), T(10), F(1), fd))
+    n_red = valu(reduce128(T(4), T(8), T(9), None, T(6), y, T(10), F(1), fd))
+    n_sbox = valu(sbox_stream(x, 22, F(1), fd, out=y))
+    lo, hi_ = [T(2 * i) for i in range(12)], [T(2 * i + 1) for i in range(12)]
+    n_rows = [valu(mds_row_stream(r, lo, hi_, x, 24, (K(0), K(2)), F(1), fd)) for r in range(12)]
+    n_fold = valu(fold3((T(34), T(36), T(38)), T(46), T(32), x, F(1), fd))
+    prog_f, _, nop_f = build_fullround()
+    prog_i, _, nop_i, _ = build_fullround_init(consts)
+    prog_p, _, nop_p, _, _ = build_partial_block(consts, 0)
+    count = lambda prog, ops: sum(1 for i in prog if i[0] in ops)
+    sc = ("sload", "waitcnt", "smov", "nop", "sandn2")
+    rows = []
+    full_sbox = 8 * 12 * n_sbox
+    full_mds = 7 * sum(n_rows)
+    init_dense = len(prog_i) - 12 * n_sbox - count(prog_i, sc)
+    part_sbox = 22 * n_sbox
+    part_fold = 22 * (n_fold + 2) + 22 * n_fold              # per round: 25 z + K (2 mads) and the fold; per block: 11 words folded
+    part_scalar = 2 * count(prog_p, sc)
+    part_lin = 2 * len(prog_p) - part_sbox - part_fold - part_scalar
+    scalar = 7 * count(prog_f, sc) + count(prog_i, sc) + part_scalar
+    total = 7 * len(prog_f) + len(prog_i) + 2 * len(prog_p)
+    # floor: 4 v_mad_u64_u32 + 2 carry adds per 64 x 64 product and 8 instructions per reduction (VERDICT r05), a mad per MDS term
+    # (12 x 12 x 2 halves) + 4 to fold a row, 6 mads per product with a 64-bit table constant (22-bit limbs, carry-free), 3 per
+    # constant, 14 per fold of three columns
+    f_mul = 4 + 2 + 8
+    f_sbox = 4 * f_mul
+    f_row = 24 + 4
+    lazy_macs = 2 * (sum(11 + q for q in range(11)) + 11 * 11)
+    floor = {"sbox_full": 96 * f_sbox, "mds_full": 7 * 12 * f_row, "init": 144 * 6 + 12 * 3 + 12 * 14, "sbox_part": 22 * f_sbox,
+             "lin_part": lazy_macs * 6 + 44 * 3 + 44, "fold_part": 44 * 14 + 44}
+    out = ["Poseidon-Goldilocks permutation on gfx950: lane-instructions by component (tools/gen_poseidon_asm.py --budget)",
+           "VALU: mulmod %d instructions (4 v_mad_u64_u32 + 4 carry adds + %d reduction), x^7 = 4 mulmod = %d, MDS row %s, 3-column fold %d" %
+           (n_mul, n_red, n_sbox, sorted(set(n_rows)), n_fold), "",
+           "%-58s %8s %7s %8s" % ("component", "emitted", "share", "floor")]
+    n_andn2 = 7 * count(prog_f, ("sandn2",)) + count(prog_i, ("sandn2",)) + 2 * count(prog_p, ("sandn2",))
+    comp = [("S-boxes of the 8 full rounds (96 x x^7)", full_sbox, floor["sbox_full"]),
+            ("MDS + next constants of 7 full rounds (84 rows)", full_mds, floor["mds_full"]),
+            ("4th full round's MDS merged with the 11x11 initial matrix", init_dense, floor["init"]),
+            ("S-boxes of the 22 partial rounds", part_sbox, floor["sbox_part"]),
+            ("partial rounds, lazy linear layer (dot products + materialisation)", part_lin - 0, floor["lin_part"]),
+            ("partial rounds, 25 z + K and the column folds", part_fold, floor["fold_part"]),
+            ("scalar unit: constant fetches, waits, s_nop, %d s_andn2" % n_andn2, scalar, 0)]
+    for name, n, fl in comp:
+        out.append("%-58s %8d %6.1f%% %8s" % (name[:58], n, 100.0 * n / total, fl if fl else "-"))
+    fsum = sum(fl for _, _, fl in comp)
+    out += ["%-58s %8d %6.1f%% %8d" % ("total (statements; + first constant layer / canonicalisation)", total, 100.0, fsum), "",
+            "floor model: 64 x 64 product = 4 mad + 2 carry adds, reduction = 8, MDS term = 1 mad per 32-bit half, fold of an MDS row = 4,",
+            "constant product = 6 mads (22-bit limbs), fold of three columns = 14.  VALU emitted / floor = %.3f." % ((total - scalar) / fsum),
+            "Round 6: the conditional +-eps corrections of every reduction use the scalar unit (x - eps b = (lo + b, hi - (b & ~c)): one",
+            "s_andn2_b64 of two carry flags replaces a v_cndmask and folds an add): reduction 9 -> 7 VALU, mulmod 17 -> %d, MDS row 31 -> %d," % (n_mul, min(n_rows)),
+            "fold 16 -> %d; VALU instructions per permutation %d (round 5: 16 223), %d s_nop in hazard slots the scheduler could not fill." %
+            (n_fold, total - scalar, 7 * nop_f + nop_i + 2 * nop_p), "",
+            "FFT-structured MDS (plonky2 `mds_multiply_freq`), costed on this ISA instead of built:",
+            "  per 12-vector of 32-bit halves: 3 x fft4 (18 add/sub) + blocks (9 + 27 + 9 = 45 multiplications, ~57 add/sub) + 3 x ifft4 (~30",
+            "  add/sub, shifts) = 45 mult + ~105 add/sub; two halves -> 90 mult + 210 add/sub.  The intermediate values exceed 32 bits (35-42),",
+            "  so every add/sub is a 64-bit operation: v_lshl_add_u64 (1 instruction, 4-cycle class) for sums, v_sub_co + v_subb (2) for",
+            "  differences -> ~90 + 105 + 2 x 105 = ~405 issue slots + the same 12 x 4 row folds, against 288 mads + 84 today (%d): the" % sum(n_rows),
+            "  multiply-accumulate is ONE issue slot here and the MDS entries are 6-bit, so trading multiplications for additions loses.",
+            "  (v_add3_u32 / v_mad_u32_u24 / v_alignbit are all in the same 4.3-cycle class as v_mad_u64_u32: no cheaper 3-operand form exists.)",
+            "  Halving the circulant over x^12 - 1 = (x^6 - 1)(x^6 + 1) (the half-sums and half-differences of the MDS row are integers)",
+            "  needs 33-bit operands for the 32 x 32 multiplier or 22-bit limbs (3 x 72 mads + 36 single-pass adds + recombination ~ 120):",
+            "  ~350 against 372.  Not built: within the noise of the scheduler's slack, and it lengthens the dependent chain of a round."]
+    return "\n".join(out) + "\n"
+
+
 def main():
     consts, tables = load_constants()
     selftest(consts, tables)
     if "--check" in sys.argv:
         print("gen_poseidon_asm: simulator self-test OK")
+        return
+    if "--budget" in sys.argv:
+        print(budget(consts), end="")
         return
     text, stats, total = render(consts, tables)
     if os.path.exists(INC_PATH) and open(INC_PATH).read() == text:

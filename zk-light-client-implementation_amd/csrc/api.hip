@@ -7,7 +7,7 @@ int32_t zklc_stage(zklc_ctx *ctx, int slot, size_t bytes, void **out) {
     zklc_devbuf &b = ctx->stage[slot];
     if (b.cap < bytes) {
         if (b.p) {
-            ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
             ZKLC_HIP(ctx, hipFree(b.p));
             b.p = nullptr;
             b.cap = 0;
@@ -122,6 +122,6 @@ extern "C" int32_t zklc_device_copy(zklc_ctx *ctx, void *dst, const void *src, u
 extern "C" int32_t zklc_synchronize(zklc_ctx *ctx) {
     if (!ctx) return ZKLC_ERR_INVALID_ARG;
     ZKLC_HIP(ctx, hipSetDevice(ctx->device));
-    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }

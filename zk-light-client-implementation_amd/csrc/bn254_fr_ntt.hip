@@ -164,7 +164,7 @@ static int32_t frn_tables(zklc_ctx *ctx, hipStream_t st, const frn_plan &p, bool
         hipLaunchKernelGGL(frn_table_entries_kernel, dim3((ne + 255) / 256), dim3(256), 0, st, (i32 *)fresh, p);
         ZKLC_HIP(ctx, hipGetLastError());
         // other streams of this context may use the block right after this call returns
-        ZKLC_HIP(ctx, hipStreamSynchronize(st));
+        ZKLC_HIP(ctx, zklc_stream_wait(st));
         slot = fresh;
     }
     *out = (const i32 *)slot;
@@ -254,6 +254,6 @@ extern "C" int32_t zklc_bn254_fr_ntt(zklc_ctx *ctx, uint64_t *data, uint32_t log
     ZKLC_HIP(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = zklc_bn254_fr_ntt_dev(ctx, ctx->stream, (uint64_t *)d, log_n, flags, coset, w, wb))) return rc;
     ZKLC_HIP(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }

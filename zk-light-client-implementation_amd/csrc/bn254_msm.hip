@@ -637,7 +637,7 @@ static int32_t msm_run_host(zklc_ctx *ctx, const uint64_t *points, const uint64_
     if (rc) return rc;
     ZKLC_HIP(ctx, hipMemcpyAsync(out_affine, dout, PB, hipMemcpyDeviceToHost, ctx->stream));
     ZKLC_HIP(ctx, hipMemcpyAsync(out_is_infinity, (char *)dout + PB, 4, hipMemcpyDeviceToHost, ctx->stream));
-    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }
 

@@ -123,6 +123,6 @@ extern "C" int32_t zklc_bn254_pairing_check(zklc_ctx *ctx, const uint64_t *g1, c
         return rc;
     ZKLC_HIP(ctx, hipMemcpyAsync(is_one, dr, (size_t)batch * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (gt_out) ZKLC_HIP(ctx, hipMemcpyAsync(gt_out, dg, (size_t)batch * 384, hipMemcpyDeviceToHost, ctx->stream));
-    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }

@@ -36,7 +36,7 @@ int32_t zklc_ed25519_init(zklc_ctx *ctx) {
     ZKLC_HIP(ctx, hipMalloc(&ctx->ed_btab, sizeof(ge_niels) * ZKLC_ED_BTABLE));
     hipLaunchKernelGGL(ed25519_base_table_kernel, dim3(1), dim3(128), 0, ctx->stream, (ge_niels *)ctx->ed_btab);
     ZKLC_HIP(ctx, hipGetLastError());
-    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }
 
@@ -80,7 +80,7 @@ extern "C" int32_t zklc_ed25519_verify_batch(zklc_ctx *ctx, const uint8_t *pks, 
                                        msg_len, msg_stride, n, (uint8_t *)dok);
     if (rc) return rc;
     ZKLC_HIP(ctx, hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, ctx->stream));
-    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }
 
@@ -112,6 +112,6 @@ extern "C" int32_t zklc_sha512_batch(zklc_ctx *ctx, const uint8_t *in, uint32_t 
     rc = zklc_sha512_batch_dev(ctx, ctx->stream, (const uint8_t *)din, stride, len, n, (uint8_t *)dout);
     if (rc) return rc;
     ZKLC_HIP(ctx, hipMemcpyAsync(out, dout, (size_t)n * 64, hipMemcpyDeviceToHost, ctx->stream));
-    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }

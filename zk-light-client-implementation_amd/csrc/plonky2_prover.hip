@@ -1050,12 +1050,23 @@ struct zklc_plonky2_circuit {
 // through this per-circuit page-locked arena, hipMemcpyAsync returns at once, and the thread sleeps in zklc_stream_wait -- blocking
 // waits by construction, no device-wide flag (the hipSetDeviceFlags option of round 5 is gone).  The arena is reset at the start of
 // a proof (a circuit proves one witness at a time) and grows by whole blocks, so pointers handed out stay valid until the next proof.
+static bool p2_pin_enabled() {
+    static const bool on = !(getenv("ZKLC_PINNED_STAGING") && getenv("ZKLC_PINNED_STAGING")[0] == '0');      // A/B switch
+    return on;
+}
+static void p2_pin_free(void *q) {
+    if (p2_pin_enabled()) (void)hipHostFree(q);
+    else free(q);
+}
 static void *p2_pin(zklc_plonky2_circuit *c, size_t bytes) {
     bytes = (bytes + 63) & ~(size_t)63;
     if (c->pin_blocks.empty() || c->pin_used + bytes > c->pin_blocks.back().second) {
         size_t cap = bytes > (1u << 20) ? bytes : (1u << 20);
         void *q = nullptr;
-        if (hipHostMalloc(&q, cap, hipHostMallocDefault) != hipSuccess) {
+        if (!p2_pin_enabled()) {
+            q = malloc(cap);                                   // A/B: pageable staging, as rounds 1-5
+            if (!q) return nullptr;
+        } else if (hipHostMalloc(&q, cap, hipHostMallocDefault) != hipSuccess) {
             (void)hipGetLastError();
             return nullptr;
         }
@@ -1072,11 +1083,13 @@ static void p2_pin_reset(zklc_plonky2_circuit *c) {
         size_t total = 0;
         for (auto &b : c->pin_blocks) {
             total += b.second;
-            (void)hipHostFree(b.first);
+            p2_pin_free(b.first);
         }
         c->pin_blocks.clear();
         void *q = nullptr;
-        if (hipHostMalloc(&q, total, hipHostMallocDefault) == hipSuccess) c->pin_blocks.push_back({(uint8_t *)q, total});
+        if (!p2_pin_enabled()) {
+            if ((q = malloc(total))) c->pin_blocks.push_back({(uint8_t *)q, total});
+        } else if (hipHostMalloc(&q, total, hipHostMallocDefault) == hipSuccess) c->pin_blocks.push_back({(uint8_t *)q, total});
         else (void)hipGetLastError();
     }
     c->pin_used = 0;
@@ -1274,7 +1287,7 @@ extern "C" void zklc_plonky2_circuit_destroy(zklc_plonky2_circuit *c) {
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (void *p : c->allocs) (void)hipFree(p);
-    for (auto &b : c->pin_blocks) (void)hipHostFree(b.first);
+    for (auto &b : c->pin_blocks) p2_pin_free(b.first);
     delete c;
 }
 

@@ -141,7 +141,7 @@ extern "C" int32_t zklc_poseidon_bn254_permute(zklc_ctx *ctx, uint64_t *states, 
     ZKLC_HIP(ctx, hipMemcpyAsync(d, states, bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = zklc_poseidon_bn254_permute_dev(ctx, ctx->stream, (uint64_t *)d, n))) return rc;
     ZKLC_HIP(ctx, hipMemcpyAsync(states, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }
 
@@ -200,6 +200,6 @@ extern "C" int32_t zklc_bn254_merkle_commit(zklc_ctx *ctx, const uint64_t *mat, 
     if ((rc = zklc_bn254_merkle_commit_dev(ctx, ctx->stream, (const uint64_t *)dm, stride, log_leaves, width, cap_height, (uint64_t *)dt)))
         return rc;
     ZKLC_HIP(ctx, hipMemcpyAsync(tree_out, dt, tree_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ZKLC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }

@@ -55,10 +55,31 @@ struct zklc_ctx {
         }                                                             \
     } while (0)
 
-// hipStreamSynchronize spins on the host by default; a proof synchronises ~10 times and a rank keeps several proving threads
-// (and a node several ranks) in flight, so the waits go through an event created with hipEventBlockingSync: the thread sleeps
-// until the stream reaches the event
+// Waiting for a stream (every host wait of the library goes through here).
+// Measured on this runtime (profiles/r06b_host_cpu_probe.txt, r05d): hipStreamSynchronize spins, and hipEventSynchronize on an event
+// created with hipEventBlockingSync spins as well -- a proving thread sat at 1.00 host cores whatever the event's flags, also after
+// every transfer had been moved to page-locked staging; only the DEVICE-wide hipDeviceScheduleBlockingSync made the runtime sleep
+// (round 5's opt-in, removed: a library must not flip a device-wide mode under its caller).  Round 6 therefore does the waiting
+// itself: record an event, query it for ~30 us (the waits inside a small proof end within that), then sleep between queries --
+// 20 us growing to 200 us, the thread's timer slack set to 1 us so that the sleeps are what they say.  The thread is asleep for all
+// but a few microseconds per query; the price is at most one sleep interval of latency per wait.
+//   ZKLC_WAIT=poll (default) | event (hipEventSynchronize on a blocking-sync event) | spin (hipStreamSynchronize)      [A/B]
+#include <stdlib.h>
+#include <string.h>
+#include <sys/prctl.h>
+#include <time.h>
+inline int zklc_wait_mode() {
+    static const int mode = [] {
+        const char *e = getenv("ZKLC_WAIT");
+        if (e && !strcmp(e, "spin")) return 0;
+        if (e && !strcmp(e, "event")) return 1;
+        return 2;
+    }();
+    return mode;
+}
 inline hipError_t zklc_stream_wait(hipStream_t st) {
+    const int mode = zklc_wait_mode();
+    if (mode == 0) return hipStreamSynchronize(st);
     static thread_local hipEvent_t ev = nullptr;
     static thread_local int ev_dev = -1;
     int dev = -1;
@@ -70,10 +91,28 @@ inline hipError_t zklc_stream_wait(hipStream_t st) {
         e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
         if (e != hipSuccess) return e;
         ev_dev = dev;
+        (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);      // this thread's nanosleep wakes within ~1 us of its deadline
     }
     e = hipEventRecord(ev, st);
     if (e != hipSuccess) return e;
-    return hipEventSynchronize(ev);
+    if (mode == 1) return hipEventSynchronize(ev);
+    auto now_ns = [] {
+        timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        return (long long)t.tv_sec * 1000000000LL + t.tv_nsec;
+    };
+    const long long t0 = now_ns();
+    long sleep_ns = 20000;
+    for (;;) {
+        e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) break;
+        if (now_ns() - t0 < 30000) continue;                    // short waits: stay on the core
+        timespec ts = {0, sleep_ns};
+        nanosleep(&ts, nullptr);
+        if (sleep_ns < 200000) sleep_ns += sleep_ns / 2;
+    }
+    (void)hipGetLastError();                                    // hipErrorNotReady of the queries is not an error of the caller's
+    return e;
 }
 
 // returns a device buffer of at least `bytes` in slot `slot`
