@@ -379,7 +379,9 @@ int32_t zklc_bn254_g2_msm_fixed_dev(zklc_ctx *ctx, void *stream, const void *d_t
  * points (16 u64 each), gnark-crypto memory layout (Montgomery); an all-zero point is the point at infinity.
  * gt_out (optional, may be NULL): the reduced pairing product of every check, 12 Fp coefficients in gnark-crypto's E12 order
  * (C0.B0.A0, C0.B0.A1, C0.B1.A0, ... C1.B2.A1), 48 u64 per check, exact exponent (p^12 - 1)/r.  Points must be on their
- * curves and in the r-torsion subgroups (as the precompile requires); this is not checked. */
+ * curves and in the r-torsion subgroups (as the precompile requires); this is NOT checked -- the same contract as gnark-crypto's
+ * `bn254.PairingCheck`, whose caller `groth16.Verify` validates the proof's points itself (`proof.isValid()`, unchanged Go code
+ * above a cgo shim); INTEGRATION.md states the precondition at the call site. */
 int32_t zklc_bn254_pairing_check(zklc_ctx *ctx, const uint64_t *g1, const uint64_t *g2, uint32_t k, uint32_t batch,
                                  uint32_t *is_one, uint64_t *gt_out);
 int32_t zklc_bn254_pairing_check_dev(zklc_ctx *ctx, void *stream, const uint64_t *d_g1, const uint64_t *d_g2, uint32_t k,
