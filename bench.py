@@ -31,6 +31,7 @@ import json
 import os
 import sys
 import time
+T_PROCESS_START = time.perf_counter()
 
 import numpy as np
 
@@ -718,6 +719,9 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         except Exception as e:
             out[ed_name]["cpu_baseline_error"] = repr(e)[:300]
     del wn
+    # the host interpreter keeps one value array per slot and thread (26 M slots x 12 bytes x 3 threads for this circuit): the
+    # blocks below generate the Ed25519 witnesses on the GPU, so the cache goes back to the allocator
+    zklc_amd._lib.load().zklc_plonky2_witness_release()
 
     # ---- a7: `recursive_proof` (prove_crypto/recursion.rs:16-97).  The fold of signatures.rs:97-105 uses two circuit shapes --
     # R(ed, ed) for the first step, R(R, ed) for every later one (its common data is a fixed point) -- the closing proof carries
@@ -808,6 +812,11 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     # the permanent generation, so that later collections only look at what a block allocates.
     import gc
     gc.collect()
+    try:                                   # what the builders and the per-circuit stages freed goes back to the OS, not only to the heap
+        import ctypes
+        ctypes.CDLL("libc.so.6").malloc_trim(0)
+    except (OSError, AttributeError):
+        pass
     gc.freeze()
     for _ in range(max(0, args.warmup - 1)):
         pipe.prove_block_bft(window)
@@ -919,6 +928,8 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
             # the closing proof with sha256(valid_keys), through BlockPipeline.prove_approvals (one rank = one GPU)
             from oracle import ed25519_ref as ref
             nv = int(args.c5_validators)
+            if nv < 0:
+                nv = 1000 if time.perf_counter() - T_PROCESS_START < args.c5_budget_s else 200
             c2_msg = window.approval_sets()[0][0]
             keys = [ref.synthetic_seed(1, i) for i in range(nv)]
             vals5 = [b"\x04\x00\x00\x00test\x00" + ref.keypair(k_)[2] + (10**30 + i).to_bytes(16, "little") for i, k_ in enumerate(keys)]
@@ -1070,9 +1081,12 @@ def main():
                     "a block's tail with the next block's signature proofs)")
     ap.add_argument("--no-strong-section", action="store_true", help="multi-GPU runs: skip the extra strong-scaling blocks after the weak region")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo lets several ranks share one GPU)")
-    ap.add_argument("--c5-validators", type=int, default=200, help="the C5 stage: a synthetic epoch of this many validators through "
-                    "BlockPipeline.prove_approvals (default 200: ~13 s on one MI355X; 1000 = BASELINE configs[4], ~63 s; 0 skips it), "
-                    "reported under stages.prove.c5_synthetic_epoch")
+    ap.add_argument("--c5-validators", type=int, default=-1, help="the C5 stage: a synthetic epoch of this many validators through "
+                    "BlockPipeline.prove_approvals, reported under stages.prove.c5_synthetic_epoch (1000 = BASELINE configs[4], ~63 s; "
+                    "200: ~13 s; 0 skips it).  Default -1 = automatic: 1000 when the run is younger than --c5-budget-s seconds at that "
+                    "point, else 200 -- the line says which (c5.validators)")
+    ap.add_argument("--c5-budget-s", type=float, default=330.0, help="with --c5-validators -1: run BASELINE's 1000 validators only if "
+                    "fewer than this many seconds have passed since the process started (the driver's command has spent ~280 s by then)")
     ap.add_argument("--extra-stages", action="store_true", help="also time the fixed-base form of the 2^22 G1 multi-exponentiation (table of "
                     "the bases built once; 4.3 GB) and the coset LDE at the Ed25519 circuit's shape 234 x (2^18 -> 2^21); both have "
                     "their own profiles under profiles/ (r05g_msm_fixed_base_*, r05a_lde_*)")

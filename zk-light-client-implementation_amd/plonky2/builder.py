@@ -1147,6 +1147,7 @@ class DeviceWitness:
         h = ctypes.c_void_p()
         if data._container is not None:      # loaded from a circuit container: the library reads the program's sections itself
             rc = self._lib.zklc_plonky2_witness_program_create_from_container(ctx._h, data._container._h, ctypes.byref(h))
+            data._container.release_pages()      # program tables uploaded: the mapping stays valid, its pages are given back
         else:
             rc = self._lib.zklc_plonky2_witness_program_create(
                 ctx._h, pr["code"].ctypes.data, len(pr["code"]), pr["params"].ctypes.data, len(pr["params"]), pr["n_slots"],

@@ -48,6 +48,7 @@ class Prover:
         if data._container is not None:
             # a circuit loaded from a container file: the library takes parameters, gates and matrices from the file's sections
             rc = self._lib.zklc_plonky2_circuit_create_from_container(ctx._h, data._container._h, int(hasher), ctypes.byref(h))
+            data._container.release_pages()      # the matrices are in HBM now: the mapped pages go back to the page cache (RSS)
         else:
             from .container import native_arguments
             p, gates, ex, kis = native_arguments(data, hasher)
