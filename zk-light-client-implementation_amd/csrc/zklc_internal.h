@@ -60,8 +60,8 @@ struct zklc_ctx {
 // created with hipEventBlockingSync spins as well -- a proving thread sat at 1.00 host cores whatever the event's flags, also after
 // every transfer had been moved to page-locked staging; only the DEVICE-wide hipDeviceScheduleBlockingSync made the runtime sleep
 // (round 5's opt-in, removed: a library must not flip a device-wide mode under its caller).  Round 6 therefore does the waiting
-// itself: record an event, query it for ~30 us (the waits inside a small proof end within that), then sleep between queries --
-// 20 us growing to 200 us, the thread's timer slack set to 1 us so that the sleeps are what they say.  The thread is asleep for all
+// itself: record an event, query it for ~20 us (the waits inside a small proof end within that), then sleep between queries --
+// 10 us growing to 60 us, the thread's timer slack set to 1 us so that the sleeps are what they say.  The thread is asleep for all
 // but a few microseconds per query; the price is at most one sleep interval of latency per wait.
 //   ZKLC_WAIT=poll (default) | event (hipEventSynchronize on a blocking-sync event) | spin (hipStreamSynchronize)      [A/B]
 #include <stdlib.h>
@@ -102,14 +102,14 @@ inline hipError_t zklc_stream_wait(hipStream_t st) {
         return (long long)t.tv_sec * 1000000000LL + t.tv_nsec;
     };
     const long long t0 = now_ns();
-    long sleep_ns = 20000;
+    long sleep_ns = 10000;
     for (;;) {
         e = hipEventQuery(ev);
         if (e != hipErrorNotReady) break;
-        if (now_ns() - t0 < 30000) continue;                    // short waits: stay on the core
+        if (now_ns() - t0 < 20000) continue;                    // short waits: stay on the core
         timespec ts = {0, sleep_ns};
         nanosleep(&ts, nullptr);
-        if (sleep_ns < 200000) sleep_ns += sleep_ns / 2;
+        if (sleep_ns < 60000) sleep_ns += sleep_ns / 2;          // 10 -> 60 us: r06c measured +185 us per wait with a 200 us cap
     }
     (void)hipGetLastError();                                    // hipErrorNotReady of the queries is not an error of the caller's
     return e;

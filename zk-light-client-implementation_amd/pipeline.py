@@ -543,6 +543,7 @@ class BlockPipeline:
         completes beside it.  The fold / DAG stages of consecutive blocks share their provers, so they run one after the other.
         Returns the BlockResults in order; `on_block_done(result)` is called as each block completes."""
         results, prev_dag, prev_st = [], [], None
+        prev_fold, prev_ks = [], []
         for window in windows:
             st = self._new_state(window.approval_sets(), False)
             try:
@@ -550,13 +551,23 @@ class BlockPipeline:
             except Exception:
                 self._join(prev_dag)
                 raise
-            self._join(prev_dag)                  # block b - 1 must be finished before block b's fold / DAG stage takes the provers
+            # Round 6: the fold thread and the keys / stakes thread of block b are chained to THEIR predecessors only (they own their
+            # provers: self.rp on fold_ctx, ks_prover on ks_ctx) and start with the signature stage -- the fold consumes the Ed25519
+            # proofs as they arrive.  Before, the whole fold / DAG stage of block b waited for the whole stage of block b - 1 (its
+            # joins and the wrap included): a fold that starts ~1 s late has a backlog of signature proofs to work through one
+            # dependent step at a time, ends late, delays the next block's stage further -- latencies of 9-12 s and a GPU at 87 %
+            # once the faster leaf hash had made the serial chain the longer path (profiles/r06c_*).
+            fold = self._start([(self._after, (prev_fold, self._fold_worker, (st,)))])
+            ks = self._start([(self._after, (prev_ks, self._ks_worker, (st,)))])
+            self._join(prev_dag)                  # the DAG thread of block b - 1 (the stub's futures, the block prover's counters)
             if prev_st is not None:
                 self._raise(prev_st)
                 results.append(prev_st["res"])
                 if on_block_done:
                     on_block_done(prev_st["res"])
-            prev_dag, prev_st = self._start_dag_stage(st, window), st
+            self._begin_dag_stage(st)
+            prev_dag = self._start([(self._dag_worker, (st, window, {}))]) + fold + ks
+            prev_fold, prev_ks, prev_st = fold, ks, st
             self._join(sig)
         self._join(prev_dag)
         if prev_st is not None:
@@ -566,6 +577,11 @@ class BlockPipeline:
                 on_block_done(prev_st["res"])
             self.last = prev_st["res"]
         return results
+
+    def _after(self, earlier, fn, args):
+        """run fn(*args) once the threads `earlier` (the same worker of the previous block) have ended"""
+        self._join(earlier)
+        fn(*args)
 
     def prove_approvals(self, msg, approvals, validators):
         """`prove_approvals` (signatures.rs:43-141) alone through the pipeline's signature stage and fold thread:
