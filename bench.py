@@ -843,6 +843,14 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
         # the timed region in every clock a profiler may stamp kernels with: tools/block_accounting.py picks the one the trace uses
         return {n: time.clock_gettime_ns(getattr(time, c)) for n, c in (("monotonic", "CLOCK_MONOTONIC"), ("boottime", "CLOCK_BOOTTIME"),
                                                                        ("realtime", "CLOCK_REALTIME"), ("monotonic_raw", "CLOCK_MONOTONIC_RAW"))}
+    def host_load():
+        # is the HOST ours?  (the GPU boxes share their CPUs between tenants: a loaded host shows up as block-time noise)
+        try:
+            la = open("/proc/loadavg").read().split()[:3]
+            return {"loadavg": [float(x) for x in la], "cpus_allowed": len(os.sched_getaffinity(0)), "cpus_online": os.cpu_count()}
+        except (OSError, ValueError):
+            return {}
+    load0 = host_load()
     clk0 = clocks_ns()
     cpu_all = time.process_time()
     t_all = time.perf_counter()
@@ -901,7 +909,8 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                       "first_block_s_incl_circuit_construction": t_setup,
                       "host_cpu_s_per_block": cpu_all / steps, "host_cores_busy": cpu_all / max(total_s, 1e-9),
                       "peak_rss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0,
-                      "timed_region_clock_ns": {k: [clk0[k], clk1[k]] for k in clk0}}
+                      "timed_region_clock_ns": {k: [clk0[k], clk1[k]] for k in clk0},
+                      "host_load_before": load0, "host_load_after": host_load()}
     if world > 1 and not strong_only and not args.no_strong_section:
         # the STRONG form of the block measured in the same run, so that one SCALE run holds both: all ranks prove
         # ONE block per step (signature shards, local folds, a binary-tree fold over the ranks, the header proofs on the other ranks,
