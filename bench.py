@@ -805,7 +805,14 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     want = window.expected_public_inputs()[0]
     n_sig = sum(1 for a in window.blocks[3][0]["approvals"] if len(a) == 66)
     barrier()
-    pipe.prove_block_bft(window)           # builds and uploads the circuits of every shape of the DAG (host Python, one-time)
+    strong_only = args.scaling == "strong" and world > 1
+    overlap = not strong_only and not args.no_block_overlap
+    # builds (or loads) and uploads the circuits of every shape of the DAG (host Python, one-time); through the SAME entry point the
+    # timed blocks use, so that everything it creates lazily (the header thread's context and provers) exists before the clock starts
+    if overlap:
+        pipe.prove_stream([window])
+    else:
+        pipe.prove_block_bft(window)
     t_setup = time.perf_counter() - t_setup
     # The circuits are tens of millions of long-lived Python objects: a full generational collection walks all of them and stalled
     # ONE block in ~15 by 15 s (round 2).  Standard remedy for a long-running service: collect once, then move everything alive to
@@ -818,8 +825,11 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     except (OSError, AttributeError):
         pass
     gc.freeze()
-    for _ in range(max(0, args.warmup - 1)):
-        pipe.prove_block_bft(window)
+    if overlap and args.warmup > 1:
+        pipe.prove_stream([window] * (args.warmup - 1))
+    else:
+        for _ in range(max(0, args.warmup - 1)):
+            pipe.prove_block_bft(window, strong=strong_only)
     barrier()
     tele = GpuTelemetry(pci=GpuTelemetry.own_pci())
     if not tele.cards:                       # sysfs does not know the address torch reports: fall back to the busiest card
@@ -828,8 +838,6 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     tele.mark()
     rss0 = rss_mb()
     steps = max(1, args.steps)
-    strong_only = args.scaling == "strong" and world > 1
-    overlap = not strong_only and not args.no_block_overlap
 
     def digests(r):
         return (hashlib.sha256(r.wrap[1]).hexdigest(), hashlib.sha256(json.dumps(r.block[2], sort_keys=True).encode()).hexdigest())
@@ -898,7 +906,7 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                       "per_step_s": per_step_s, "latency_s": [round(r.t_done - r.t0, 4) for r in res_list],
                       "telemetry_mean": tele_all, "per_step_telemetry": tele_steps, "rss_mb_before": rss0, "rss_mb_after": rss_mb(),
                       "blocks_overlapped": overlap, "keys_stakes_cache_hits": pipe.ks_prover.cache_hits,
-                      "seconds_until_signature_aggregate": lastr.t_signatures - lastr.t0, "streams": pipe.nthreads + 2,
+                      "seconds_until_signature_aggregate": lastr.t_signatures - lastr.t0, "streams": pipe.nthreads + 2 + (1 if pipe.hprover is not None else 0),
                       "approvals": n_sig, "witness_on": "gpu" if pipe.dev_wit else "host", "witness_batch": pipe.wchunk,
                       "witness_producer_seconds": lastr.witness_s, "preverify_ms": lastr.t_verify * 1e3,
                       "fold_thread_seconds": {k: round(v / 1e3, 3) for k, v in lastr.fold_host_ms.items()},

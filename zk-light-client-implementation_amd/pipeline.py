@@ -192,6 +192,7 @@ class BlockPipeline:
         self.stub = _ApprovalStub(RecursionProver(self.dag_ctx, HASH_GL))
         self.bprover = BlockProver(self.dag_ctx, self.stub)
         self.rpw = RecursionProver(self.dag_ctx, HASH_BN128) if wrap else None
+        self.hdr_ctx = self.hprover = None        # the header thread of prove_stream (its own context and provers), on first use
         self._ed = {}
         self._lock = threading.Lock()
         self._sig_failed = False
@@ -260,12 +261,12 @@ class BlockPipeline:
         for _ in range(self.nthreads):
             st["ready"].put(None)
 
-    def _precheck(self, st):
+    def _precheck(self, st, ctx=None):
         """a3 for every approval set of the block + the witness inputs of the signatures this rank proves"""
         from .plonky2 import ed25519_circuit as E
         t0 = time.perf_counter()
         for s in st["sets"]:
-            s.valid_keys, valid_pos, _, _ = SG.verify_approvals(self.ctx, s.msg, s.approvals, s.validators)   # raises InvalidSignature
+            s.valid_keys, valid_pos, _, _ = SG.verify_approvals(ctx or self.ctx, s.msg, s.approvals, s.validators)   # raises InvalidSignature
             if not valid_pos:
                 raise ValueError("no approvals present")
             _, pks, sigs = SG.slice_approvals(s.approvals, s.validators)
@@ -394,11 +395,38 @@ class BlockPipeline:
         except Exception as e:
             self._fail(st, e)
 
+    def _header_prover(self):
+        """a second BlockProver on its own high-priority context, used for NOTHING but the block-header proofs (bft.rs:64-205) of the
+        streaming form: they are independent leaves of the DAG, so the header thread of block b + 1 runs beside the joins and
+        the wrap of block b instead of behind them"""
+        if self.hprover is None:
+            import zklc_amd
+            from .plonky2 import HASH_GL
+            from .plonky2.recursion import RecursionProver
+            from .prove_bft import BlockProver
+            self.hdr_ctx = zklc_amd.Context(self.device_id, high_priority=True)
+            self.hprover = BlockProver(self.hdr_ctx, _ApprovalStub(RecursionProver(self.hdr_ctx, HASH_GL)))
+        return self.hprover
+
+    def _stream_header_worker(self, st, window):
+        try:
+            hp = self._header_prover()
+            hp.counts, hp.seconds = {}, {}
+            a, kw = window.bft_args()
+            jobs = hp.header_jobs(*a, kw.get("ep3_last_block_bytes"), kw.get("ep3_last_block_hash"))
+            got = {name: hp.prove_header_job(job) for name, job in jobs.items()}
+            st["hdr_counts"], st["hdr_seconds"] = dict(hp.counts), dict(hp.seconds)
+            st["hdr_future"].set_result(got)
+        except Exception as e:
+            self._fail(st, e)
+
     def _dag_worker(self, st, window, owner):
         try:
             res = st["res"]
             remote = None
-            if st["strong"]:      # the header proofs of the other ranks arrive through hdr_future; rank 0's own are made here
+            if st.get("hdr_thread"):   # streaming form: every header proof comes from the header thread
+                remote = lambda name: st["hdr_future"].result()[name]
+            elif st["strong"]:    # the header proofs of the other ranks arrive through hdr_future; rank 0's own are made here
                 remote = lambda name: None if owner[name] == 0 else st["hdr_future"].result()[name]
             a, kw = window.bft_args()
             res.block, res.block_n_1 = self.bprover.prove_block_bft(*a, window.validators, header_proofs=remote, **kw)
@@ -408,6 +436,10 @@ class BlockPipeline:
                 if res.block_n_1 is not None:
                     res.wrap_n_1 = self.rpw.recursive_proof(res.block_n_1, None, list(res.block_n_1[2]["public_inputs"]), raw=True)
             res.dag_seconds, res.dag_counts = dict(self.bprover.seconds), dict(self.bprover.counts)
+            for k, v in st.get("hdr_counts", {}).items():        # what the header thread proved belongs to the block's DAG as well
+                res.dag_counts[k] = res.dag_counts.get(k, 0) + v
+            for k, v in st.get("hdr_seconds", {}).items():
+                res.dag_seconds[k] = res.dag_seconds.get(k, 0.0) + v
             res.t_done = time.perf_counter()
         except Exception as e:
             self._fail(st, e)
@@ -439,6 +471,18 @@ class BlockPipeline:
                 self._reset_slots(ent)
             self._sig_failed = False
         return self._start([(self._witness_producer, (st,))] + [(self._ed_worker, (st, w)) for w in range(len(self.ed_ctxs))])
+
+    def _start_signature_stage_after(self, st, prev):
+        """streaming form: the producer and the prover of stream w start when THEIR predecessors of the previous block (`prev`: the
+        list _start_signature_stage returned for it) have ended -- the next block's first witnesses are made while this block's last
+        batch is still being proven, so the prover streams go from one block to the next without waiting for a witness batch"""
+        st["res"].t0 = time.perf_counter()
+        # the batched pre-check runs on the witness producer's context: the producer of the previous block has ended (the caller
+        # waited for it) while the first prover stream -- self.ctx -- may still be in the middle of a proof
+        self._precheck(st, self.wit_ctx)
+        prev = prev or [None] * (1 + len(self.ed_ctxs))
+        return self._start([(self._after, ([prev[0]] if prev[0] else [], self._witness_producer, (st,)))] +
+                           [(self._after, ([prev[1 + w]] if prev[1 + w] else [], self._ed_worker, (st, w))) for w in range(len(self.ed_ctxs))])
 
     def _begin_dag_stage(self, st):
         """the fold / DAG / keys-stakes stage of a block owns the stub's futures and the block prover's counters"""
@@ -537,44 +581,61 @@ class BlockPipeline:
         return st["res"] if (not strong or self.rank == 0) else None
 
     def prove_stream(self, windows, on_block_done=None):
-        """Consecutive blocks as a two-stage pipeline (a light client proves a stream of blocks): the signature stage of block
-        b + 1 starts as soon as the last signature proof of block b is out, while the tail of block b -- its last fold steps, the
-        closing proof, the joining recursions and the BN128 wrap, ~0.4 s during which the GPU would otherwise sit nearly idle --
-        completes beside it.  The fold / DAG stages of consecutive blocks share their provers, so they run one after the other.
-        Returns the BlockResults in order; `on_block_done(result)` is called as each block completes."""
+        """Consecutive blocks as a software pipeline (a light client proves a stream of blocks).  Every worker of block b -- the
+        witness producer, the prover of stream w, the fold thread, the header thread, the keys / stakes thread, the DAG thread (joins
+        and the BN128 wrap) -- owns its context and its provers and is chained to ITS predecessor of block b - 1 only:
+          * the fold thread and the keys / stakes thread start with the signature stage; the fold consumes the Ed25519 proofs as
+            they arrive instead of working through a backlog;
+          * the block-header proofs (independent leaves of the DAG, ~4 s of small proofs) have a thread and provers of their own
+            (`_header_prover`): the headers of block b + 1 are proven beside the joins and the wrap of block b, not behind them;
+          * the loop goes on to block b + 1 when the witness PRODUCER of block b has ended, i.e. while its last batch is still being
+            proven: the next block's first witnesses are ready before the prover streams run dry.
+        Rounds 3-5 chained whole stages (the fold / DAG stage of a block after the previous block's, the next signature stage after
+        the last signature proof): once the faster leaf hash of round 6 had made the serial chains the longer path, the GPU idled
+        between blocks (87-95 % busy, block latencies of 9-12 s: profiles/r06c_*, r06e_*).
+        Returns the BlockResults in order; `on_block_done(result)` is called as each block completes.  A block that fails ends the
+        stream: the blocks before it are delivered, its error is raised, the block started after it is abandoned."""
         results, prev_dag, prev_st = [], [], None
-        prev_fold, prev_ks = [], []
+        prev_fold, prev_ks, prev_hdr, prev_sig, all_threads = [], [], [], None, []
+
+        def deliver(st_):
+            results.append(st_["res"])
+            if on_block_done:
+                on_block_done(st_["res"])
         for window in windows:
             st = self._new_state(window.approval_sets(), False)
+            st["hdr_thread"] = True
             try:
-                sig = self._start_signature_stage(st)
+                if self._sig_failed:             # a failed signature stage leaves the slot accounting void: start from a clean state
+                    self._join(all_threads)
+                    for ent in self._ed.values():
+                        self._reset_slots(ent)
+                    self._sig_failed, prev_sig = False, None
+                sig = self._start_signature_stage_after(st, prev_sig)
             except Exception:
-                self._join(prev_dag)
+                self._join(all_threads)
                 raise
-            # Round 6: the fold thread and the keys / stakes thread of block b are chained to THEIR predecessors only (they own their
-            # provers: self.rp on fold_ctx, ks_prover on ks_ctx) and start with the signature stage -- the fold consumes the Ed25519
-            # proofs as they arrive.  Before, the whole fold / DAG stage of block b waited for the whole stage of block b - 1 (its
-            # joins and the wrap included): a fold that starts ~1 s late has a backlog of signature proofs to work through one
-            # dependent step at a time, ends late, delays the next block's stage further -- latencies of 9-12 s and a GPU at 87 %
-            # once the faster leaf hash had made the serial chain the longer path (profiles/r06c_*).
             fold = self._start([(self._after, (prev_fold, self._fold_worker, (st,)))])
             ks = self._start([(self._after, (prev_ks, self._ks_worker, (st,)))])
+            hdr = self._start([(self._after, (prev_hdr, self._stream_header_worker, (st, window)))])
+            all_threads = [t for t in all_threads if t.is_alive()] + sig + fold + ks + hdr
             self._join(prev_dag)                  # the DAG thread of block b - 1 (the stub's futures, the block prover's counters)
             if prev_st is not None:
-                self._raise(prev_st)
-                results.append(prev_st["res"])
-                if on_block_done:
-                    on_block_done(prev_st["res"])
+                if prev_st["errors"]:             # block b - 1 failed: abandon block b, raise b - 1's error
+                    self._fail(st, RuntimeError("the previous block of the stream failed"))
+                    self._join(all_threads)
+                    self._raise(prev_st)
+                deliver(prev_st)
             self._begin_dag_stage(st)
-            prev_dag = self._start([(self._dag_worker, (st, window, {}))]) + fold + ks
-            prev_fold, prev_ks, prev_st = fold, ks, st
-            self._join(sig)
-        self._join(prev_dag)
+            dag = self._start([(self._dag_worker, (st, window, {}))])
+            all_threads += dag
+            prev_dag = dag + fold + ks + hdr
+            prev_fold, prev_ks, prev_hdr, prev_sig, prev_st = fold, ks, hdr, sig, st
+            sig[0].join()                         # the witness producer of this block
+        self._join(all_threads)
         if prev_st is not None:
             self._raise(prev_st)
-            results.append(prev_st["res"])
-            if on_block_done:
-                on_block_done(prev_st["res"])
+            deliver(prev_st)
             self.last = prev_st["res"]
         return results
 
@@ -607,6 +668,10 @@ class BlockPipeline:
         if self.rpw is not None:
             self.rpw.close()
         self.bprover.close()              # closes the stub's recursion prover, the SHA-256 and primitive provers of the DAG thread
+        if self.hprover is not None:
+            self.hprover.close()
+            self.hdr_ctx.close()
+            self.hprover = self.hdr_ctx = None
         self.ks_prover.close()
         for c in self.ed_ctxs[1:] + [x for x in (self.wit_ctx, self.fold_ctx, self.ks_ctx, self.dag_ctx) if x is not None]:
             c.close()
