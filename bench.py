@@ -32,6 +32,8 @@ import os
 import sys
 import time
 T_PROCESS_START = time.perf_counter()
+# before anything can initialise the HIP runtime (torch, the library): one hardware queue per stream of the pipeline (zklc_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 

@@ -5,7 +5,7 @@ set -u
 TAG=${1:-r02}
 export TMPDIR=/tmp
 declare -A RES
-for pass in "SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY" "FETCH_SIZE" "WRITE_SIZE"; do
+for pass in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
   rm -rf gpurun_out/pmc_tmp
   timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d gpurun_out/pmc_tmp -o pmc -- python tools/merkle_only.py 3 > gpurun_out/${TAG}_pmc_merkle.log 2>&1
   f=$(find gpurun_out/pmc_tmp -name '*counter_collection.csv' | head -1)
