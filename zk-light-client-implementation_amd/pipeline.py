@@ -26,6 +26,7 @@ binary-tree fold of the partial aggregates over the ranks (distributed.tree_fold
 ranks, joins and wrap on rank 0.  No data-path collective in the weak form (every rank its own blocks).
 """
 import hashlib
+import os
 import queue
 import threading
 import time
@@ -597,6 +598,10 @@ class BlockPipeline:
         stream: the blocks before it are delivered, its error is raised, the block started after it is abandoned."""
         results, prev_dag, prev_st = [], [], None
         prev_fold, prev_ks, prev_hdr, prev_sig, all_threads = [], [], [], None, []
+        # A/B (ZKLC_STREAM, a comma list; default "fold,hdr,ahead"; "stages" = none of them = rounds 3-5): fold = the fold and keys /
+        # stakes threads start with the signature stage; hdr = the header thread; ahead = the producer lookahead
+        opts = set(x for x in os.environ.get("ZKLC_STREAM", "fold,hdr,ahead").split(",") if x and x != "stages")
+        o_fold, o_hdr, o_ahead = "fold" in opts, "hdr" in opts, "ahead" in opts
 
         def deliver(st_):
             results.append(st_["res"])
@@ -604,21 +609,24 @@ class BlockPipeline:
                 on_block_done(st_["res"])
         for window in windows:
             st = self._new_state(window.approval_sets(), False)
-            st["hdr_thread"] = True
+            st["hdr_thread"] = o_hdr
             try:
-                if self._sig_failed:             # a failed signature stage leaves the slot accounting void: start from a clean state
+                if self._sig_failed and o_ahead:  # a failed signature stage leaves the slot accounting void: start from a clean state
                     self._join(all_threads)
                     for ent in self._ed.values():
                         self._reset_slots(ent)
                     self._sig_failed, prev_sig = False, None
-                sig = self._start_signature_stage_after(st, prev_sig)
+                sig = self._start_signature_stage_after(st, prev_sig) if o_ahead else self._start_signature_stage(st)
             except Exception:
                 self._join(all_threads)
                 raise
-            fold = self._start([(self._after, (prev_fold, self._fold_worker, (st,)))])
-            ks = self._start([(self._after, (prev_ks, self._ks_worker, (st,)))])
-            hdr = self._start([(self._after, (prev_hdr, self._stream_header_worker, (st, window)))])
-            all_threads = [t for t in all_threads if t.is_alive()] + sig + fold + ks + hdr
+            early = []
+            if o_fold:
+                early += [(prev_fold, self._fold_worker, (st,)), (prev_ks, self._ks_worker, (st,))]
+            if o_hdr:
+                early += [(prev_hdr, self._stream_header_worker, (st, window))]
+            started = [self._start([(self._after, e)])[0] for e in early]
+            all_threads = [t for t in all_threads if t.is_alive()] + sig + started
             self._join(prev_dag)                  # the DAG thread of block b - 1 (the stub's futures, the block prover's counters)
             if prev_st is not None:
                 if prev_st["errors"]:             # block b - 1 failed: abandon block b, raise b - 1's error
@@ -627,11 +635,21 @@ class BlockPipeline:
                     self._raise(prev_st)
                 deliver(prev_st)
             self._begin_dag_stage(st)
-            dag = self._start([(self._dag_worker, (st, window, {}))])
+            late = [(self._dag_worker, (st, window, {}))]
+            if not o_fold:
+                late += [(self._fold_worker, (st,)), (self._ks_worker, (st,))]
+            dag = self._start(late)
             all_threads += dag
-            prev_dag = dag + fold + ks + hdr
-            prev_fold, prev_ks, prev_hdr, prev_sig, prev_st = fold, ks, hdr, sig, st
-            sig[0].join()                         # the witness producer of this block
+            prev_dag = dag + started
+            if o_fold:
+                prev_fold, prev_ks = [started[0]], [started[1]]
+            if o_hdr:
+                prev_hdr = [started[-1]]
+            prev_sig, prev_st = sig, st
+            if o_ahead:
+                sig[0].join()                     # the witness producer of this block
+            else:
+                self._join(sig)
         self._join(all_threads)
         if prev_st is not None:
             self._raise(prev_st)
