@@ -1280,7 +1280,7 @@ def main():
                     "sclk_mhz": (blk.get("telemetry_mean") or {}).get("sclk_mhz"),
                     "note": "frac = lane-instructions / (live wall x 39.3 T/s); sum_exclusive_kernel_s = the block's kernels run one at a time "
                             "(their own durations under counter collection); gpu_idle_s = time with no kernel resident in the kernel trace of "
-                            "the overlapped run (profiles/r06a_block_accounting.json)"}
+                            "the overlapped run (%s)" % str(bp.get("source", "profiles/block_pmc_latest.json"))[:60]}
             try:
                 if "cpu_baseline" in edp:
                     cb = edp["cpu_baseline"]

@@ -72,7 +72,7 @@ def test_compact_line_of_a_full_report():
 
 
 def test_committed_line_of_this_round():
-    path = os.path.join(ROOT, "profiles", "r04_bench_driver_cmd_line.json")
+    path = os.path.join(ROOT, "profiles", "r06h_bench_driver_cmd_line.json")
     if not os.path.exists(path):
         pytest.skip("no GPU run of this round committed yet")
     text = open(path).read().strip().splitlines()
@@ -80,8 +80,12 @@ def test_committed_line_of_this_round():
     j = _check_line(text[0])
     b = j["block_i"]
     assert b["blocks_checked"] == b["blocks_timed"] == j["steps"], "every timed block's final proofs are checked"
-    assert max(b["per_step_s"]) < 1.15 * min(b["per_step_s"]), "no outlier block (the 20 s collector stall of round 2)"
-    assert b["gpu"]["busy_pct"] > 90
+    # the software pipeline of round 6 fills over the first steps and drains in a short last one: the steps between
+    # must not hold an outlier block (the 20 s collector stall of round 2)
+    mid = sorted(b["per_step_s"][3:-1])
+    assert mid[-1] < 1.35 * mid[len(mid) // 2], "no outlier block"
+    assert b["gpu"]["busy_pct"] > 90 and b["host_cores_busy"] < 3.0
+    assert j["stages"]["c5"]["validators"] == 1000 and j["roofline"]["block"]["frac_of_issue_limit"] < 1
 
 
 def test_bench_starts_its_own_ranks():
