@@ -132,3 +132,95 @@ def test_signature_stage_with_failing_provers_terminates_and_frees_its_slots():
     import pytest as _pytest
     with _pytest.raises(RuntimeError):
         p._raise(st)
+
+
+# ---- prove_stream as a software pipeline (round 6) on stand-in workers: who may run beside whom, in which order results come out,
+# and what a failing block does to the stream
+def _fake_stream(n_blocks, fail_block=None, opts=None, monkeypatch=None):
+    import threading
+    import time
+    from zklc_amd import pipeline as PL
+    if opts is not None:
+        monkeypatch.setenv("ZKLC_STREAM", opts)
+    p = object.__new__(PL.BlockPipeline)
+    p.ed_ctxs, p._sig_failed, p._ed, p.last, p.wit_ctx = [None, None], False, {}, None, None
+    p.stub = type("S", (), {})()
+    p.bprover = type("B", (), {"counts": {}, "seconds": {}})()
+    log, lock, running = [], threading.Lock(), {}
+
+    def work(kind, b, seconds, st):
+        with lock:
+            running[kind] = running.get(kind, 0) + 1
+            assert running[kind] == 1, "two %s workers at once: they share provers" % kind
+            log.append(("start", kind, b))
+        time.sleep(seconds)
+        with lock:
+            running[kind] -= 1
+            log.append(("end", kind, b))
+    blocks = iter(range(n_blocks))
+    p._new_state = lambda sets, strong: {"sets": [], "errors": [], "res": PL.BlockResult(), "b": next(blocks), "strong": False,
+                                         "hdr_future": PL.Future(), "ready": __import__("queue").Queue()}
+    p._precheck = lambda st, ctx=None: None
+    p._witness_producer = lambda st: work("producer", st["b"], 0.03, st)
+    p._ed_worker = lambda st, w: work("ed%d" % w, st["b"], 0.06, st)
+    p._ks_worker = lambda st: work("ks", st["b"], 0.01, st)
+    p._stream_header_worker = lambda st, window: work("hdr", st["b"], 0.05, st)
+    p._begin_dag_stage = lambda st: None
+
+    def fold(st):
+        work("fold", st["b"], 0.07, st)
+        if st["b"] == fail_block:
+            p._fail(st, RuntimeError("stand-in fold failure in block %d" % st["b"]))
+    p._fold_worker = fold
+
+    def dag(st, window, owner):
+        while not any(e == ("end", "fold", st["b"]) for e in list(log)) and not st["errors"]:
+            time.sleep(0.002)                 # the DAG thread waits for the block's aggregate
+        work("dag", st["b"], 0.03, st)
+        st["res"].t_done = time.perf_counter()
+    p._dag_worker = dag
+    p.nthreads = 3
+    done = []
+    win = type("W", (), {"approval_sets": lambda self: []})()
+    err = None
+    try:
+        res = p.prove_stream([win] * n_blocks, lambda r: done.append(r))
+    except RuntimeError as e:
+        res, err = None, e
+    assert threading.active_count() <= 2, "prove_stream left worker threads behind"
+    return p, log, res, done, err
+
+
+def test_prove_stream_chains_every_worker_to_its_own_predecessor(monkeypatch):
+    p, log, res, done, err = _fake_stream(4, monkeypatch=monkeypatch)
+    assert err is None and len(res) == 4 and done == res
+    pos = {e: i for i, e in enumerate(log)}
+    for kind in ("producer", "ed0", "ed1", "fold", "ks", "hdr", "dag"):
+        ends = [pos[("end", kind, b)] for b in range(4)]
+        starts = [pos[("start", kind, b)] for b in range(4)]
+        assert all(starts[b + 1] > ends[b] for b in range(3)), "%s of block b + 1 started before block b's ended" % kind
+    # the point of the software pipeline: the NEXT block's producer, provers, fold and headers run beside THIS block's DAG thread
+    for b in range(3):
+        assert pos[("start", "producer", b + 1)] < pos[("end", "dag", b)]
+        assert pos[("start", "fold", b + 1)] < pos[("end", "dag", b)]
+        assert pos[("start", "hdr", b + 1)] < pos[("end", "dag", b)]
+    # .. and the lookahead: the producer of block b + 1 starts while a prover stream of block b is still busy
+    assert any(pos[("start", "producer", b + 1)] < pos[("end", "ed0", b)] for b in range(3))
+    assert p.last is res[-1]
+
+
+def test_prove_stream_stage_chained_form_is_still_selectable(monkeypatch):
+    p, log, res, done, err = _fake_stream(3, opts="stages", monkeypatch=monkeypatch)
+    assert err is None and len(res) == 3
+    pos = {e: i for i, e in enumerate(log)}
+    assert not any(e[1] == "hdr" for e in log)                                    # no header thread
+    for b in range(2):                                                            # rounds 3-5: stage after stage
+        assert pos[("start", "fold", b + 1)] > pos[("end", "dag", b)]
+        assert pos[("start", "producer", b + 1)] > max(pos[("end", "ed0", b)], pos[("end", "ed1", b)])
+
+
+def test_prove_stream_delivers_the_blocks_before_a_failed_one_and_raises(monkeypatch):
+    p, log, res, done, err = _fake_stream(4, fail_block=1, monkeypatch=monkeypatch)
+    assert err is not None and "block 1" in str(err)
+    assert len(done) == 1                                                         # block 0 was delivered, nothing after it
+    assert not any(e[2] == 3 for e in log), "the stream went on after the failed block"
