@@ -175,7 +175,12 @@ class BlockPipeline:
         self.nthreads = max(2, int(prove_streams))
         self.dev_wit = not host_witness
         self.wrap = wrap
-        self.nbuf = 2
+        # wire-matrix buffers per circuit (each witness_batch x 0.49 GB of HBM).  Round 6: the kernel trace of the overlapped bench
+        # showed all three prover queues idle TOGETHER for 0.3-0.4 s two to three times per block (profiles/r06h_*: the gaps of queues
+        # 4-6 coincide) -- the provers had run out of witnesses: with two buffers the next block's first large batch can only be
+        # produced once the previous block's last batch is fully proven.  Three buffers and a producer whose (latency-bound,
+        # single-workgroup) kernels get the device's high stream priority keep a batch ahead.   ZKLC_WIT_BUFS / ZKLC_WIT_PRIORITY: A/B
+        self.nbuf = max(2, int(os.environ.get("ZKLC_WIT_BUFS", "3")))
         if self.dev_wit:
             self.wchunk = max(1, min(64, int(witness_batch)))
         else:
@@ -184,7 +189,7 @@ class BlockPipeline:
             self.wchunk = max(1, min(12 if world == 1 else 6, cores // max(1, world) - self.nthreads))
         self.ctx = zklc_amd.Context(device_id)                       # pre-check + the first Ed25519 prover
         self.ed_ctxs = [self.ctx] + [zklc_amd.Context(device_id) for _ in range(self.nthreads - 2)]
-        self.wit_ctx = zklc_amd.Context(device_id) if self.dev_wit else None
+        self.wit_ctx = zklc_amd.Context(device_id, high_priority=os.environ.get("ZKLC_WIT_PRIORITY", "1") != "0") if self.dev_wit else None
         self.fold_ctx = zklc_amd.Context(device_id, high_priority=True)
         self.ks_ctx = zklc_amd.Context(device_id)
         self.dag_ctx = zklc_amd.Context(device_id, high_priority=True)
