@@ -184,7 +184,6 @@ class BlockPipeline:
         if self.dev_wit:
             self.wchunk = max(1, min(64, int(witness_batch)))
         else:
-            import os
             cores = host_threads or len(os.sched_getaffinity(0))
             self.wchunk = max(1, min(12 if world == 1 else 6, cores // max(1, world) - self.nthreads))
         self.ctx = zklc_amd.Context(device_id)                       # pre-check + the first Ed25519 prover
