@@ -178,8 +178,9 @@ class BlockPipeline:
         # wire-matrix buffers per circuit (each witness_batch x 0.49 GB of HBM).  Round 6: the kernel trace of the overlapped bench
         # showed all three prover queues idle TOGETHER for 0.3-0.4 s two to three times per block (profiles/r06h_*: the gaps of queues
         # 4-6 coincide) -- the provers had run out of witnesses: with two buffers the next block's first large batch can only be
-        # produced once the previous block's last batch is fully proven.  Three buffers and a producer whose (latency-bound,
-        # single-workgroup) kernels get the device's high stream priority keep a batch ahead.   ZKLC_WIT_BUFS / ZKLC_WIT_PRIORITY: A/B
+        # produced once the previous block's last batch is fully proven.  Three buffers keep a batch ahead: 5.46 -> 5.18 s per block
+        # on one box (profiles/r06k_*); giving the producer's stream the device's high priority on top measured WORSE (5.39-5.58 s)
+        # and stays off.   ZKLC_WIT_BUFS / ZKLC_WIT_PRIORITY=1: A/B
         self.nbuf = max(2, int(os.environ.get("ZKLC_WIT_BUFS", "3")))
         if self.dev_wit:
             self.wchunk = max(1, min(64, int(witness_batch)))
@@ -188,7 +189,7 @@ class BlockPipeline:
             self.wchunk = max(1, min(12 if world == 1 else 6, cores // max(1, world) - self.nthreads))
         self.ctx = zklc_amd.Context(device_id)                       # pre-check + the first Ed25519 prover
         self.ed_ctxs = [self.ctx] + [zklc_amd.Context(device_id) for _ in range(self.nthreads - 2)]
-        self.wit_ctx = zklc_amd.Context(device_id, high_priority=os.environ.get("ZKLC_WIT_PRIORITY", "1") != "0") if self.dev_wit else None
+        self.wit_ctx = zklc_amd.Context(device_id, high_priority=os.environ.get("ZKLC_WIT_PRIORITY", "0") == "1") if self.dev_wit else None
         self.fold_ctx = zklc_amd.Context(device_id, high_priority=True)
         self.ks_ctx = zklc_amd.Context(device_id)
         self.dag_ctx = zklc_amd.Context(device_id, high_priority=True)
@@ -293,7 +294,9 @@ class BlockPipeline:
             for s in st["sets"]:
                 ent, n_mine = s.ed, len(s.my_sigs)
                 # a small first chunk (one signature per prover stream) so that proving starts after one witness time
-                bounds = [0, min(n_mine, self.wchunk, max(1, self.nthreads - 1))] if first else [0]
+                # (not for a block whose predecessor's proofs still occupy the provers: ZKLC_WIT_SMALL_FIRST=always restores it)
+                small = first and (not st.get("has_prev") or os.environ.get("ZKLC_WIT_SMALL_FIRST") == "always")
+                bounds = [0, min(n_mine, self.wchunk, max(1, self.nthreads - 1))] if small else [0]
                 first = False
                 while bounds[-1] < n_mine:
                     bounds.append(min(n_mine, bounds[-1] + self.wchunk))
@@ -485,6 +488,7 @@ class BlockPipeline:
         # the batched pre-check runs on the witness producer's context: the producer of the previous block has ended (the caller
         # waited for it) while the first prover stream -- self.ctx -- may still be in the middle of a proof
         self._precheck(st, self.wit_ctx)
+        st["has_prev"] = prev is not None
         prev = prev or [None] * (1 + len(self.ed_ctxs))
         return self._start([(self._after, ([prev[0]] if prev[0] else [], self._witness_producer, (st,)))] +
                            [(self._after, ([prev[1 + w]] if prev[1 + w] else [], self._ed_worker, (st, w))) for w in range(len(self.ed_ctxs))])
