@@ -179,7 +179,7 @@ class BlockPipeline:
         # showed all three prover queues idle TOGETHER for 0.3-0.4 s two to three times per block (profiles/r06h_*: the gaps of queues
         # 4-6 coincide) -- the provers had run out of witnesses: with two buffers the next block's first large batch can only be
         # produced once the previous block's last batch is fully proven.  Three buffers keep a batch ahead: 5.46 -> 5.18 s per block
-        # on one box (profiles/r06k_*); giving the producer's stream the device's high priority on top measured WORSE (5.39-5.58 s)
+        # on one box (profiles/r06k_*; within the noise on a second, r06l_*); giving the producer's stream the device's high priority on top measured WORSE (5.39-5.58 s)
         # and stays off.   ZKLC_WIT_BUFS / ZKLC_WIT_PRIORITY=1: A/B
         self.nbuf = max(2, int(os.environ.get("ZKLC_WIT_BUFS", "3")))
         if self.dev_wit:
