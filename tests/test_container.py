@@ -140,8 +140,9 @@ def test_sections_that_contradict_each_other_are_refused(tmp_path, sha_circuit):
     pr = data._program
     dims = C.DimsC(len(pr["code"]), len(pr["params"]), len(pr["wire_slot"]), pr["n_slots"], len(pr["input_slots"]), 135, data.n, len(pr["pi_slots"]), 0)
 
-    def write(path, sig=None, wire_index=None, pi_slots=None, dims_=None):
+    def write(path, sig=None, wire_index=None, pi_slots=None, dims_=None, code=None):
         sig = data.sigmas if sig is None else sig
+        code_ = pr["code"] if code is None else code
         wi = pr["wire_index"] if wire_index is None else wire_index
         ps = pr["pi_slots"] if pi_slots is None else pi_slots
         e = [(C.SEC_PARAMS, ctypes.sizeof(p), ctypes.addressof(p), ctypes.sizeof(p)),
@@ -149,7 +150,7 @@ def test_sections_that_contradict_each_other_are_refused(tmp_path, sha_circuit):
              (C.SEC_K_IS, 8, kis.ctypes.data, kis.nbytes), (C.SEC_CONSTANTS, 8, data.constants.ctypes.data, data.constants.nbytes),
              (C.SEC_SIGMAS, 8, sig.ctypes.data, sig.nbytes),
              (C.SEC_WP_DIMS, ctypes.sizeof(dims), ctypes.addressof(dims_ or dims), ctypes.sizeof(dims)),
-             (C.SEC_WP_CODE, 4, pr["code"].ctypes.data, pr["code"].nbytes), (C.SEC_WP_PARAMS, 8, pr["params"].ctypes.data, pr["params"].nbytes),
+             (C.SEC_WP_CODE, 4, code_.ctypes.data, code_.nbytes), (C.SEC_WP_PARAMS, 8, pr["params"].ctypes.data, pr["params"].nbytes),
              (C.SEC_WP_INPUT_SLOTS, 4, pr["input_slots"].ctypes.data, pr["input_slots"].nbytes),
              (C.SEC_WP_WIRE_SLOT, 4, pr["wire_slot"].ctypes.data, pr["wire_slot"].nbytes), (C.SEC_WP_WIRE_INDEX, 4, wi.ctypes.data, wi.nbytes),
              (C.SEC_WP_PI_SLOTS, 4, ps.ctypes.data, ps.nbytes)]
@@ -186,6 +187,21 @@ def test_sections_that_contradict_each_other_are_refused(tmp_path, sha_circuit):
     assert params_rc(oob) == (0, FORMAT)
     d2 = C.DimsC(len(pr["code"]) - 1, len(pr["params"]), len(pr["wire_slot"]), pr["n_slots"], len(pr["input_slots"]), 135, data.n, len(pr["pi_slots"]), 0)
     write(oob, dims_=d2)
+    assert params_rc(oob) == (0, FORMAT)
+    # the instruction words are walked before any interpreter sees them: a slot that does not exist, an instruction that runs past
+    # the end of the code, parameters past the end of the parameter array
+    code = pr["code"].copy()
+    n_in = int(code[2])
+    code[4 + n_in] = pr["n_slots"] + 5                       # first output slot of the first instruction
+    write(oob, code=code)
+    assert params_rc(oob) == (0, FORMAT)
+    code = pr["code"].copy()
+    code[3] += 1                                             # one more output than the stream holds: the tiling breaks
+    write(oob, code=code)
+    assert params_rc(oob) == (0, FORMAT)
+    code = pr["code"].copy()
+    code[1] = len(pr["params"]) + 1
+    write(oob, code=code)
     assert params_rc(oob) == (0, FORMAT)
     # duplicate tags and the library's own tags as "host" sections are refused by the writers
     e2 = (C.EntryC * 2)(C.EntryC(0x1000, 1, kis.ctypes.data, 8), C.EntryC(0x1000, 1, kis.ctypes.data, 8))

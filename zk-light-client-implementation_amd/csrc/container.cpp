@@ -299,6 +299,20 @@ int32_t program_sections(const zklc_container *c, program_view *v) {
         if (v->input_slots[k] >= D.n_slots) return ZKLC_ERR_FORMAT;
     for (u32 k = 0; k < D.n_pi; k++)
         if (v->pi_slots[k] >= D.n_slots) return ZKLC_ERR_FORMAT;
+    // the instruction stream, structurally: [opcode, n_params, n_in, n_out, in slots.., out slots..]* must tile the code words exactly,
+    // every slot must exist and the parameter blocks must lie inside the parameter array (the host interpreter indexes with these
+    // numbers unchecked; the device scheduler checks them again).  What a parameter MEANS to its opcode is the writer's business:
+    // the file comes from whoever built the circuit, and a wrong parameter is no worse than a wrong constant of the circuit itself.
+    u64 ip = 0, pp = 0;
+    while (ip < D.code_len) {
+        if (ip + 4 > D.code_len) return ZKLC_ERR_FORMAT;
+        const u64 np = v->code[ip + 1], ni = v->code[ip + 2], no = v->code[ip + 3];
+        if (v->code[ip] > 255 || ip + 4 + ni + no > D.code_len || pp + np > D.n_params) return ZKLC_ERR_FORMAT;
+        for (u64 k = 0; k < ni + no; k++)
+            if (v->code[ip + 4 + k] >= D.n_slots) return ZKLC_ERR_FORMAT;
+        ip += 4 + ni + no;
+        pp += np;
+    }
     return ZKLC_OK;
 }
 }  // namespace

@@ -103,7 +103,7 @@ def encode_obj(obj):
     """Length-framed wire form of what the ranks exchange -- proof triples (common_data dict, verifier_only dict, proof as
     `to_bytes` bytes or in the proof.json schema) and dicts / lists of them: [u32 n][JSON text of n bytes][u32 k][k x (u64 len, raw
     bytes)].  The JSON holds the structure (dict, list, tuple as {"__t": [..]}, int, str, None); byte strings travel raw and are
-    referenced as {"__b": index}.  Decoding builds plain data only: nothing a peer sends is ever executed (no pickle)."""
+    referenced as {"__b": index}.  Decoding builds plain data only: nothing a peer sends is ever executed (no Python object serialisation)."""
     import json
     import struct
     blobs = []

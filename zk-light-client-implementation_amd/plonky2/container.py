@@ -10,7 +10,7 @@ Rust shim beside plonky2's `CircuitBuilder` can emit one.  The 
 What the host mirror needs on top of the native sections travels in three sections of its own (tags >= ZKLC_SEC_HOST_FIRST, ignored
 by the library): a JSON note (config, gate ids, the caller's `aux` tree with targets replaced by table indices), the table of target
 keys and the indices of the witness program's input targets.  Loading executes nothing: JSON + integer arrays (the cache of rounds
-2-5 was a pickle).
+2-5 stored serialised Python objects).
 """
 import ctypes
 import json
