@@ -120,7 +120,11 @@ def test_two_ranks_share_the_one_gpu_over_gloo():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "1",
                         "--no-cpu-baseline", "--no-bn254-extras", "--c5-validators", "0"], capture_output=True, text=True, timeout=1500, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
+    if r.returncode != 0:                      # the ranks' tracebacks are long: the whole stderr goes to a file, the first error here
+        with open(os.path.join(ROOT, "gpurun_out", "test_two_ranks_stderr.log"), "w") as f:
+            f.write(r.stderr)
+        first = r.stderr.find("Traceback")
+        raise AssertionError(r.stderr[max(0, first):first + 3000] if first >= 0 else r.stderr[-3000:])
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["final_proof_verified"] is True
     blk = line["block_i"]
