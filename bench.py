@@ -660,7 +660,8 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     ed_name = "ed25519_circuit_2p18x234"
     t_setup = time.perf_counter()
     pipe = BlockPipeline(torch.cuda.current_device(), prove_streams=args.prove_streams, witness_batch=args.witness_batch,
-                         host_witness=args.host_witness, rank=rank, world=world, comm_device=dev, host_threads=host_cores())
+                         host_witness=args.host_witness, rank=rank, world=world, comm_device=dev, host_threads=host_cores(),
+                         device_share=-(-world // max(1, torch.cuda.device_count())))
 
     # cold start: the cacheable circuits the run needs (Ed25519, the SHA-256 circuits of the header chains) that are not in the
     # circuit cache yet are built by worker processes side by side, not one after the other under this process's GIL
@@ -920,7 +921,9 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                       "host_cpu_s_per_block": cpu_all / steps, "host_cores_busy": cpu_all / max(total_s, 1e-9),
                       "peak_rss_mb": resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0,
                       "timed_region_clock_ns": {k: [clk0[k], clk1[k]] for k in clk0},
-                      "host_load_before": load0, "host_load_after": host_load()}
+                      "host_load_before": load0, "host_load_after": host_load(),
+                      "hbm_used_gb": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),   # the whole device, all processes
+                      "witness_buffers": pipe.nbuf, "device_share": pipe.device_share}
     if world > 1 and not strong_only and not args.no_strong_section:
         # the STRONG form of the block measured in the same run, so that one SCALE run holds both: all ranks prove
         # ONE block per step (signature shards, local folds, a binary-tree fold over the ranks, the header proofs on the other ranks,

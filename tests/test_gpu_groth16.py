@@ -53,6 +53,23 @@ def test_groth16_prove_on_the_gpu_equals_the_oracle_and_verifies(zctx):
     assert not G.verify(vk, ((got[0], got[1]), ((got[3], got[2]), (got[5], got[4])), (got[6], got[7])), [1, 2, 3])
 
 
+def test_groth16_prove_over_fixed_base_tables_equals_the_oracle(zctx, monkeypatch):
+    """ZKLC_GROTH16_FIXED=1: the four big sums over fixed-base tables (built once per key); the proof words are the oracle's and the
+    plain form's -- the affine result of a multi-exponentiation is canonical"""
+    n_con, n_pub = 100, 3
+    r1cs, wit = G.square_chain_r1cs(n_con, n_public=n_pub)
+    pk, vk = G.setup(r1cs, n_pub, (0x1234567891, 0xabcdef12345, 0x777766665555, 0x3133731337, 0x42424242))
+    w = wit([4, 5, 6], 11)
+    abc = G.abc_evaluations(r1cs, w, pk["n"])
+    want = G.proof_to_uint256x8(G.prove(pk, r1cs, w, 0x9999, 0x7777))
+    monkeypatch.setenv("ZKLC_GROTH16_FIXED", "1")
+    fixed = Groth16Prover(zctx, pk)
+    assert fixed.fixed and fixed.prove(w, abc, 0x9999, 0x7777) == want
+    monkeypatch.setenv("ZKLC_GROTH16_FIXED", "0")
+    plain = Groth16Prover(zctx, pk)
+    assert not plain.fixed and plain.prove(w, abc, 0x9999, 0x7777) == want
+
+
 def test_proving_key_with_infinity_points_removed(zctx):
     """gnark stores G1.A / G1.B / G2.B without their points at infinity and marks the positions (InfinityA / InfinityB); the prover
     filters the wire values accordingly.  The compacted key + masks must give the proof of the complete key."""

@@ -6,14 +6,18 @@ proof bytes); gnark v0.9.1 backend/groth16/bn254/prove.go is un-vendored (go.mod
   host    a, b, c = (A w, B w, C w) per constraint (the solved witness is the caller's: gnark's solver is the Go side)
   GPU     computeH: 3 inverse NTTs, 3 coset NTTs, (a b - c) / (5^n - 1) pointwise, 1 coset inverse NTT  (zklc_bn254_fr_ntt_dev,
           zklc_bn254_fr_mul_sub_scale_dev) -- data stays in HBM between the seven transforms
-  GPU     Ar  = alpha + sum_i w_i A_i + r delta                       one G1 MSM (alpha, delta appended as points)
-          Bs  = beta  + sum_i w_i B_i + s delta                       one G2 MSM
-          Bs1 = beta1 + sum_i w_i B1_i + s delta1                     one G1 MSM
-          Krs = sum_priv w_i K_i + sum_j h_j Z_j + s Ar + r Bs1 - r s delta1      one G1 MSM (Ar, Bs1 appended)
+  GPU     Ar  = alpha + sum_i w_i A_i + r delta                       one G1 MSM (alpha, delta among the bases)        stream 1
+          Bs1 = beta1 + sum_i w_i B1_i + s delta1                     one G1 MSM                                        stream 1
+          Bs  = beta  + sum_i w_i B_i + s delta                       one G2 MSM                                        stream 2
+          Krs = [sum_priv w_i K_i + sum_j h_j Z_j] + s Ar + r Bs1 - r s delta1
+                the bracket: one G1 MSM over fixed bases, after computeH on stream 3; the rest: a four-point MSM at the end
+          every base is a fixed point of the key: ZKLC_GROTH16_FIXED=1 runs the four big sums over fixed-base tables (measured: no gain)
   host    the eight coordinates out of Montgomery form -> the uint256[8] / 256-byte / compressed encodings (zklc_amd/formats.py)
 The proving key arrives as affine points in gnark-crypto's memory layout (what a cgo shim hands over) and stays
 resident on the device.  No CPU fallback: every transform and MSM is a kernel launch through the C ABI.
 """
+import os
+
 import numpy as np
 
 R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
@@ -91,31 +95,57 @@ class Groth16Prover:
         assert A.shape[0] == n_a and B1.shape[0] == B2.shape[0] == n_b, "key arrays do not match the infinity masks"
         assert K.shape[0] == self.n_wires - 1 - self.n_public and Z.shape[0] == self.n - 1
         up = lambda a: torch.from_numpy(a.view(np.int64)).to(self.dev)
-        # MSM operand layouts: the fixed points first, the per-proof extras (alpha / beta, delta, Ar, Bs1) in the tail
-        self.d_A = up(np.concatenate([A, al, de1]))
-        self.d_B1 = up(np.concatenate([B1, be1, de1]))
-        self.d_B2 = up(np.concatenate([B2, be2, de2]))
-        self.d_KZ = up(np.concatenate([K, Z, np.zeros((2, 8), np.uint64), de1]))
+        # MSM operands: every base of the four sums is a FIXED point of the key -- the per-proof points Ar and Bs1 of Krs are folded
+        # in by a four-point sum at the end (prove_words).  ZKLC_GROTH16_FIXED=1 puts the operands on fixed-base tables (zklc.h:
+        # rows of 2^(c w) P_i, one bucket set, no closing doublings; 16 x the memory, built once here).  Measured at 2^22 on one
+        # box (profiles/r06o_groth16_quickbench.txt): 71.2 ms with the tables, 69.6 ms without -- the table form saves the serial
+        # tail of a sum, which the three streams below already hide under the other sums' slice kernels, and its 4.3 GB of records
+        # per operand no longer sit in the 256 MB last-level cache the way 2^22 plain 64-byte records do.  Default: plain.
+        self.fixed = os.environ.get("ZKLC_GROTH16_FIXED", "0") == "1"
+        self.n_priv = K.shape[0]
+        ops = {"A": (np.concatenate([A, al, de1]), 1), "B1": (np.concatenate([B1, be1, de1]), 1),
+               "B2": (np.concatenate([B2, be2, de2]), 2), "KZ": (np.concatenate([K, Z]), 1)}
+        self.delta1_words = de1.reshape(8).copy()
+        self.n_op = {k: v[0].shape[0] for k, v in ops.items()}
+        self.d_op = {}
+        for name, (arr, group) in ops.items():
+            d_pts = up(arr)
+            if self.fixed:
+                self.d_op[name] = ctx.bn254_msm_fixed_table(d_pts, arr.shape[0], group, stream=ctx.stream_ptr())
+                ctx.synchronize()                                 # d_pts goes back to torch's allocator below
+                del d_pts
+            else:
+                self.d_op[name] = d_pts
         lib = ctx._lib
-        self.ws1 = torch.empty(int(lib.zklc_bn254_g1_msm_workspace_bytes(max(self.d_A.shape[0], self.d_KZ.shape[0]))), dtype=torch.uint8, device=self.dev)
-        self.ws2 = torch.empty(int(lib.zklc_bn254_g2_msm_workspace_bytes(self.d_B2.shape[0])), dtype=torch.uint8, device=self.dev)
+        wsb = lambda fn, k: torch.empty(int(fn(k)), dtype=torch.uint8, device=self.dev)
+        # one workspace per stream: A and B1 run one after the other on ctx, B2 on ctx2, computeH and K / Z on ctx3
+        self.ws1 = wsb(lib.zklc_bn254_g1_msm_workspace_bytes, max(self.n_op["A"], self.n_op["B1"]))
+        self.ws2 = wsb(lib.zklc_bn254_g2_msm_workspace_bytes, self.n_op["B2"])
+        self.ws3 = wsb(lib.zklc_bn254_g1_msm_workspace_bytes, self.n_op["KZ"])
         self.wsn = torch.empty(int(lib.zklc_bn254_fr_ntt_workspace_bytes(self.log_n)), dtype=torch.uint8, device=self.dev)
         self.den = np.array(fr_to_mont_words(pow((pow(5, self.n, R) - 1) % R, R - 2, R)), dtype=np.uint64)
         # resident operands of the Montgomery -> regular conversion of h (a pointwise (a * 1_raw - 0) * 1: see prove_words)
         self.one_raw = torch.zeros((self.n, 4), dtype=torch.int64, device=self.dev)
         self.one_raw[:, 0] = 1
         self.zero = torch.zeros((self.n, 4), dtype=torch.int64, device=self.dev)
-        # the G2 multi-exponentiation runs on its own context (= HIP stream) beside the G1 ones: its slice kernel keeps one wave per
-        # SIMD (363 VGPRs) and its serial tail a handful of lanes, both of which the G1 kernels fill
+        # the scalars of the K / Z sum: [private wires | h_0 .. h_(n-2)], assembled in place (no concatenation per proof)
+        self.sc_k = torch.zeros((self.n_op["KZ"], 4), dtype=torch.int64, device=self.dev)
+        # Three streams per proof (round 6): the sums are independent of each other once Krs is split into its fixed part and
+        # s Ar + r Bs1 - r s delta1, so A and B1 (ctx), B2 (ctx2: its slice kernel keeps one wave per SIMD and its serial tail a
+        # handful of lanes, both of which the G1 kernels fill) and computeH followed by the K / Z sum (ctx3) run side by side; the
+        # latency-bound tails of one sum (segment / window / final kernels, ~1.6 ms each) lie under the slice kernels of the others.
         from .context import Context
         self.ctx2 = Context(ctx.device_id)
+        self.ctx3 = Context(ctx.device_id)
         torch.cuda.synchronize(self.dev)
         self.last_ms = {}
 
     def close(self):
-        if self.ctx2 is not None:
-            self.ctx2.close()
-            self.ctx2 = None
+        for name in ("ctx2", "ctx3"):
+            c = getattr(self, name, None)
+            if c is not None:
+                c.close()
+                setattr(self, name, None)
 
     def __del__(self):
         try:
@@ -123,34 +153,47 @@ class Groth16Prover:
         except Exception:
             pass
 
-    def _ntt(self, d, flags, coset):
-        self.ctx._check(self.ctx._lib.zklc_bn254_fr_ntt_dev(self.ctx._h, self.ctx.stream_ptr(), d.data_ptr(), self.log_n, flags, coset,
-                                                            self.wsn.data_ptr(), self.wsn.numel()))
+    def _ntt(self, d, flags, coset, ctx=None):
+        ctx = ctx or self.ctx
+        ctx._check(ctx._lib.zklc_bn254_fr_ntt_dev(ctx._h, ctx.stream_ptr(), d.data_ptr(), self.log_n, flags, coset,
+                                                  self.wsn.data_ptr(), self.wsn.numel()))
+
+    def _compute_h_enqueue(self, d, ctx):
+        """gnark `computeH` on ctx's stream, in place in d[0]; d = the three device tensors [n, 4] (Montgomery) of A w, B w, C w.
+        Leaves h in REGULAR form (the MSM takes non-Montgomery scalars): the last step is a multiplication by 1 with the pointwise
+        kernel  a <- (a * b - c) * scale,  b = raw 1 (the Montgomery form of 2^-256: strips one factor 2^256), c = 0, scale = 1."""
+        from . import _lib
+        for x in d:
+            self._ntt(x, _lib.NTT_INVERSE, 0, ctx)            # evaluations on the subgroup -> coefficients
+            self._ntt(x, 0, 1, ctx)                           # -> evaluations on the coset 5 <w>
+        ctx._check(ctx._lib.zklc_bn254_fr_mul_sub_scale_dev(ctx._h, ctx.stream_ptr(), d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
+                                                            self.den.ctypes.data, self.n))
+        self._ntt(d[0], _lib.NTT_INVERSE, 1, ctx)             # coset evaluations of (a b - c) / Z -> coefficients of h
+        mont_one = np.array(fr_to_mont_words(1), dtype=np.uint64)
+        ctx._check(ctx._lib.zklc_bn254_fr_mul_sub_scale_dev(ctx._h, ctx.stream_ptr(), d[0].data_ptr(), self.one_raw.data_ptr(),
+                                                            self.zero.data_ptr(), mont_one.ctypes.data, self.n))
 
     def compute_h(self, a, b, c):
         """gnark `computeH`; a, b, c: uint64 [n, 4] (Montgomery) constraint evaluations -> device tensor of the n coefficients of h
-        (regular form is produced by the caller: the MSM takes non-Montgomery scalars)"""
+        in regular form"""
         torch = self.torch
-        from . import _lib
         d = [torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint64).view(np.int64)).to(self.dev) for x in (a, b, c)]
-        for x in d:
-            self._ntt(x, _lib.NTT_INVERSE, 0)                 # evaluations on the subgroup -> coefficients
-            self._ntt(x, 0, 1)                                # -> evaluations on the coset 5 <w>
-        self.ctx._check(self.ctx._lib.zklc_bn254_fr_mul_sub_scale_dev(self.ctx._h, self.ctx.stream_ptr(), d[0].data_ptr(), d[1].data_ptr(),
-                                                                      d[2].data_ptr(), self.den.ctypes.data, self.n))
-        self._ntt(d[0], _lib.NTT_INVERSE, 1)                  # coset evaluations of (a b - c) / Z -> coefficients of h
+        torch.cuda.current_stream(self.dev).synchronize()
+        self._compute_h_enqueue(d, self.ctx)
         # b and c go back to torch's allocator when this function returns, and torch hands blocks out on ITS stream: the kernels
         # that still read them run on ctx's stream, so drain it first
         self.ctx.synchronize()
         return d[0]
 
-    def _msm1(self, d_pts, d_sc, n):
-        torch = self.torch
-        out = torch.zeros(8, dtype=torch.int64, device=self.dev)
-        inf = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        torch.cuda.current_stream(self.dev).synchronize()
-        self.ctx.bn254_g1_msm_dev(d_pts, d_sc, n, out, inf, self.ws1, self.ws1.numel(), stream=self.ctx.stream_ptr())
-        return out, inf
+    def _msm(self, ctx, name, d_sc, d_out, d_inf, ws, group=1):
+        n = self.n_op[name]
+        if self.fixed:
+            ctx.bn254_msm_fixed_dev(self.d_op[name], d_sc, n, d_out, d_inf, ws, ws.numel(), group=group, stream=ctx.stream_ptr())
+        elif group == 1:
+            ctx.bn254_g1_msm_dev(self.d_op[name], d_sc, n, d_out, d_inf, ws, ws.numel(), stream=ctx.stream_ptr())
+        else:
+            ctx._check(ctx._lib.zklc_bn254_g2_msm_dev(ctx._h, ctx.stream_ptr(), self.d_op[name].data_ptr(), d_sc.data_ptr(), n,
+                                                      d_out.data_ptr(), d_inf.data_ptr(), ws.data_ptr(), ws.numel()))
 
     def prove(self, witness, abc, r, s):
         """witness: all wire values (ints, witness[0] = 1); abc = (a, b, c): per-constraint values of A w, B w, C w (ints, padded
@@ -168,45 +211,51 @@ class Groth16Prover:
         import time
         torch = self.torch
         t0 = time.perf_counter()
+        tsync = lambda: torch.cuda.current_stream(self.dev).synchronize()   # torch builds operands on ITS stream; the kernels run on the contexts'
         w_reg = np.ascontiguousarray(w_reg, dtype=np.uint64).reshape(self.n_wires, 4)
-        d_h = self.compute_h(*abc_mont)
-        t1 = time.perf_counter()
-        # h comes back in Montgomery form; the MSM wants regular scalars: the conversion is a multiplication by 1 on the device with the
-        # pointwise kernel  a <- (a * b - c) * scale,  b = raw 1 (the Montgomery form of 2^-256: strips one factor 2^256), c = 0, scale = 1
-        mont_one = np.array(fr_to_mont_words(1), dtype=np.uint64)
-        self.ctx._check(self.ctx._lib.zklc_bn254_fr_mul_sub_scale_dev(self.ctx._h, self.ctx.stream_ptr(), d_h.data_ptr(), self.one_raw.data_ptr(),
-                                                                      self.zero.data_ptr(), mont_one.ctypes.data, self.n))
         tail = lambda *xs: np.array([fr_to_regular_words(x) for x in xs], dtype=np.uint64)
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(self.dev)
-        # the witness crosses PCIe ONCE; the three scalar vectors are assembled from it on the device
+        # the witness crosses PCIe ONCE; the scalar vectors are assembled from it on the device
         d_w = up(w_reg)
         pick = lambda keep: d_w if keep is None else d_w[torch.from_numpy(np.nonzero(keep)[0]).to(self.dev)]
         sc_a = torch.cat([pick(self.keep_a), up(tail(1, r))])
         sc_b = torch.cat([pick(self.keep_b), up(tail(1, s))])
-        bs2 = torch.zeros(17, dtype=torch.int64, device=self.dev)
-        torch.cuda.current_stream(self.dev).synchronize()     # torch built the operands on ITS stream; the kernels run on the contexts'
-        self.ctx2._check(self.ctx._lib.zklc_bn254_g2_msm_dev(self.ctx2._h, self.ctx2.stream_ptr(), self.d_B2.data_ptr(), sc_b.data_ptr(),
-                                                             self.d_B2.shape[0], bs2.data_ptr(), bs2.data_ptr() + 128, self.ws2.data_ptr(),
-                                                             self.ws2.numel()))
-        ar, ar_inf = self._msm1(self.d_A, sc_a, self.d_A.shape[0])
-        bs1, bs1_inf = self._msm1(self.d_B1, sc_b, self.d_B1.shape[0])
-        # Krs: the points Ar and Bs1 of this proof go into the two free slots before delta
-        nk = self.d_KZ.shape[0]
-        self.ctx.synchronize()                                # Ar, Bs1, h are complete before torch touches them
-        self.d_KZ[nk - 3] = ar
-        self.d_KZ[nk - 2] = bs1
-        sc_k = torch.cat([d_w[1 + self.n_public:], d_h[:self.n - 1], up(tail(s, r, (R - r * s % R) % R))])
-        torch.cuda.current_stream(self.dev).synchronize()
-        krs, krs_inf = self._msm1(self.d_KZ, sc_k, nk)
-        self.ctx.synchronize()
-        self.ctx2.synchronize()
+        self.sc_k[:self.n_priv] = d_w[1 + self.n_public:]
+        outs = {k: torch.zeros(16 if k == "B2" else 8, dtype=torch.int64, device=self.dev) for k in ("A", "B1", "B2", "KZ")}
+        infs = {k: torch.zeros(1, dtype=torch.int32, device=self.dev) for k in outs}
+        tsync()
+        t1 = time.perf_counter()
+        # stream 2: Bs = beta + sum_i w_i B_i + s delta (G2);  stream 1: Ar, then Bs1
+        self._msm(self.ctx2, "B2", sc_b, outs["B2"], infs["B2"], self.ws2, group=2)
+        self._msm(self.ctx, "A", sc_a, outs["A"], infs["A"], self.ws1)
+        self._msm(self.ctx, "B1", sc_b, outs["B1"], infs["B1"], self.ws1)
+        # stream 3: computeH (the three operands cross PCIe while the sums above run), then the K / Z part of Krs
+        d = [up(x) for x in abc_mont]
+        tsync()
+        self._compute_h_enqueue(d, self.ctx3)
+        self.ctx3.synchronize()
+        self.sc_k[self.n_priv:] = d[0][:self.n - 1]
+        tsync()
         t2 = time.perf_counter()
-        if int(ar_inf[0]) or int(krs_inf[0]) or int(bs2[16]) or int(bs1_inf[0]):
+        self._msm(self.ctx3, "KZ", self.sc_k, outs["KZ"], infs["KZ"], self.ws3)
+        self.ctx.synchronize()
+        self.ctx3.synchronize()
+        if int(infs["A"][0]) or int(infs["B1"][0]):
             raise ValueError("groth16: a proof element is the point at infinity (degenerate key or witness)")
-        a_w, k_w, b_w = ar.cpu().numpy().view(np.uint64), krs.cpu().numpy().view(np.uint64), bs2[:16].cpu().numpy().view(np.uint64)
+        # Krs = (sum_priv w_i K_i + sum_j h_j Z_j) + s Ar + r Bs1 - r s delta1: four points, through the same kernels
+        h = lambda t: t.cpu().numpy().view(np.uint64)
+        kz = np.zeros(8, np.uint64) if int(infs["KZ"][0]) else h(outs["KZ"])
+        pts4 = np.stack([kz, h(outs["A"]), h(outs["B1"]), self.delta1_words])
+        k_w, k_inf = self.ctx.bn254_g1_msm(pts4, tail(1, s, r, (R - r * s % R) % R))
+        self.ctx2.synchronize()
+        t3 = time.perf_counter()
+        if k_inf or int(infs["B2"][0]):
+            raise ValueError("groth16: a proof element is the point at infinity (degenerate key or witness)")
+        a_w, b_w = h(outs["A"]), h(outs["B2"])
         f = fp_from_mont_words
         proof = [f(a_w[0:4]), f(a_w[4:8]), f(b_w[4:8]), f(b_w[0:4]), f(b_w[12:16]), f(b_w[8:12]), f(k_w[0:4]), f(k_w[4:8])]
-        self.last_ms = {"compute_h": (t1 - t0) * 1e3, "msm": (t2 - t1) * 1e3}
+        self.last_ms = {"witness_upload_and_scalars": (t1 - t0) * 1e3, "compute_h_beside_A_B1_B2": (t2 - t1) * 1e3,
+                        "kz_and_tails": (t3 - t2) * 1e3, "total": (t3 - t0) * 1e3, "fixed_base": self.fixed}
         return proof
 
 

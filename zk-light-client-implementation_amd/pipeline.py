@@ -162,10 +162,12 @@ class BlockResult:
 
 class BlockPipeline:
     def __init__(self, device_id=0, prove_streams=4, witness_batch=32, host_witness=False, rank=0, world=1, comm_device=None,
-                 host_threads=None, wrap=True):
+                 host_threads=None, wrap=True, device_share=1):
         """One per process (= per GPU rank).  prove_streams: proofs in flight (prove_streams - 1 Ed25519 provers + the fold
         stream); witness_batch: signatures per device witness batch (<= 64; 0.49 GB of HBM each, two buffers per message length).
-        rank / world / comm_device: the torch.distributed position for the strong form (collectives on `comm_device`)."""
+        rank / world / comm_device: the torch.distributed position for the strong form (collectives on `comm_device`).
+        device_share: processes that share THIS device (functional multi-rank runs on a one-GPU box): the wire-matrix buffers are
+        sized so that all of them fit (two buffers instead of three, the batch divided by the share)."""
         import zklc_amd
         from .keys_stakes import KeysStakesProver
         from .plonky2 import HASH_BN128, HASH_GL
@@ -181,9 +183,10 @@ class BlockPipeline:
         # produced once the previous block's last batch is fully proven.  Three buffers keep a batch ahead: 5.46 -> 5.18 s per block
         # on one box (profiles/r06k_*; within the noise on a second, r06l_*); giving the producer's stream the device's high priority on top measured WORSE (5.39-5.58 s)
         # and stays off.   ZKLC_WIT_BUFS / ZKLC_WIT_PRIORITY=1: A/B
-        self.nbuf = max(2, int(os.environ.get("ZKLC_WIT_BUFS", "3")))
+        self.device_share = max(1, int(device_share))
+        self.nbuf = max(2, int(os.environ.get("ZKLC_WIT_BUFS", "3" if self.device_share == 1 else "2")))
         if self.dev_wit:
-            self.wchunk = max(1, min(64, int(witness_batch)))
+            self.wchunk = max(1, min(64, int(witness_batch) // self.device_share))
         else:
             cores = host_threads or len(os.sched_getaffinity(0))
             self.wchunk = max(1, min(12 if world == 1 else 6, cores // max(1, world) - self.nthreads))
