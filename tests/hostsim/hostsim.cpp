@@ -698,6 +698,22 @@ u32 hostsim_gl_ntt_group(u32 g, u32 dit, u32 inverse, u32 logn, u32 s_first, u64
 #undef GRP
     return 0;
 }
+// The zero-aware first group of an 8x LDE (gl_ntt_group_regs<G, false, false, 3>): x holds 2^g values of which only the first
+// 2^(g - 3) are taken (the others are the zero padding and are NOT read); general: the general group on the same values padded with
+// zeros.  Returns the number of elements (0 = unsupported g).
+u32 hostsim_gl_ntt_group_zero_padded(u32 g, u32 logn, u32 s_first, u64 J, u64 *x, u64 *general) {
+    u64 w = gl_root_of_unity(logn);
+    const u32 M = 1u << g;
+    u64 tab[16];
+    for (u32 m = 1; m < M; m++) tab[m - 1] = gl_pow(w, ((u64)gl_bitrev_small(m, (int)g) * J) << s_first);
+    for (u32 m = 0; m < M; m++) general[m] = m < (M >> 3) ? x[m] : 0;
+    for (u32 m = (M >> 3); m < M; m++) x[m] = 0xDEADBEEFDEADBEEFull;          // must not be read
+    switch (g) {
+        case 3: gl_ntt_group_regs<3, false, false>(general, tab); gl_ntt_group_regs<3, false, false, 3>(x, tab); return M;
+        case 4: gl_ntt_group_regs<4, false, false>(general, tab); gl_ntt_group_regs<4, false, false, 3>(x, tab); return M;
+    }
+    return 0;
+}
 u32 hostsim_g2_op(int op, const u32 *p32, const u32 *q32, u32 *out32) {
     g2_xyzz a;
     a.X = fp2_reduce(fp2_from_gnark(p32));

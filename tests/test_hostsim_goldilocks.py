@@ -130,6 +130,27 @@ def test_ntt_group_shift_twiddles_equal_the_definition(hostsim):
                     assert list(x) == list(pl), (g, dit, inverse, logn, s_first, J)
 
 
+def test_ntt_group_zero_padded_form_equals_the_general_group(hostsim):
+    """the first group of an 8x LDE's first pass (round 6): with the top three index bits of the input known to be zero the group
+    evaluates only the butterflies that have a non-zero input, never reads the padded positions, and gives the general group's
+    sixteen (eight) values"""
+    rng = random.Random(11)
+    f = hostsim.hostsim_gl_ntt_group_zero_padded
+    f.restype = ctypes.c_uint32
+    f.argtypes = [ctypes.c_uint32] * 3 + [ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
+    edge = [0, 1, P - 1, 2**32 - 1, 2**32, P - 2**32]
+    for g in (3, 4):
+        for _ in range(40):
+            logn = rng.randrange(g, 25)
+            J = rng.randrange(1 << (logn - g))
+            m = 1 << g
+            xs = [rng.choice(edge + [rng.randrange(P)] * 3) for _ in range(m)]
+            x = (ctypes.c_uint64 * m)(*xs)
+            ge = (ctypes.c_uint64 * m)()
+            assert f(g, logn, 0, J, x, ge) == m
+            assert list(x) == list(ge), (g, logn, J, xs[:m >> 3])
+
+
 def test_poseidon_asm_generator_selftest_and_committed_file_is_current():
     """csrc/poseidon_gl_asm.inc (the hand-scheduled gfx950 statements of the permutation) is generated by
     tools/gen_poseidon_asm.py: every instruction list is executed by the generator's simulator against big-integer arithmetic

@@ -62,6 +62,7 @@ struct ntt_pass {
     // offset of the group's block in the table of per-element twiddles (gl_get_group_twiddles)
     int ng, gsz[4];
     u64 goff[4];
+    int zskip_ok;      // the zero-aware first group of an 8x LDE may be used (off: ZKLC_NTT_ZSKIP=0)
 };
 
 template <bool DIT>
@@ -244,7 +245,7 @@ gl_ntt_pass_r8_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t 
 // 15 general multiplications + 17 shifts per 32 butterflies instead of 32 multiplications, and ceil(k / 4) LDS round trips per
 // pass.  LDS tile padded by one element per 16 (unit-stride and stride-16 / stride-8 groups all spread over the banks).
 #define NTT_TJ(e) ((e) + ((e) >> 4))
-template <int G, bool DIT, bool INV>
+template <int G, bool DIT, bool INV, int ZP = 0>
 ZKLC_D void gl_ntt_group_lds(u64 *tile, const u64 *__restrict__ tabJ, u64 nj, u32 base, int pb_low) {
     constexpr int M = 1 << G;
     u64 x[M], t[M - 1 > 0 ? M - 1 : 1];
@@ -252,9 +253,13 @@ ZKLC_D void gl_ntt_group_lds(u64 *tile, const u64 *__restrict__ tabJ, u64 nj, u3
     for (int m = 1; m < M; m++) t[m - 1] = tabJ[(u64)(m - 1) * nj];
     // NTT_TJ is additive over disjoint bit fields: the lane's part once, the group-index part is wave-uniform (scalar)
     const u32 tjb = NTT_TJ(base);
+    // ZP: only the first 2^(G - ZP) elements of the group exist (zero padding of an LDE): the others are neither read nor were
+    // they written by the tile load
 #pragma unroll
-    for (int m = 0; m < M; m++) x[m] = tile[tjb + NTT_TJ((u32)m << pb_low)];
-    gl_ntt_group_regs<G, DIT, INV>(x, t);
+    for (int m = 0; m < (M >> ZP); m++) x[m] = tile[tjb + NTT_TJ((u32)m << pb_low)];
+#pragma unroll
+    for (int m = (M >> ZP); m < M; m++) x[m] = 0;
+    gl_ntt_group_regs<G, DIT, INV, ZP>(x, t);
 #pragma unroll
     for (int m = 0; m < M; m++) tile[tjb + NTT_TJ((u32)m << pb_low)] = x[m];
 }
@@ -294,17 +299,26 @@ gl_ntt_pass_g4_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t 
     const u64 g_tid = global_index(tid);
     const u32 lds_tid = NTT_TJ(tid);
     const bool lane_in = tid < (u32)tile_n;               // tiles smaller than the workgroup (small transforms)
+    // Zero padding of an 8x LDE (round 6): the first pass of a DIF transform sees its window bits on top, so the padded positions
+    // are the elements e >= tile_n / 8 of every tile.  When the first group spans all three padded bits it runs in its
+    // zero-aware form (goldilocks_ntt_group.cuh, ZP = 3): the padded seven eighths of the tile are neither loaded, scaled (two
+    // multiplications per element that produced zeros) nor written to LDS -- the first group writes every position before the
+    // second group reads any.  ZKLC_NTT_ZSKIP=0: the general form (A/B).
+    bool zskip = false;
+    if constexpr (!DIT) zskip = p.s0 == 0 && p.d == 0 && p.logn - p.log_in == 3 && p.gsz[0] >= 3 && p.zskip_ok;
+    const u32 load_n = zskip ? (u32)tile_n >> 3 : (u32)tile_n;
     {
         constexpr int LD = 8;
         const u64 lim = 1ULL << p.log_in;
-        for (u32 hi0 = 0; hi0 < (u32)tile_n; hi0 += LD * n_threads) {
+        const bool lane_ld = tid < load_n;
+        for (u32 hi0 = 0; hi0 < load_n; hi0 += LD * n_threads) {
             u64 g[LD], v[LD], sh[LD], sl[LD];
 #pragma unroll
             for (int q = 0; q < LD; q++) {
                 const u32 hi = hi0 + q * n_threads;                      // wave-uniform
-                g[q] = hi < (u32)tile_n ? (g_tid | global_index(hi)) : g_tid;
+                g[q] = hi < load_n ? (g_tid | global_index(hi)) : g_tid;
                 v[q] = 0;
-                if (lane_in && g[q] < lim) v[q] = src[g[q]];          // predicated, still all in flight: nothing below waits before the batch is issued
+                if (lane_ld && g[q] < lim) v[q] = src[g[q]];          // predicated, still all in flight: nothing below waits before the batch is issued
             }
             if (p.scale_shift) {
 #pragma unroll
@@ -317,7 +331,7 @@ gl_ntt_pass_g4_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t 
 #pragma unroll
             for (int q = 0; q < LD; q++) {
                 const u32 hi = hi0 + q * n_threads;
-                if (hi >= (u32)tile_n || !lane_in) continue;
+                if (hi >= load_n || !lane_ld) continue;
                 u64 x = g[q] < lim ? v[q] : 0;
                 if (p.scale_shift) x = gl_mul(x, gl_mul(sh[q], sl[q]));
                 tile[lds_tid + NTT_TJ(hi)] = x;
@@ -341,6 +355,15 @@ gl_ntt_pass_g4_kernel(const u64 *__restrict__ in, u64 *__restrict__ out, size_t 
             u64 lowc = base & ((1u << p.c) - 1);
             u64 mid_low = (base >> p.c) & ((1u << mg) - 1);
             u64 J = (mid_low << lowbits) | ((tileL << p.c) | lowc);
+            if constexpr (!DIT) {
+                if (zskip && gi_ == 0) {               // wave-uniform
+                    if (g == 4)
+                        gl_ntt_group_lds<4, DIT, INV, 3>(tile, gtab + J, nj, base, pb_low);
+                    else
+                        gl_ntt_group_lds<3, DIT, INV, 3>(tile, gtab + J, nj, base, pb_low);
+                    continue;
+                }
+            }
             if (g == 4)
                 gl_ntt_group_lds<4, DIT, INV>(tile, gtab + J, nj, base, pb_low);
             else if (g == 3)
@@ -754,6 +777,8 @@ static int32_t gl_ntt_run(zklc_ctx *ctx, hipStream_t st, const u64 *in, size_t i
         p.log_in = first ? log_in : logn;
         p.scale_shift = (first && load_shift) ? GL_SCALE_LO_LOG : 0;
         p.out_scale = last ? n_inv : 1;
+        static const bool zskip_on = !(getenv("ZKLC_NTT_ZSKIP") && getenv("ZKLC_NTT_ZSKIP")[0] == '0');
+        p.zskip_ok = zskip_on ? 1 : 0;
         p.ng = ng_of[i];
         for (int j = 0; j < 4; j++) {
             p.gsz[j] = j < ng_of[i] ? gsz_of[i][j] : 0;

@@ -94,9 +94,16 @@ ZKLC_HD constexpr u32 gl_bitrev_small(u32 m, int g) {
 // the g stages of one group on the M = 2^g values x[] of a lane.  t[m - 1] = T^(bitrev_g(m)) = w^((bitrev_g(m) * J) << s'): the
 // lane's M - 1 entries of the group's table block, fetched by the caller BEFORE it reads x (all loads in flight at once; left to
 // the compiler they were issued one by one in front of their multiplication, each behind its own s_waitcnt vmcnt(0)).
-template <int G, bool DIT, bool INV>
+//
+// ZP > 0 (DIF only, the FIRST group of an LDE's first pass, round 6): the top ZP index bits of the input are known to be zero (the
+// coefficients of a degree-2^log_in polynomial padded to 2^(log_in + ZP)), i.e. only x[m], m < 2^(G - ZP), are non-zero on entry.
+// A butterfly of stage u < ZP then has b = 0: x[m] stays, x[m | bit] = +-a * 2^e -- one shift instead of add + sub + shift -- and
+// the butterflies whose two inputs are both zero are not evaluated at all (G = 4, ZP = 3: 2 + 4 + 8 shifts and the 8 butterflies
+// of the last stage instead of 32 butterflies).  x[m] for m >= 2^(G - ZP) need not be initialised.
+template <int G, bool DIT, bool INV, int ZP = 0>
 ZKLC_HD void gl_ntt_group_regs(u64 *x, const u64 *t) {
     constexpr int M = 1 << G;
+    static_assert(ZP >= 0 && ZP <= G && (ZP == 0 || !DIT), "zero-padded form: DIF groups only");
     if (DIT) gl_mul_batch<M - 1>(x + 1, t);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -113,6 +120,14 @@ ZKLC_HD void gl_ntt_group_regs(u64 *x, const u64 *t) {
             const u32 e = gl_omega_log2(G, lp << u, INV);   // omega_M^(lp << u) = 2^e, e < 192
             const bool neg = e >= 96;                          // 2^96 = -1
             const u32 sh = neg ? e - 96 : e;
+            if (u < ZP) {
+                // the inputs that can be non-zero at this stage: bits (G - ZP) .. bit of m are all zero
+                const int zmask = ((1 << (bit + 1)) - 1) & ~((1 << (G - ZP)) - 1);
+                if (m & zmask) continue;
+                const u64 a0 = x[m];
+                x[m | (1 << bit)] = gl_mul_2exp(neg ? gl_sub(0, a0) : a0, sh);
+                continue;
+            }
             u64 a = x[m], b = x[m | (1 << bit)];
             if (DIT) {
                 b = gl_mul_2exp(b, sh);
