@@ -452,7 +452,7 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
         res["lde"]["roofline"]["valu"] = valu_block(pl_["valu_wave_instructions_per_lde"], ms, "all passes of one extension, "
                                                                                                 "profiles/lde_pmc_latest.json", "lde")
     # the PRODUCT shape: every commitment of the Ed25519 circuit extends 2^18 -> 2^21 (prove_crypto/ed25519.rs:60), the less efficient
-    # case of the two: PMC at this shape in profiles/r05a_lde_pmc_2p18_to_2p21.json
+    # case of the two: PMC at this shape in profiles/lde_pmc_2p18_latest.json
     try:
         c18 = torch.randint(0, 2**63 - 1, (batch, 1 << 18), generator=g, device=dev, dtype=torch.int64)
         l21 = torch.empty((batch, 1 << 21), dtype=torch.int64, device=dev)
@@ -464,11 +464,11 @@ def run_stages(args, ctx, dev, stream, rank, world, with_cpu):
                            "unit": "GB/s", "ms": ms18,
                            "roofline": {"bound": "hbm", "achieved": alg18 / (ms18 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                         "frac": alg18 / (ms18 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None}}
-        p18 = pmc_json("r05a_lde_pmc_2p18_to_2p21.json")
+        p18 = pmc_json("lde_pmc_2p18_latest.json")
         if p18 is not None:
             res["lde_2p18"]["roofline"]["traffic"] = p18.get("hbm_bytes_per_lde")
             res["lde_2p18"]["roofline"]["valu"] = valu_block(p18["valu_wave_instructions_per_lde"], ms18, "all passes of one extension, "
-                                                             "profiles/r05a_lde_pmc_2p18_to_2p21.json", "lde")
+                                                             "profiles/lde_pmc_2p18_latest.json", "lde")
         del c18, l21
     except KeyError:
         pass
