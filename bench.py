@@ -31,6 +31,7 @@ import json
 import os
 import sys
 import time
+import threading
 T_PROCESS_START = time.perf_counter()
 # before anything can initialise the HIP runtime (torch, the library): one hardware queue per stream of the pipeline (zklc_amd/__init__.py)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -861,6 +862,39 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
             return {"loadavg": [float(x) for x in la], "cpus_allowed": len(os.sched_getaffinity(0)), "cpus_online": os.cpu_count()}
         except (OSError, ValueError):
             return {}
+    # The collector's pauses stop EVERY Python thread of the pipeline (the streams then drain: GPU idle): measured here (gc.callbacks);
+    # prove_stream replaces the automatic collections by one young-generation collection per block (ZKLC_STREAM_GC=auto: A/B)
+    gc_mode = os.environ.get("ZKLC_STREAM_GC", "block") if overlap else "auto"
+    gc_stat = {"n": [0, 0, 0], "s": [0.0, 0.0, 0.0], "max_s": 0.0, "t0": 0.0}
+
+    def gc_cb(phase, info):
+        if phase == "start":
+            gc_stat["t0"] = time.perf_counter()
+        else:
+            dt_, g_ = time.perf_counter() - gc_stat["t0"], min(2, int(info.get("generation", 0)))
+            gc_stat["n"][g_] += 1
+            gc_stat["s"][g_] += dt_
+            gc_stat["max_s"] = max(gc_stat["max_s"], dt_)
+    gc.callbacks.append(gc_cb)
+    # interpreter-wide stalls, whatever their cause (collector, a C call that keeps the GIL, a descheduled process on a shared host):
+    # a thread that asks for 2 ms of sleep and records by how much it overslept
+    stall = {"late_s": 0.0, "n5": 0, "n20": 0, "n100": 0, "max_s": 0.0, "stop": False}
+
+    def stall_probe():
+        t_ = time.perf_counter()
+        while not stall["stop"]:
+            time.sleep(0.002)
+            t2_ = time.perf_counter()
+            late = t2_ - t_ - 0.002
+            t_ = t2_
+            if late > 0.005:
+                stall["late_s"] += late
+                stall["n5"] += 1
+                stall["n20"] += late > 0.02
+                stall["n100"] += late > 0.1
+                stall["max_s"] = max(stall["max_s"], late)
+    stall_th = threading.Thread(target=stall_probe, daemon=True)
+    stall_th.start()
     load0 = host_load()
     clk0 = clocks_ns()
     cpu_all = time.process_time()
@@ -877,6 +911,9 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                 block_done(r)
     barrier()
     total_s = reduce_max(time.perf_counter() - t_all)
+    gc.callbacks.remove(gc_cb)
+    stall["stop"] = True
+    stall_th.join()
     clk1 = clocks_ns()
     cpu_all = time.process_time() - cpu_all        # user + system seconds of THIS rank's process (all threads) over the timed blocks
     block_s = total_s / steps
@@ -923,7 +960,12 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                       "timed_region_clock_ns": {k: [clk0[k], clk1[k]] for k in clk0},
                       "host_load_before": load0, "host_load_after": host_load(),
                       "hbm_used_gb": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1),   # the whole device, all processes
-                      "witness_buffers": pipe.nbuf, "device_share": pipe.device_share}
+                      "witness_buffers": pipe.nbuf, "device_share": pipe.device_share,
+                      "gc": {"mode": gc_mode, "switch_interval_ms": os.environ.get("ZKLC_SWITCH_INTERVAL_MS", "0.5") if overlap else None, "collections_by_generation": gc_stat["n"], "pause_s_by_generation": [round(x, 3) for x in gc_stat["s"]],
+                             "pause_s_per_block": round(sum(gc_stat["s"]) / steps, 4), "max_pause_s": round(gc_stat["max_s"], 4)},
+                      "interpreter_stalls": {"late_s_per_block": round(stall["late_s"] / steps, 4), "over_5ms": stall["n5"], "over_20ms": int(stall["n20"]),
+                                             "over_100ms": int(stall["n100"]), "max_s": round(stall["max_s"], 4),
+                                             "note": "a 2 ms sleeper's oversleep beyond 5 ms, summed: time in which no Python thread of the pipeline could run"}}
     if world > 1 and not strong_only and not args.no_strong_section:
         # the STRONG form of the block measured in the same run, so that one SCALE run holds both: all ranks prove
         # ONE block per step (signature shards, local folds, a binary-tree fold over the ranks, the header proofs on the other ranks,

@@ -224,3 +224,31 @@ def test_prove_stream_delivers_the_blocks_before_a_failed_one_and_raises(monkeyp
     assert err is not None and "block 1" in str(err)
     assert len(done) == 1                                                         # block 0 was delivered, nothing after it
     assert not any(e[2] == 3 for e in log), "the stream went on after the failed block"
+
+
+def test_prove_stream_host_policy_is_scoped_to_the_stream(monkeypatch):
+    """for the duration of a stream the automatic collections are replaced by one young-generation collection per delivered block
+    and the switch interval is what ZKLC_SWITCH_INTERVAL_MS says; both are the caller's again afterwards -- also after a failed
+    stream -- and ZKLC_STREAM_GC=auto leaves the collector alone"""
+    import gc
+    import sys
+    seen = []
+    real_collect = gc.collect
+    monkeypatch.setattr(gc, "collect", lambda *a: (seen.append((a, gc.isenabled(), sys.getswitchinterval())), real_collect(*a))[1])
+    monkeypatch.setenv("ZKLC_SWITCH_INTERVAL_MS", "1")
+    sw0 = sys.getswitchinterval()
+    assert gc.isenabled()
+    p, log, res, done, err = _fake_stream(3, monkeypatch=monkeypatch)
+    assert err is None and len(done) == 3
+    assert [s for s in seen if s[0] == (1,)] == [((1,), False, 0.001)] * 3       # one per block, collector off, interval set
+    assert gc.isenabled() and sys.getswitchinterval() == sw0
+    seen.clear()
+    p, log, res, done, err = _fake_stream(3, fail_block=1, monkeypatch=monkeypatch)
+    assert err is not None and gc.isenabled() and sys.getswitchinterval() == sw0
+    seen.clear()
+    monkeypatch.setenv("ZKLC_STREAM_GC", "auto")
+    monkeypatch.setenv("ZKLC_SWITCH_INTERVAL_MS", "0")
+    inside = []
+    real_new_state = None
+    p, log, res, done, err = _fake_stream(2, monkeypatch=monkeypatch)
+    assert err is None and not [s for s in seen if s[0] == (1,)] and gc.isenabled() and sys.getswitchinterval() == sw0

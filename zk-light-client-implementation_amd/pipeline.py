@@ -27,6 +27,7 @@ ranks, joins and wrap on rank 0.  No data-path collective in the weak form (ever
 """
 import hashlib
 import os
+import sys
 import queue
 import threading
 import time
@@ -606,7 +607,41 @@ class BlockPipeline:
         the last signature proof): once the faster leaf hash of round 6 had made the serial chains the longer path, the GPU idled
         between blocks (87-95 % busy, block latencies of 9-12 s: profiles/r06c_*, r06e_*).
         Returns the BlockResults in order; `on_block_done(result)` is called as each block completes.  A block that fails ends the
-        stream: the blocks before it are delivered, its error is raised, the block started after it is abandoned."""
+        stream: the blocks before it are delivered, its error is raised, the block started after it is abandoned.
+
+        Host policy for the duration of the stream (round 6, profiles/r06r_gc_ab.txt; both restored on return): the cyclic
+        collector's automatic runs stop EVERY thread of the pipeline -- measured 0.25-0.29 s of pauses per block, five full
+        collections of ~40 ms among them, which are the > 20 ms holes of the kernel trace -- so they are replaced by ONE
+        young-generation collection per delivered block (ZKLC_STREAM_GC=auto keeps the interpreter's thresholds: 5.83 s per block
+        against 5.2-5.5 on one box, the GPU 86 % instead of 91-96 % busy);
+        the interpreter's thread switch interval is 0.5 ms instead of 5 ms (ZKLC_SWITCH_INTERVAL_MS; 0 = leave it): a worker that
+        returns from a proof waits up to one interval for the GIL while another thread runs Python -- a 2 ms sleeper overslept
+        0.34 s per block in total at 5 ms and 0.07 s at 0.5 ms; the block time moved inside the run-to-run noise (mid-run mean
+        5.31 -> 5.17 s, profiles/r06s_switch_interval_ab.txt)."""
+        import gc
+        mode, sw = os.environ.get("ZKLC_STREAM_GC", "block"), os.environ.get("ZKLC_SWITCH_INTERVAL_MS", "0.5")
+        sw = sw if float(sw) > 0 else None
+        manual = mode == "block" and gc.isenabled()
+        old_sw = sys.getswitchinterval()
+        cb = on_block_done
+        if manual:
+            gc.disable()
+
+            def cb(res):
+                if on_block_done:
+                    on_block_done(res)
+                gc.collect(1)
+        if sw:
+            sys.setswitchinterval(float(sw) / 1e3)
+        try:
+            return self._prove_stream(windows, cb)
+        finally:
+            if manual:
+                gc.enable()
+            if sw:
+                sys.setswitchinterval(old_sw)
+
+    def _prove_stream(self, windows, on_block_done):
         results, prev_dag, prev_st = [], [], None
         prev_fold, prev_ks, prev_hdr, prev_sig, all_threads = [], [], [], None, []
         # A/B (ZKLC_STREAM, a comma list; default "fold,hdr,ahead"; "stages" = none of them = rounds 3-5): fold = the fold and keys /
