@@ -895,10 +895,37 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
                 stall["max_s"] = max(stall["max_s"], late)
     stall_th = threading.Thread(target=stall_probe, daemon=True)
     stall_th.start()
+    # diagnostic (ZKLC_BENCH_SAMPLE=<file>): every 20 ms where each pipeline thread is (innermost frame inside this repo), written as
+    # JSON lines [t, {thread: "file:line"}] -- which worker waits where while a prover queue of the kernel trace is idle
+    sampler = {"stop": False, "rows": []}
+
+    def sample_threads():
+        names = {}
+        while not sampler["stop"]:
+            time.sleep(0.02)
+            for th in threading.enumerate():
+                names[th.ident] = th.name
+            row = {}
+            for ident, fr in sys._current_frames().items():
+                nm = names.get(ident, "")
+                if not nm.startswith("zklc-") and nm != "MainThread":
+                    continue
+                inner = "%s:%d" % (os.path.basename(fr.f_code.co_filename), fr.f_lineno)
+                f2 = fr
+                while f2 is not None and ROOT not in f2.f_code.co_filename:
+                    f2 = f2.f_back
+                ours = "%s:%d" % (os.path.basename(f2.f_code.co_filename), f2.f_lineno) if f2 is not None else "?"
+                row[nm] = ours if ours == inner else ours + "<" + inner
+            sampler["rows"].append([round(time.perf_counter() - t_all, 3), row])
+    sample_th = None
+    if os.environ.get("ZKLC_BENCH_SAMPLE"):
+        sample_th = threading.Thread(target=sample_threads, daemon=True)
     load0 = host_load()
     clk0 = clocks_ns()
     cpu_all = time.process_time()
     t_all = time.perf_counter()
+    if sample_th is not None:
+        sample_th.start()
     if overlap:
         # exactly K complete Block_i proofs; consecutive blocks overlap by the tail of the earlier one (BlockPipeline.prove_stream)
         res_list = pipe.prove_stream([window] * steps, block_done)
@@ -914,6 +941,12 @@ def run_prove_stage(args, ctx, dev, stream, rank, world, barrier, reduce_max):
     gc.callbacks.remove(gc_cb)
     stall["stop"] = True
     stall_th.join()
+    if sample_th is not None:
+        sampler["stop"] = True
+        sample_th.join()
+        with open(os.environ["ZKLC_BENCH_SAMPLE"], "w") as f_:
+            for row in sampler["rows"]:
+                f_.write(json.dumps(row) + "\n")
     clk1 = clocks_ns()
     cpu_all = time.process_time() - cpu_all        # user + system seconds of THIS rank's process (all threads) over the timed blocks
     block_s = total_s / steps

@@ -457,8 +457,16 @@ class BlockPipeline:
             self._fail(st, e)
 
     # ------------------------------------------------------------------------------------------------ stages
+    @staticmethod
+    def _thread_name(f, a):
+        # worker threads carry their role in their name (diagnostics: bench.py's ZKLC_BENCH_SAMPLE reads it)
+        if getattr(f, "__name__", "") == "_after" and len(a) == 3:
+            f, a = a[1], a[2]
+        n = getattr(f, "__name__", "worker").lstrip("_")
+        return "zklc-%s%s" % (n, "-%d" % a[1] if n == "ed_worker" and len(a) > 1 else "")
+
     def _start(self, fns):
-        ths = [threading.Thread(target=f, args=a) for f, a in fns]
+        ths = [threading.Thread(target=f, args=a, name=self._thread_name(f, a)) for f, a in fns]
         for th in ths:
             th.start()
         return ths
