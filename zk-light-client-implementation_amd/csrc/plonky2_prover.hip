@@ -1140,7 +1140,7 @@ static int32_t p2_commit_coeffs(zklc_plonky2_circuit *c, hipStream_t st, p2_batc
     u32 cap_h = c->P.cap_height < c->lde_bits ? c->P.cap_height : c->lde_bits;
     cap.resize((size_t)32 << cap_h);
     P2_PIN(c, h_cap, uint8_t, cap.size());
-    ZKLC_HIP(ctx, hipMemcpyAsync(h_cap, p2_tree_level(b.tree, c->lde_bits, c->lde_bits - cap_h), cap.size(), hipMemcpyDeviceToHost, st));
+    ZKLC_HIP(ctx, zklc_readback_async(h_cap, p2_tree_level(b.tree, c->lde_bits, c->lde_bits - cap_h), cap.size(), st));
     ZKLC_HIP(ctx, zklc_stream_wait(st));
     memcpy(cap.data(), h_cap, cap.size());
     return ZKLC_OK;
@@ -1169,7 +1169,7 @@ static int32_t p2_hash_no_pad(zklc_plonky2_circuit *c, hipStream_t st, const std
     memcpy(h_v + 4, v.data(), v.size() * 8);
     ZKLC_HIP(ctx, hipMemcpyAsync(dv + 8, h_v + 4, v.size() * 8, hipMemcpyHostToDevice, st));
     P2_RC(zklc_bn254_merkle_commit_strided(ctx, st, dv + 8, 1, 0, 0, (u32)v.size(), 0, dv));
-    ZKLC_HIP(ctx, hipMemcpyAsync(h_v, dv, 32, hipMemcpyDeviceToHost, st));
+    ZKLC_HIP(ctx, zklc_readback_async(h_v, dv, 32, st));
     ZKLC_HIP(ctx, zklc_stream_wait(st));
     memcpy(out32, h_v, 32);
     return ZKLC_OK;
@@ -1566,7 +1566,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
                            (const u64 *)c->d_totals, (const u64 *)c->d_rp, n, npp, c->zs.coeffs + (size_t)k * n,
                            c->zs.coeffs + (size_t)(nch + k * npp) * n);
         ZKLC_HIP(ctx, hipGetLastError());
-        ZKLC_HIP(ctx, hipMemcpyAsync(&grand[k], c->d_grand, 8, hipMemcpyDeviceToHost, st));
+        ZKLC_HIP(ctx, zklc_readback_async(&grand[k], c->d_grand, 8, st));
     }
     P2_RC(p2_commit_values(c, st, c->zs, zs_cap));
     for (u32 k = 0; k < nch; k++)
@@ -1694,7 +1694,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
         hipLaunchKernelGGL(p2_eval_finish_kernel, dim3((n_open + 255) / 256), dim3(256), 0, st, (const gl2 *)c->d_open_partial, n_open,
                            c->d_open);
         ZKLC_HIP(ctx, hipGetLastError());
-        ZKLC_HIP(ctx, hipMemcpyAsync(open, c->d_open, (size_t)n_open * sizeof(gl2), hipMemcpyDeviceToHost, st));
+        ZKLC_HIP(ctx, zklc_readback_async(open, c->d_open, (size_t)n_open * sizeof(gl2), st));
         ZKLC_HIP(ctx, zklc_stream_wait(st));
     }
     // transcript order = FriOpenings: batch at zeta (constants, sigmas, wires, zs, partial products, quotient), then zs_next
@@ -1748,8 +1748,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
             u32 cap_h = P.cap_height < leaves_bits ? P.cap_height : leaves_bits;
             fri_caps[r].resize((size_t)32 << cap_h);
             P2_PIN(c, h_fcap, uint8_t, fri_caps[r].size());
-            ZKLC_HIP(ctx, hipMemcpyAsync(h_fcap, p2_tree_level(c->d_fri_tree[r], leaves_bits, leaves_bits - cap_h), fri_caps[r].size(),
-                                         hipMemcpyDeviceToHost, st));
+            ZKLC_HIP(ctx, zklc_readback_async(h_fcap, p2_tree_level(c->d_fri_tree[r], leaves_bits, leaves_bits - cap_h), fri_caps[r].size(), st));
             ZKLC_HIP(ctx, zklc_stream_wait(st));
             memcpy(fri_caps[r].data(), h_fcap, fri_caps[r].size());
             p2_observe_cap(ch, fri_caps[r], hasher);
@@ -1771,7 +1770,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
     }
     const size_t final_n = (size_t)1 << final_bits;
     P2_PIN(c, final_poly, gl2, final_n);
-    ZKLC_HIP(ctx, hipMemcpyAsync(final_poly, c->d_final, final_n * sizeof(gl2), hipMemcpyDeviceToHost, st));
+    ZKLC_HIP(ctx, zklc_readback_async(final_poly, c->d_final, final_n * sizeof(gl2), st));
     ZKLC_HIP(ctx, zklc_stream_wait(st));
     const u32 final_len = 1u << (final_bits - P.rate_bits);
     for (size_t i = final_len; i < final_n; i++)
@@ -1802,7 +1801,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
             a.base = base;
             hipLaunchKernelGGL(p2_pow_kernel, dim3((unsigned)(batch / P2_THREADS)), dim3(P2_THREADS), 0, st, a);
             ZKLC_HIP(ctx, hipGetLastError());
-            ZKLC_HIP(ctx, hipMemcpyAsync(h_found, c->d_found, 8, hipMemcpyDeviceToHost, st));
+            ZKLC_HIP(ctx, zklc_readback_async(h_found, c->d_found, 8, st));
             ZKLC_HIP(ctx, zklc_stream_wait(st));
             found = *h_found;
             if (found != ~0ULL) break;
@@ -1865,7 +1864,7 @@ extern "C" int32_t zklc_plonky2_prove_dev(zklc_ctx *ctx, void *stream, zklc_plon
         hipLaunchKernelGGL(p2_gather_kernel, dim3((unsigned)gs.size()), dim3(64), 0, st, (const p2_gather *)c->d_gather, (u32)gs.size(),
                            c->d_gather_out);
         ZKLC_HIP(ctx, hipGetLastError());
-        ZKLC_HIP(ctx, hipMemcpyAsync(qwords, c->d_gather_out, n_qwords * 8, hipMemcpyDeviceToHost, st));
+        ZKLC_HIP(ctx, zklc_readback_async(qwords, c->d_gather_out, n_qwords * 8, st));
         ZKLC_HIP(ctx, zklc_stream_wait(st));
     }
 

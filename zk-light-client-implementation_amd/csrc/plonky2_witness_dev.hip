@@ -491,6 +491,8 @@ extern "C" int32_t zklc_plonky2_witness_run_dev(zklc_ctx *ctx, void *stream, zkl
                            (const u32 *)p->d_pi_slots, p->n_pi, W, p->d_pis, p->d_err);
     ZKLC_HIP(ctx, hipGetLastError());
     unsigned long long errs[64];
+    // settled read-backs (zklc_internal.h): the copies are enqueued when the ~2 300 kernels of the batch have ended, not behind them
+    if (zklc_settled_copies()) ZKLC_HIP(ctx, zklc_stream_wait(st));
     if (p->n_pi) ZKLC_HIP(ctx, hipMemcpyAsync(p->h_pin + pi_off, p->d_pis, pi_bytes, hipMemcpyDeviceToHost, st));
     ZKLC_HIP(ctx, hipMemcpyAsync(p->h_pin + err_off, p->d_err, 64 * 8, hipMemcpyDeviceToHost, st));
     ZKLC_HIP(ctx, zklc_stream_wait(st));

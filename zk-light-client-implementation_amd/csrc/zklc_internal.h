@@ -115,6 +115,25 @@ inline hipError_t zklc_stream_wait(hipStream_t st) {
     return e;
 }
 
+// Device -> host read-back of a result the host is about to wait for.  Enqueued right behind the kernels that produce it, the copy
+// command sits in the runtime's DMA queue until those kernels have ended -- and copies of OTHER streams that the runtime put into the
+// same queue wait behind it (round 6, kernel trace cut by hardware queue: two of the three Ed25519 prover streams stood still for
+// 0.6-1.0 s, between their proof-of-work kernel and the gather of the query openings, exactly as long as the witness producer's
+// batch -- 2 300 small kernels with the read-back of its public inputs enqueued behind them -- was running; the third prover
+// stream, on another queue, went on).  So: wait for the stream FIRST, then enqueue the copy (it runs at once), then the caller waits
+// for it as before.  ZKLC_SETTLED_COPIES=0 restores the enqueue-behind-the-kernels form (A/B).
+inline bool zklc_settled_copies() {
+    static const bool on = !(getenv("ZKLC_SETTLED_COPIES") && getenv("ZKLC_SETTLED_COPIES")[0] == '0');
+    return on;
+}
+inline hipError_t zklc_readback_async(void *dst, const void *src, size_t bytes, hipStream_t st) {
+    if (zklc_settled_copies()) {
+        hipError_t e = zklc_stream_wait(st);
+        if (e != hipSuccess) return e;
+    }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+}
+
 // returns a device buffer of at least `bytes` in slot `slot`
 int32_t zklc_stage(zklc_ctx *ctx, int slot, size_t bytes, void **out);
 // *_dev entry points launch on exactly the hipStream_t they are given (NULL = the legacy default stream)
