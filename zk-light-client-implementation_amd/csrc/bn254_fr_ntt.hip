@@ -253,7 +253,7 @@ extern "C" int32_t zklc_bn254_fr_ntt(zklc_ctx *ctx, uint64_t *data, uint32_t log
     if ((rc = zklc_stage(ctx, 1, wb, &w))) return rc;
     ZKLC_HIP(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = zklc_bn254_fr_ntt_dev(ctx, ctx->stream, (uint64_t *)d, log_n, flags, coset, w, wb))) return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, zklc_readback_async(data, d, bytes, ctx->stream));
     ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }

@@ -635,8 +635,8 @@ static int32_t msm_run_host(zklc_ctx *ctx, const uint64_t *points, const uint64_
     rc = msm_run_dev<F>(ctx, ctx->stream, (const uint64_t *)dp, (const uint64_t *)ds, n, (uint64_t *)dout, (uint32_t *)((char *)dout + PB),
                         dw, wb);
     if (rc) return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(out_affine, dout, PB, hipMemcpyDeviceToHost, ctx->stream));
-    ZKLC_HIP(ctx, hipMemcpyAsync(out_is_infinity, (char *)dout + PB, 4, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, zklc_readback_async(out_affine, dout, PB, ctx->stream));
+    ZKLC_HIP(ctx, zklc_readback_async(out_is_infinity, (char *)dout + PB, 4, ctx->stream));
     ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }

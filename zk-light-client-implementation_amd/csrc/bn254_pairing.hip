@@ -121,8 +121,8 @@ extern "C" int32_t zklc_bn254_pairing_check(zklc_ctx *ctx, const uint64_t *g1, c
     if ((rc = zklc_bn254_pairing_check_dev(ctx, ctx->stream, (const uint64_t *)d1, (const uint64_t *)d2, k, batch, (uint32_t *)dr,
                                            gt_out ? (uint64_t *)dg : nullptr)))
         return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(is_one, dr, (size_t)batch * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (gt_out) ZKLC_HIP(ctx, hipMemcpyAsync(gt_out, dg, (size_t)batch * 384, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, zklc_readback_async(is_one, dr, (size_t)batch * 4, ctx->stream));
+    if (gt_out) ZKLC_HIP(ctx, zklc_readback_async(gt_out, dg, (size_t)batch * 384, ctx->stream));
     ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }

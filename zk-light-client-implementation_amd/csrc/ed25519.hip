@@ -79,7 +79,7 @@ extern "C" int32_t zklc_ed25519_verify_batch(zklc_ctx *ctx, const uint8_t *pks, 
     rc = zklc_ed25519_verify_batch_dev(ctx, ctx->stream, (const uint8_t *)dpk, (const uint8_t *)dsg, (const uint8_t *)dmsg,
                                        msg_len, msg_stride, n, (uint8_t *)dok);
     if (rc) return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, zklc_readback_async(ok, dok, n, ctx->stream));
     ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }
@@ -111,7 +111,7 @@ extern "C" int32_t zklc_sha512_batch(zklc_ctx *ctx, const uint8_t *in, uint32_t 
     if (in_bytes) ZKLC_HIP(ctx, hipMemcpyAsync(din, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     rc = zklc_sha512_batch_dev(ctx, ctx->stream, (const uint8_t *)din, stride, len, n, (uint8_t *)dout);
     if (rc) return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(out, dout, (size_t)n * 64, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, zklc_readback_async(out, dout, (size_t)n * 64, ctx->stream));
     ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }

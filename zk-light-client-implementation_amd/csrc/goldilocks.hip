@@ -952,7 +952,7 @@ extern "C" int32_t zklc_gl_ntt(zklc_ctx *ctx, uint64_t *data, uint32_t log_n, ui
     if ((rc = zklc_stage(ctx, 0, bytes, &d))) return rc;
     ZKLC_HIP(ctx, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = zklc_gl_ntt_dev(ctx, ctx->stream, (uint64_t *)d, log_n, batch, flags, coset_shift))) return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, zklc_readback_async(data, d, bytes, ctx->stream));
     ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }
@@ -970,7 +970,7 @@ extern "C" int32_t zklc_gl_lde(zklc_ctx *ctx, const uint64_t *coeffs, uint32_t l
     ZKLC_HIP(ctx, hipMemcpyAsync(din, coeffs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = zklc_gl_lde_dev(ctx, ctx->stream, (const uint64_t *)din, log_n, rate_bits, batch, coset_shift, (uint64_t *)dout, flags)))
         return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, zklc_readback_async(out, dout, out_bytes, ctx->stream));
     ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }
@@ -985,7 +985,7 @@ extern "C" int32_t zklc_poseidon_gl_permute(zklc_ctx *ctx, uint64_t *states, uin
     if ((rc = zklc_stage(ctx, 0, bytes, &d))) return rc;
     ZKLC_HIP(ctx, hipMemcpyAsync(d, states, bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = zklc_poseidon_gl_permute_dev(ctx, ctx->stream, (uint64_t *)d, n))) return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(states, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, zklc_readback_async(states, d, bytes, ctx->stream));
     ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }
@@ -1003,7 +1003,7 @@ extern "C" int32_t zklc_gl_merkle_commit(zklc_ctx *ctx, const uint64_t *mat, uin
     ZKLC_HIP(ctx, hipMemcpyAsync(dm, mat, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = zklc_gl_merkle_commit_dev(ctx, ctx->stream, (const uint64_t *)dm, stride, log_leaves, width, cap_height, (uint64_t *)dt)))
         return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(tree_out, dt, tree_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, zklc_readback_async(tree_out, dt, tree_bytes, ctx->stream));
     ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }

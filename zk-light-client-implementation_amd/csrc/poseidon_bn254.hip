@@ -140,7 +140,7 @@ extern "C" int32_t zklc_poseidon_bn254_permute(zklc_ctx *ctx, uint64_t *states, 
     if ((rc = zklc_stage(ctx, 0, bytes, &d))) return rc;
     ZKLC_HIP(ctx, hipMemcpyAsync(d, states, bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = zklc_poseidon_bn254_permute_dev(ctx, ctx->stream, (uint64_t *)d, n))) return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(states, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, zklc_readback_async(states, d, bytes, ctx->stream));
     ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }
@@ -199,7 +199,7 @@ extern "C" int32_t zklc_bn254_merkle_commit(zklc_ctx *ctx, const uint64_t *mat, 
     ZKLC_HIP(ctx, hipMemcpyAsync(dm, mat, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = zklc_bn254_merkle_commit_dev(ctx, ctx->stream, (const uint64_t *)dm, stride, log_leaves, width, cap_height, (uint64_t *)dt)))
         return rc;
-    ZKLC_HIP(ctx, hipMemcpyAsync(tree_out, dt, tree_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZKLC_HIP(ctx, zklc_readback_async(tree_out, dt, tree_bytes, ctx->stream));
     ZKLC_HIP(ctx, zklc_stream_wait(ctx->stream));
     return ZKLC_OK;
 }
