@@ -72,7 +72,7 @@ def test_compact_line_of_a_full_report():
 
 
 def test_committed_line_of_this_round():
-    path = os.path.join(ROOT, "profiles", "r06h_bench_driver_cmd_line.json")
+    path = os.path.join(ROOT, "profiles", "r06x_bench_driver_cmd_line.json")
     if not os.path.exists(path):
         pytest.skip("no GPU run of this round committed yet")
     text = open(path).read().strip().splitlines()
@@ -84,7 +84,9 @@ def test_committed_line_of_this_round():
     # must not hold an outlier block (the 20 s collector stall of round 2)
     mid = sorted(b["per_step_s"][3:-1])
     assert mid[-1] < 1.35 * mid[len(mid) // 2], "no outlier block"
-    assert b["gpu"]["busy_pct"] > 90 and b["host_cores_busy"] < 3.0
+    # with the read-backs settled the blocks of a run are alike and the chip is never without work
+    assert mid[-1] < 1.06 * mid[0] and b["gpu"]["busy_pct"] > 98 and b["host_cores_busy"] < 3.0
+    assert j["value"] > 0.21 and 0.8 < j["roofline"]["block"]["frac_of_issue_limit"] < 1
     assert j["stages"]["c5"]["validators"] == 1000 and j["roofline"]["block"]["frac_of_issue_limit"] < 1
 
 
