@@ -9,8 +9,8 @@ proof bytes); gnark v0.9.1 backend/groth16/bn254/prove.go is un-vendored (go.mod
   GPU     Ar  = alpha + sum_i w_i A_i + r delta                       one G1 MSM (alpha, delta among the bases)        stream 1
           Bs1 = beta1 + sum_i w_i B1_i + s delta1                     one G1 MSM                                        stream 1
           Bs  = beta  + sum_i w_i B_i + s delta                       one G2 MSM                                        stream 2
-          Krs = [sum_priv w_i K_i + sum_j h_j Z_j] + s Ar + r Bs1 - r s delta1
-                the bracket: one G1 MSM over fixed bases, after computeH on stream 3; the rest: a four-point MSM at the end
+          Krs = sum_priv w_i K_i + sum_j h_j Z_j + s Ar + r Bs1 - r s delta1
+                the K sum: one G1 MSM on stream 1; the Z sum: one G1 MSM after computeH on stream 3; the rest: a five-point MSM at the end
           every base is a fixed point of the key: ZKLC_GROTH16_FIXED=1 runs the four big sums over fixed-base tables (measured: no gain)
   host    the eight coordinates out of Montgomery form -> the uint256[8] / 256-byte / compressed encodings (zklc_amd/formats.py)
 The proving key arrives as affine points in gnark-crypto's memory layout (what a cgo shim hands over) and stays
@@ -104,11 +104,14 @@ class Groth16Prover:
         self.fixed = os.environ.get("ZKLC_GROTH16_FIXED", "0") == "1"
         self.n_priv = K.shape[0]
         ops = {"A": (np.concatenate([A, al, de1]), 1), "B1": (np.concatenate([B1, be1, de1]), 1),
-               "B2": (np.concatenate([B2, be2, de2]), 2), "KZ": (np.concatenate([K, Z]), 1)}
+               "B2": (np.concatenate([B2, be2, de2]), 2), "K": (K, 1), "Z": (Z, 1)}
         self.delta1_words = de1.reshape(8).copy()
         self.n_op = {k: v[0].shape[0] for k, v in ops.items()}
         self.d_op = {}
         for name, (arr, group) in ops.items():
+            if arr.shape[0] == 0:                                 # no private wire: the K sum is skipped
+                self.d_op[name] = None
+                continue
             d_pts = up(arr)
             if self.fixed:
                 self.d_op[name] = ctx.bn254_msm_fixed_table(d_pts, arr.shape[0], group, stream=ctx.stream_ptr())
@@ -118,25 +121,24 @@ class Groth16Prover:
                 self.d_op[name] = d_pts
         lib = ctx._lib
         wsb = lambda fn, k: torch.empty(int(fn(k)), dtype=torch.uint8, device=self.dev)
-        # one workspace per stream: A and B1 run one after the other on ctx, B2 on ctx2, computeH and K / Z on ctx3
-        self.ws1 = wsb(lib.zklc_bn254_g1_msm_workspace_bytes, max(self.n_op["A"], self.n_op["B1"]))
+        # one workspace per stream: A, B1 and K run one after the other on ctx, B2 on ctx2, computeH and Z on ctx3
+        self.ws1 = wsb(lib.zklc_bn254_g1_msm_workspace_bytes, max(self.n_op["A"], self.n_op["B1"], self.n_op["K"]))
         self.ws2 = wsb(lib.zklc_bn254_g2_msm_workspace_bytes, self.n_op["B2"])
-        self.ws3 = wsb(lib.zklc_bn254_g1_msm_workspace_bytes, self.n_op["KZ"])
+        self.ws3 = wsb(lib.zklc_bn254_g1_msm_workspace_bytes, self.n_op["Z"])
         self.wsn = torch.empty(int(lib.zklc_bn254_fr_ntt_workspace_bytes(self.log_n)), dtype=torch.uint8, device=self.dev)
         self.den = np.array(fr_to_mont_words(pow((pow(5, self.n, R) - 1) % R, R - 2, R)), dtype=np.uint64)
         # resident operands of the Montgomery -> regular conversion of h (a pointwise (a * 1_raw - 0) * 1: see prove_words)
         self.one_raw = torch.zeros((self.n, 4), dtype=torch.int64, device=self.dev)
         self.one_raw[:, 0] = 1
         self.zero = torch.zeros((self.n, 4), dtype=torch.int64, device=self.dev)
-        # the scalars of the K / Z sum: [private wires | h_0 .. h_(n-2)], assembled in place (no concatenation per proof)
-        self.sc_k = torch.zeros((self.n_op["KZ"], 4), dtype=torch.int64, device=self.dev)
-        # Three streams per proof (round 6): the sums are independent of each other once Krs is split into its fixed part and
-        # s Ar + r Bs1 - r s delta1, so A and B1 (ctx), B2 (ctx2: its slice kernel keeps one wave per SIMD and its serial tail a
-        # handful of lanes, both of which the G1 kernels fill) and computeH followed by the K / Z sum (ctx3) run side by side; the
-        # latency-bound tails of one sum (segment / window / final kernels, ~1.6 ms each) lie under the slice kernels of the others.
+        # Three streams per proof (round 6): the sums are independent of each other once Krs is split into sum w_i K_i, sum h_j Z_j
+        # and s Ar + r Bs1 - r s delta1, so A, B1 and the K sum (ctx), B2 (ctx2: its slice kernel keeps one wave per SIMD and its
+        # serial tail a handful of lanes, both of which the G1 kernels fill) and computeH followed by the Z sum (ctx3) run side by
+        # side -- only the Z sum (2^22 of the 2^23 points of gnark's Krs sum) waits for h; the latency-bound tails of one sum
+        # (segment / window / final kernels, ~1.6 ms each) lie under the slice kernels of the others.
         from .context import Context
         self.ctx2 = Context(ctx.device_id)
-        self.ctx3 = Context(ctx.device_id)
+        self.ctx3 = Context(ctx.device_id)           # (the device's high priority for this stream: measured, no effect -- profiles/r06z2_*)
         torch.cuda.synchronize(self.dev)
         self.last_ms = {}
 
@@ -220,33 +222,32 @@ class Groth16Prover:
         pick = lambda keep: d_w if keep is None else d_w[torch.from_numpy(np.nonzero(keep)[0]).to(self.dev)]
         sc_a = torch.cat([pick(self.keep_a), up(tail(1, r))])
         sc_b = torch.cat([pick(self.keep_b), up(tail(1, s))])
-        self.sc_k[:self.n_priv] = d_w[1 + self.n_public:]
-        outs = {k: torch.zeros(16 if k == "B2" else 8, dtype=torch.int64, device=self.dev) for k in ("A", "B1", "B2", "KZ")}
-        infs = {k: torch.zeros(1, dtype=torch.int32, device=self.dev) for k in outs}
+        sc_kp = d_w[1 + self.n_public:]                        # the private wires: a view, no copy
+        outs = {k: torch.zeros(16 if k == "B2" else 8, dtype=torch.int64, device=self.dev) for k in ("A", "B1", "B2", "K", "Z")}
+        infs = {k: torch.ones(1, dtype=torch.int32, device=self.dev) for k in outs}      # 1 = infinity until a sum has run
         tsync()
         t1 = time.perf_counter()
-        # stream 2: Bs = beta + sum_i w_i B_i + s delta (G2);  stream 1: Ar, then Bs1
+        # stream 2: Bs = beta + sum_i w_i B_i + s delta (G2);  stream 1: Ar, then Bs1, then the K part of Krs
         self._msm(self.ctx2, "B2", sc_b, outs["B2"], infs["B2"], self.ws2, group=2)
         self._msm(self.ctx, "A", sc_a, outs["A"], infs["A"], self.ws1)
         self._msm(self.ctx, "B1", sc_b, outs["B1"], infs["B1"], self.ws1)
-        # stream 3: computeH (the three operands cross PCIe while the sums above run), then the K / Z part of Krs
+        if self.n_priv:
+            self._msm(self.ctx, "K", sc_kp, outs["K"], infs["K"], self.ws1)
+        # stream 3: computeH (the three operands cross PCIe while the sums above run), then the Z part of Krs straight from h
         d = [up(x) for x in abc_mont]
         tsync()
         self._compute_h_enqueue(d, self.ctx3)
-        self.ctx3.synchronize()
-        self.sc_k[self.n_priv:] = d[0][:self.n - 1]
-        tsync()
         t2 = time.perf_counter()
-        self._msm(self.ctx3, "KZ", self.sc_k, outs["KZ"], infs["KZ"], self.ws3)
+        self._msm(self.ctx3, "Z", d[0], outs["Z"], infs["Z"], self.ws3)        # the first n - 1 coefficients of h
         self.ctx.synchronize()
         self.ctx3.synchronize()
         if int(infs["A"][0]) or int(infs["B1"][0]):
             raise ValueError("groth16: a proof element is the point at infinity (degenerate key or witness)")
-        # Krs = (sum_priv w_i K_i + sum_j h_j Z_j) + s Ar + r Bs1 - r s delta1: four points, through the same kernels
+        # Krs = sum_priv w_i K_i + sum_j h_j Z_j + s Ar + r Bs1 - r s delta1: five points, through the same kernels
         h = lambda t: t.cpu().numpy().view(np.uint64)
-        kz = np.zeros(8, np.uint64) if int(infs["KZ"][0]) else h(outs["KZ"])
-        pts4 = np.stack([kz, h(outs["A"]), h(outs["B1"]), self.delta1_words])
-        k_w, k_inf = self.ctx.bn254_g1_msm(pts4, tail(1, s, r, (R - r * s % R) % R))
+        part = lambda k: np.zeros(8, np.uint64) if int(infs[k][0]) else h(outs[k])
+        pts5 = np.stack([part("K"), part("Z"), h(outs["A"]), h(outs["B1"]), self.delta1_words])
+        k_w, k_inf = self.ctx.bn254_g1_msm(pts5, tail(1, 1, s, r, (R - r * s % R) % R))
         self.ctx2.synchronize()
         t3 = time.perf_counter()
         if k_inf or int(infs["B2"][0]):
@@ -254,8 +255,8 @@ class Groth16Prover:
         a_w, b_w = h(outs["A"]), h(outs["B2"])
         f = fp_from_mont_words
         proof = [f(a_w[0:4]), f(a_w[4:8]), f(b_w[4:8]), f(b_w[0:4]), f(b_w[12:16]), f(b_w[8:12]), f(k_w[0:4]), f(k_w[4:8])]
-        self.last_ms = {"witness_upload_and_scalars": (t1 - t0) * 1e3, "compute_h_beside_A_B1_B2": (t2 - t1) * 1e3,
-                        "kz_and_tails": (t3 - t2) * 1e3, "total": (t3 - t0) * 1e3, "fixed_base": self.fixed}
+        self.last_ms = {"witness_upload_and_scalars": (t1 - t0) * 1e3, "operands_of_compute_h_cross_pcie_beside_A_B1_K_B2": (t2 - t1) * 1e3,
+                        "compute_h_z_and_tails": (t3 - t2) * 1e3, "total": (t3 - t0) * 1e3, "fixed_base": self.fixed}
         return proof
 
 
