@@ -368,7 +368,8 @@ def test_full_block_proof_on_a_mainnet_window(zctx, block_prover):
 
 QUOTIENT_VARIANTS = [{}, {"ZKLC_P2_POSEIDON_GATE": "plain"}, {"ZKLC_P2_POSEIDON_GATE": "lazy"}, {"ZKLC_P2_POSEIDON_GATE": "lazy1"},
                      {"ZKLC_P2_ADDMANY": "pergate"}, {"ZKLC_P2_ADDMANY": "multi"}, {"ZKLC_P2_GATE_LAUNCH": "single"},
-                     {"ZKLC_P2_QUOTIENT": "fused"}, {"ZKLC_MERKLE_FUSED": "0"}]
+                     {"ZKLC_P2_QUOTIENT": "fused"}, {"ZKLC_MERKLE_FUSED": "0"},
+                     {"ZKLC_NTT_ZSKIP": "0"}, {"ZKLC_SETTLED_COPIES": "0"}]        # round 6: the general first LDE group, parked read-backs
 
 _VARIANT_CHILD = r'''
 import hashlib, sys
