@@ -625,7 +625,10 @@ class BlockPipeline:
         the interpreter's thread switch interval is 0.5 ms instead of 5 ms (ZKLC_SWITCH_INTERVAL_MS; 0 = leave it): a worker that
         returns from a proof waits up to one interval for the GIL while another thread runs Python -- a 2 ms sleeper overslept
         0.34 s per block in total at 5 ms and 0.07 s at 0.5 ms; the block time moved inside the run-to-run noise (mid-run mean
-        5.31 -> 5.17 s, profiles/r06s_switch_interval_ab.txt)."""
+        5.31 -> 5.17 s, profiles/r06s_switch_interval_ab.txt).
+        A host that streams without end should move its long-lived objects out of the collector's sight once after start-up
+        (gc.freeze(), as bench.py does: the circuits are tens of millions of objects) and run a full collection when IT chooses:
+        objects that survive the per-block collection are only looked at again by a full one."""
         import gc
         mode, sw = os.environ.get("ZKLC_STREAM_GC", "block"), os.environ.get("ZKLC_SWITCH_INTERVAL_MS", "0.5")
         sw = sw if float(sw) > 0 else None
