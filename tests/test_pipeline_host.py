@@ -248,7 +248,5 @@ def test_prove_stream_host_policy_is_scoped_to_the_stream(monkeypatch):
     seen.clear()
     monkeypatch.setenv("ZKLC_STREAM_GC", "auto")
     monkeypatch.setenv("ZKLC_SWITCH_INTERVAL_MS", "0")
-    inside = []
-    real_new_state = None
     p, log, res, done, err = _fake_stream(2, monkeypatch=monkeypatch)
     assert err is None and not [s for s in seen if s[0] == (1,)] and gc.isenabled() and sys.getswitchinterval() == sw0
